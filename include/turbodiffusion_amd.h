@@ -1,0 +1,175 @@
+/*
+ * turbodiffusion_amd.h — C-ABI of libturbodiffusion_amd.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the TurboDiffusion denoising hot path.  Every entry point takes
+ * raw DEVICE pointers, sizes and an explicit HIP stream (void* == hipStream_t), never
+ * allocates, never synchronises, and returns an int status (0 == TD_OK).  On failure the
+ * reason is retrievable with td_last_error().  Unlike the reference's pybind module,
+ * an unsupported shape is an ERROR, not a silent no-op (ops/gemm/launch.hpp:34-35).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/turbodiffusion):
+ *   quant_cuda      ops/quant/quant.cu:28-75      -> td_quant_i8_block128
+ *   gemm_cuda       ops/gemm/gemm.cu:27-72        -> td_gemm_w8a8
+ *   rms_norm_cuda   ops/norm/rmsnorm.cu:12-59     -> td_rmsnorm
+ *   layer_norm_cuda ops/norm/layernorm.cu:10-62   -> td_layernorm (+ fused modulate)
+ *   Triton norms    ops/core.py:96-136,193-335    -> td_rmsnorm / td_layernorm
+ *   AdaLN glue      rcm/networks/wan2pt1.py:404-413 -> td_layernorm (modulate), td_gated_residual
+ *   rope_apply      rcm/networks/wan2pt1.py:156-178 -> td_qk_norm_rope
+ *   SLA/utils.py get_block_map :55-67, mean_pool :43-52 -> td_sla_pool, td_sla_topk
+ *   spas_sage_attn.utils.get_vanilla_qk_quant (SLA/core.py:201-203) -> td_sage_quant
+ *   spas_sage_attn._qattn.qk_int8_sv_f16_*_block_sparse_attn (SLA/core.py:214)
+ *                                              -> td_attn_i8 (sparse via LUT / dense)
+ *   Triton _attn_fwd SLA/kernel.py:21-82       -> td_attn_bf16 (sparse via LUT / dense)
+ *   SLA linear branch SLA/core.py:243-253      -> td_sla_linear_kv, td_sla_linear_out
+ *
+ * Tensor conventions: row-major contiguous unless a stride argument says otherwise;
+ * 16-byte aligned base pointers; dtype codes below.
+ */
+#ifndef TURBODIFFUSION_AMD_H
+#define TURBODIFFUSION_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TD_ABI_VERSION 1
+
+/* status codes */
+#define TD_OK 0
+#define TD_ERR_INVALID 1     /* bad argument (null pointer, negative size, ...) */
+#define TD_ERR_UNSUPPORTED 2 /* shape / dtype this build cannot run (e.g. k % 128 != 0) */
+#define TD_ERR_LAUNCH 3      /* HIP launch error */
+
+/* dtype codes */
+#define TD_F16 0
+#define TD_BF16 1
+#define TD_F32 2
+
+/* GEMM epilogues */
+#define TD_EPI_NONE 0
+#define TD_EPI_GELU_TANH 1
+
+typedef void* td_stream_t; /* hipStream_t */
+
+int td_abi_version(void);
+const char* td_last_error(void);
+
+/* ---- a16: per-128x128-block INT8 quantiser (quant_cuda, ops/quant/quant.cu:28-71) ----
+ * x [m,n] f16|bf16 -> q [m,n] int8, s [ceil(m/128), ceil(n/128)] f32.
+ * amax = max(1e-8, max|x|) over the block's valid elements; q = sat_s8(rne(x*(128/amax)));
+ * s = amax/128 (quant.hpp:91-98). Requires n % 8 == 0. */
+int td_quant_i8_block128(const void* x, int dtype, int8_t* q, float* s, int64_t m, int64_t n,
+                         td_stream_t stream);
+
+/* ---- a17: block-scaled W8A8 GEMM (gemm_cuda, ops/gemm/gemm.cu:27-68) ----
+ * d[m,n] = cast( sum_kb fma(float(sum_{k in kb} a[m,k]*b[n,k]), a_s[m/128,kb]*b_s[n/128,kb], acc) )
+ * then, matching Int8Linear.forward (ops/core.py:408-412): + bias (rounded again in the
+ * output dtype) and optionally GELU-tanh (the FFN activation, wan2pt1.py:375).
+ * a [m,k] int8, a_s [ceil(m/128), k/128] f32, b [n,k] int8, b_s [ceil(n/128), k/128] f32,
+ * bias [n] (out dtype) or NULL, d [m,n] f16|bf16 with row stride ldd (elements).
+ * Requires k % 128 == 0 and n % 8 == 0; otherwise TD_ERR_UNSUPPORTED. */
+int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                 const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
+                 int64_t k, int64_t ldd, td_stream_t stream);
+
+/* ---- a5: RMSNorm over the last dim (ops/core.py:139-191; rms_norm_cuda) ----
+ * y = cast((x*rsqrt(mean(x^2)+eps))*w), fp32 math. x [m,n] in_dtype (f32|bf16|f16),
+ * w [n] f32, y [m,n] out_dtype. Requires n % 8 == 0, n <= 8192. */
+int td_rmsnorm(const void* x, int in_dtype, const float* w, void* y, int out_dtype, float eps,
+               int64_t m, int64_t n, td_stream_t stream);
+
+/* ---- a6 + a7: LayerNorm (+ fused AdaLN modulate) (ops/core.py:380-386; wan2pt1.py:404,411) ----
+ * xn = cast_out((x-mean)*rstd [*w + b])            (w,b f32 [n] or NULL,NULL)
+ * if scale != NULL: y = cast_out(float(xn)*(1+scale[bi]) + shift[bi]) with
+ *   bi = row / rows_per_batch, scale/shift f32 [batch, n]   (the two roundings of the reference)
+ * x [m,n] in_dtype, y [m,n] out_dtype. Requires n % 8 == 0, n <= 8192. */
+int td_layernorm(const void* x, int in_dtype, const float* w, const float* b, const float* scale,
+                 const float* shift, int64_t rows_per_batch, void* y, int out_dtype, float eps,
+                 int64_t m, int64_t n, td_stream_t stream);
+
+/* ---- a7: gated residual  x = x + y*gate.type_as(x)  (wan2pt1.py:405-406,412-413) ----
+ * x,y [m,n] f16|bf16 (in place on x), gate f32 [batch,n] or NULL (plain x += y, :410).
+ * Rounding order of the reference: t = round(y*round(gate)); x = round(x + t). */
+int td_gated_residual(void* x, const void* y, const float* gate, int64_t rows_per_batch,
+                      int dtype, int64_t m, int64_t n, td_stream_t stream);
+
+/* ---- a3 + a8: q/k RMSNorm over the full model dim + interleaved RoPE + head-major relayout ----
+ * (WanSelfAttention.forward wan2pt1.py:261-269; FastRMSNorm ops/core.py:441-442; rope_apply :156-178)
+ * src [L, >=dim] 16-bit with row stride ld_src (elements) -> dst [H, L, D] (dim = H*D).
+ * xn = cast(rmsnorm(x)*w); if cos != NULL: (x0,x1) -> cast(x0*c - x1*s, x0*s + x1*c) with
+ * cos/sin f32 [L, D/2].  w may be NULL (no norm: plain relayout, used for V / cross K,V). */
+int td_qk_norm_rope(const void* src, int64_t ld_src, const float* w, const float* cosv,
+                    const float* sinv, void* dst, int dtype, float eps, int64_t L, int H, int D,
+                    td_stream_t stream);
+
+/* ---- V tile transpose for the PV MFMA: v 16-bit, element (h,l,d) at v + h*stride_h + l*stride_l + d
+ * (so both [H,L,D] and a column slice of a [L, 3*dim] GEMM output work) ->
+ * vt [H, ceil(L/64), D, 64] out_dtype, keys of each 16-group stored in MFMA operand order
+ * (0-3,8-11,4-7,12-15), tail keys zero-filled.  Replaces v.to(float16) (SLA/core.py:213)
+ * and spas_sage_attn._fused.transpose_pad_permute_cuda (:221). D must be 128. */
+int td_v_transpose(const void* v, int in_dtype, int64_t stride_h, int64_t stride_l, void* vt,
+                   int out_dtype, int64_t L, int H, int D, td_stream_t stream);
+
+/* ---- a11/a13: per-head sequence mean of K  (k.mean(dim=-2), SLA/core.py:197, utils.py:56) ----
+ * k [H, L, D] 16-bit -> km [H, D] same dtype (fp32 accumulate, one rounding). D == 128.
+ * ws: f32 workspace [H, 64, D] (deterministic two-stage sum, no atomics). */
+int td_seq_mean(const void* k, void* km, float* ws, int dtype, int64_t L, int H, int D,
+                td_stream_t stream);
+
+/* ---- a11 + a13 fused pass over Q or K [H, L, D] (D == 128):
+ *  - block mean pool (mean_pool, SLA/utils.py:43-52) of x (Q) or of cast(x - km) (K, smooth-K
+ *    utils.py:56) with block `pool_blk`, fp32 sum / valid count, cast to dtype -> pooled [H, nb, D]
+ *  - per-block INT8 quantisation (get_vanilla_qk_quant, SLA/core.py:201-203) with block
+ *    `pool_blk`: xf = float(x) - float(km); scale = max|xf|/127 + 1e-7;
+ *    q = trunc(xf/scale + 0.5*sign)  -> xq [H, L, D] int8, xs [H, nb] f32.
+ * km may be NULL (Q). pooled or xq/xs may be NULL to skip that output.
+ * pool_blk in {64, 128}. */
+int td_sage_quant_pool(const void* x, const void* km, int dtype, int pool_blk, void* pooled,
+                       int8_t* xq, float* xs, int64_t L, int H, int D, td_stream_t stream);
+
+/* ---- a11: pooled score + top-k block selection (SLA/utils.py:59-66) ----
+ * score[h,i,j] = cast(sum_d pq[h,i,d]*pk[h,j,d]) (16-bit rounding like the reference's
+ * bf16 matmul); select the `topk` largest per row (ties -> lower index), write ascending
+ * block ids to lut [H, Qb, topk] int32. Kb <= 2048. */
+int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb, int Kb,
+                int D, int topk, td_stream_t stream);
+
+/* ---- a13 / a9: SageAttention INT8-QK, FP16-PV, fp32 softmax+accumulate ----
+ * q_i8 [H, L, 128] int8, q_s [H, ceil(L/128)], k_i8 [H, Lk, 128] int8, k_s [H, ceil(Lk/64)],
+ * vt from td_v_transpose (f16) [H, ceil(Lk/64), 128, 64].
+ * lut [H, Qb, nsel] ascending K-block ids, or NULL for dense attention (all K blocks).
+ * o: 16-bit, element (h, l, d) at o + h*o_stride_h + l*o_stride_l + d.
+ * sm_scale: softmax scale (D^-0.5). */
+int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+               const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
+               int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
+               int H, td_stream_t stream);
+
+/* ---- a12 / a9 / a4: 16-bit QK attention (SLA Triton arithmetic; dense cross-attention) ----
+ * q [H, L, 128], k [H, Lk, 128] dtype (bf16|f16); vt [H, ceil(Lk/64), 128, 64] same dtype;
+ * P is rounded to dtype before P@V (SLA/kernel.py:68). lut as above. */
+int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
+               int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+               int64_t Lk, int H, td_stream_t stream);
+
+/* ---- a14: linear-attention branch (SLA/core.py:243-253, feature_map = softmax) ----
+ * pass 1: ck = cast(softmax_D(k)); kvsum[h] = cast(ck^T @ v) ; ksum[h] = cast(sum_L ck)
+ *   k [H, L, D] dtype; vt = the V^T tiles of td_v_transpose (vt_dtype); ws_kv f32 [H,16,D,D] and
+ *   ws_ks f32 [H,16,D] are scratch (partials summed in order: deterministic);
+ *   outputs kvsum_t [H, D(d2), D(d1)] dtype (TRANSPOSED: the A operand of pass 2), ksum [H, D]. */
+int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
+                     float* ws_ks, void* kvsum_t, void* ksum, int64_t L, int H, int D,
+                     td_stream_t stream);
+/* pass 2: cq = cast(softmax_D(q)); o_l = cast(cast(cq@kvsum)/cast(1e-5 + cast(sum_D cast(cq*ksum))));
+ *   o_l = cast(o_l @ cast(Wp)^T + cast(bp)) (proj_l under autocast); o[h,l,:] = cast(o[h,l,:] + o_l)
+ *   (o addressed with the same strides as td_attn_*; updated in place).
+ *   q [H, L, D] dtype; Wp [D, D] f32 (nn.Linear weight [out,in]), bp [D] f32. */
+int td_sla_linear_out(const void* q, int dtype, const void* kvsum_t, const void* ksum,
+                      const float* wp, const float* bp, void* o, int64_t o_stride_h,
+                      int64_t o_stride_l, int64_t L, int H, int D, td_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TURBODIFFUSION_AMD_H */

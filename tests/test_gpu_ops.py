@@ -1,0 +1,138 @@
+"""-m gpu parity tests: HIP kernels (through the C-ABI) vs the CPU oracle — linear/norm operators."""
+import pytest
+import torch
+
+from oracle import ops_ref as O
+from tests.util import act_like, rel_l2, ulp_diff_bf16
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def K():
+    from turbodiffusion_amd import kernels
+    return kernels
+
+
+@pytest.mark.parametrize("m,n", [(128, 128), (1, 8), (300, 256), (1000, 1536), (257, 8960 // 4), (5, 136)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_quant_bit_exact(K, m, n, dtype):
+    x = act_like(m, n, dtype, seed=m * 7 + n)
+    q_ref, s_ref = O.quant_block128(x)
+    q, s = K.quant_i8_block128(x.to(DEV))
+    assert torch.equal(s.cpu(), s_ref), "scales must be bit-exact"
+    assert torch.equal(q.cpu(), q_ref), "int8 codes must be bit-exact"
+
+
+def test_quant_edge_cases(K):
+    # all-zero block -> amax clamps to 1e-8; saturation: +amax -> 127, -amax -> -128
+    x = torch.zeros(256, 256, dtype=torch.bfloat16)
+    x[130, 5] = 3.0
+    x[131, 6] = -3.0
+    q, s = K.quant_i8_block128(x.to(DEV))
+    q_ref, s_ref = O.quant_block128(x)
+    assert torch.equal(q.cpu(), q_ref) and torch.equal(s.cpu(), s_ref)
+    assert q[130, 5].item() == 127 and q[131, 6].item() == -128
+    assert s[0, 0].item() == pytest.approx(1e-8 / 128, rel=1e-6)
+
+
+def test_quant_rejects_bad_shape(K):
+    from turbodiffusion_amd._lib import TurboDiffusionAMDError
+    with pytest.raises(TurboDiffusionAMDError):
+        K.quant_i8_block128(torch.zeros(4, 12, dtype=torch.bfloat16, device=DEV))  # n % 8 != 0
+
+
+@pytest.mark.parametrize("m,n,k", [(128, 128, 128), (200, 384, 512), (1000, 1536, 1536), (77, 136, 256),
+                                   (512, 256, 8960 // 2 - 8960 // 2 % 128)])
+@pytest.mark.parametrize("bias,gelu", [(False, False), (True, False), (True, True)])
+def test_gemm_w8a8(K, m, n, k, bias, gelu):
+    x = act_like(m, k, torch.bfloat16, seed=m + n + k, outliers=False)
+    w = (torch.randn(n, k, generator=torch.Generator().manual_seed(k)) / k ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(n, generator=torch.Generator().manual_seed(3)) * 0.1).to(torch.bfloat16) if bias else None
+    xq, xs = O.quant_block128(x)
+    wq, ws = O.quant_block128(w)
+    ref = O.gemm_w8a8(xq, xs, wq, ws, torch.bfloat16, bias=b, gelu_tanh=gelu)
+    out = K.gemm_w8a8(xq.to(DEV), xs.to(DEV), wq.to(DEV), ws.to(DEV), torch.bfloat16,
+                      bias=None if b is None else b.to(DEV), gelu_tanh=gelu)
+    ulp = ulp_diff_bf16(out, ref)
+    assert ulp.max().item() <= 1, f"max ulp {ulp.max().item()}"
+    assert (ulp > 0).float().mean().item() < 0.01
+    # and against the fp32 matmul of the de-quantised operands (rel-L2 <= 1e-2)
+    if not gelu:
+        deq = (x.float() @ w.float().t()) + (0 if b is None else b.float())
+        assert rel_l2(out, deq) < 2e-2
+
+
+def test_gemm_rejects_bad_k(K):
+    from turbodiffusion_amd._lib import TurboDiffusionAMDError
+    a = torch.zeros(128, 192, dtype=torch.int8, device=DEV)
+    s = torch.ones(1, 1, device=DEV)
+    with pytest.raises((TurboDiffusionAMDError, AssertionError)):
+        K.gemm_w8a8(a, s, a, s)
+
+
+@pytest.mark.parametrize("m,n", [(7, 1536), (300, 256), (64, 5120), (33, 1024), (5, 8)])
+def test_rmsnorm(K, m, n):
+    x = act_like(m, n, torch.bfloat16, seed=n)
+    w = torch.rand(n, generator=torch.Generator().manual_seed(1)) + 0.5
+    ref = O.rmsnorm_fast(x, w, 1e-6)
+    out = K.rmsnorm(x.to(DEV), w.to(DEV), 1e-6)
+    assert ulp_diff_bf16(out, ref).max().item() <= 1
+    # fp32 in / fp32 out (the reference's API-level contract, ops/core.py:139)
+    out32 = K.rmsnorm(x.float().to(DEV), w.to(DEV), 1e-6)
+    ref32 = O.rmsnorm_fast(x.float(), w, 1e-6)
+    torch.testing.assert_close(out32.cpu(), ref32, rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("m,n", [(7, 1536), (300, 256), (64, 5120)])
+@pytest.mark.parametrize("affine", [False, True])
+@pytest.mark.parametrize("mod", [False, True])
+def test_layernorm_modulate(K, m, n, affine, mod):
+    g = torch.Generator().manual_seed(n + m)
+    x = act_like(m, n, torch.bfloat16, seed=n + 1)
+    w = (torch.rand(n, generator=g) + 0.5) if affine else None
+    b = (torch.randn(n, generator=g) * 0.1) if affine else None
+    ref = O.layernorm_fast(x, w, b, 1e-6)
+    scale = shift = None
+    if mod:
+        scale = torch.randn(1, n, generator=g) * 0.3
+        shift = torch.randn(1, n, generator=g) * 0.3
+        ref = O.modulate(ref, scale, shift)
+    out = K.layernorm(x.to(DEV), None if w is None else w.to(DEV), None if b is None else b.to(DEV), 1e-6,
+                      None if scale is None else scale.to(DEV), None if shift is None else shift.to(DEV))
+    ulp = ulp_diff_bf16(out, ref)
+    # modulate amplifies a 1-ulp difference of the rounded norm output by (1+scale): allow 2 there
+    assert ulp.max().item() <= (2 if mod else 1), f"max ulp {ulp.max().item()}"
+    assert (ulp > 0).float().mean().item() < 0.02
+
+
+def test_gated_residual_bit_exact(K):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 1536, generator=g).bfloat16()
+    y = torch.randn(300, 1536, generator=g).bfloat16()
+    gate = torch.randn(1, 1536, generator=g)
+    ref = O.gated_residual(x, y, gate)
+    out = K.gated_residual_(x.clone().to(DEV), y.to(DEV), gate.to(DEV))
+    assert torch.equal(out.cpu(), ref)
+    ref2 = x + y
+    out2 = K.gated_residual_(x.clone().to(DEV), y.to(DEV), None)
+    assert torch.equal(out2.cpu(), ref2)
+
+
+@pytest.mark.parametrize("L,H", [(100, 2), (333, 12)])
+def test_qk_norm_rope(K, L, H):
+    D = 128
+    g = torch.Generator().manual_seed(L)
+    src = torch.randn(L, 3 * H * D, generator=g).bfloat16()
+    w = torch.rand(H * D, generator=g) + 0.5
+    freqs = O.rope_freqs(5, 9, 11, D)[:L] if L <= 495 else None
+    qn = O.rmsnorm_fast(src[:, : H * D], w, 1e-6)
+    ref = O.rope_apply(qn.view(1, L, H, D), freqs)[0].transpose(0, 1)  # [H, L, D]
+    cos, sin = torch.cos(freqs).float(), torch.sin(freqs).float()
+    out = K.qk_norm_rope(src.to(DEV), 0, H, D, w.to(DEV), cos.to(DEV), sin.to(DEV), 1e-6)
+    ulp = ulp_diff_bf16(out, ref.contiguous())
+    assert ulp.max().item() <= 2 and (ulp > 0).float().mean().item() < 0.02
+    # plain relayout of the V columns
+    v = K.qk_norm_rope(src.to(DEV), 2 * H * D, H, D, None, None, None, 1e-6)
+    assert torch.equal(v.cpu(), src[:, 2 * H * D:].view(L, H, D).transpose(0, 1))

@@ -1,0 +1,154 @@
+"""Per-kernel microbenchmark at BASELINE shapes (Wan2.1-1.3B 480p: L=32760, dim=1536, H=12, ffn=8960).
+
+    python tools/kbench.py [--only gemm,attn] [--iters 10] [--L 32760]
+
+Prints one line per kernel: time (HIP events on the launch stream), algorithmic GB/s or TFLOP/s,
+fraction of the MI355X roofline (HBM 8 TB/s, INT8 MFMA 5 POP/s dense, FP16 MFMA 2.5 PFLOP/s).
+"""
+import argparse
+import json
+import math
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from turbodiffusion_amd import kernels as K  # noqa: E402
+
+HBM, I8, F16 = 8.0e12, 5.0e15, 2.5e15
+
+
+def timeit(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        fn()
+    e1.record(st)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--L", type=int, default=32760)
+    ap.add_argument("--dim", type=int, default=1536)
+    ap.add_argument("--ffn", type=int, default=8960)
+    ap.add_argument("--topk", type=float, default=0.1)
+    ap.add_argument("--dense", action="store_true", help="also time dense attention (slow)")
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    dev = "cuda"
+    L, dim, ffn = args.L, args.dim, args.ffn
+    H, D = dim // 128, 128
+    res = []
+
+    def rep(name, t, bytes_=None, flops=None, peak_f=None):
+        r = {"kernel": name, "ms": round(t * 1e3, 4)}
+        if bytes_:
+            r["GBps"] = round(bytes_ / t / 1e9, 1)
+            r["hbm_frac"] = round(bytes_ / t / HBM, 3)
+        if flops:
+            r["TFLOPs"] = round(flops / t / 1e12, 1)
+            r["mfma_frac"] = round(flops / t / peak_f, 3)
+        print(json.dumps(r), flush=True)
+        res.append(r)
+
+    torch.manual_seed(0)
+    x = torch.randn(L, dim, device=dev).bfloat16()
+    if not only or "quant" in only:
+        t = timeit(lambda: K.quant_i8_block128(x), args.iters)
+        rep("quant_i8_block128 [L,dim]", t, bytes_=3 * L * dim)
+    if not only or "norm" in only:
+        sc = torch.randn(1, dim, device=dev)
+        t = timeit(lambda: K.layernorm(x, None, None, 1e-6, sc, sc), args.iters)
+        rep("layernorm+modulate [L,dim]", t, bytes_=4 * L * dim)
+        w = torch.ones(dim, device=dev)
+        t = timeit(lambda: K.rmsnorm(x, w, 1e-6), args.iters)
+        rep("rmsnorm [L,dim]", t, bytes_=4 * L * dim)
+        y = torch.randn_like(x)
+        t = timeit(lambda: K.gated_residual_(x, y, sc), args.iters)
+        rep("gated_residual [L,dim]", t, bytes_=6 * L * dim)
+    if not only or "gemm" in only:
+        xq, xs = K.quant_i8_block128(x)
+        for (n, k, nm) in ((dim, dim, "attn proj"), (3 * dim, dim, "fused qkv"), (ffn, dim, "ffn1"), (dim, ffn, "ffn2")):
+            a = torch.randn(L, k, device=dev).bfloat16()
+            aq, as_ = K.quant_i8_block128(a)
+            wq, ws = K.quant_i8_block128((torch.randn(n, k, device=dev) / math.sqrt(k)).bfloat16())
+            b = torch.zeros(n, device=dev).bfloat16()
+            t = timeit(lambda: K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=(nm == "ffn1")), args.iters)
+            rep(f"gemm_w8a8 {nm} M={L} N={n} K={k}", t, bytes_=L * k + n * k + 2 * L * n, flops=2.0 * L * n * k, peak_f=I8)
+            del a, aq, wq
+    if not only or "prep" in only:
+        qkv = torch.randn(L, 3 * dim, device=dev).bfloat16()
+        w = torch.ones(dim, device=dev)
+        cos = torch.rand(L, 64, device=dev)
+        t = timeit(lambda: K.qk_norm_rope(qkv, 0, H, D, w, cos, cos, 1e-6), args.iters)
+        rep("qk_norm_rope [L,dim]->[H,L,D]", t, bytes_=4 * L * dim + 8 * L * 64)
+        t = timeit(lambda: K.v_transpose(qkv[:, 2 * dim:], D, 3 * dim, L, H, D, torch.float16), args.iters)
+        rep("v_transpose", t, bytes_=4 * L * dim)
+        kk = K.qk_norm_rope(qkv, dim, H, D, w, cos, cos, 1e-6)
+        t = timeit(lambda: K.seq_mean(kk), args.iters)
+        rep("seq_mean", t, bytes_=2 * L * dim)
+        km = K.seq_mean(kk)
+        t = timeit(lambda: K.sage_quant_pool(kk, km, 64), args.iters)
+        rep("sage_quant_pool K (blk 64)", t, bytes_=3 * L * dim)
+        t = timeit(lambda: K.sage_quant_pool(kk, None, 128), args.iters)
+        rep("sage_quant_pool Q (blk 128)", t, bytes_=3 * L * dim)
+        pq, _, _ = K.sage_quant_pool(kk, None, 128, want_quant=False)
+        pk, _, _ = K.sage_quant_pool(kk, km, 64, want_quant=False)
+        kb = pk.shape[1]
+        topk = min(kb, int(args.topk * kb))
+        t = timeit(lambda: K.sla_topk(pq, pk, topk), args.iters)
+        rep(f"sla_topk Qb={pq.shape[1]} Kb={kb} topk={topk}", t)
+    if not only or "attn" in only:
+        qkv = torch.randn(L, 3 * dim, device=dev).bfloat16()
+        w = torch.ones(dim, device=dev)
+        ang = torch.rand(L, 64, device=dev) * 6
+        cos, sin = torch.cos(ang), torch.sin(ang)
+        q = K.qk_norm_rope(qkv, 0, H, D, w, cos, sin, 1e-6)
+        k = K.qk_norm_rope(qkv, dim, H, D, w, cos, sin, 1e-6)
+        vt = K.v_transpose(qkv[:, 2 * dim:], D, 3 * dim, L, H, D, torch.float16)
+        km = K.seq_mean(k)
+        pq, q8, qs = K.sage_quant_pool(q, None, 128)
+        pk, k8, ks = K.sage_quant_pool(k, km, 64)
+        qb, kb = pq.shape[1], pk.shape[1]
+        topk = min(kb, int(args.topk * kb))
+        lut = K.sla_topk(pq, pk, topk)
+        out = torch.empty(L, H, D, device=dev, dtype=torch.bfloat16)
+        t = timeit(lambda: K.attn_i8(q8, qs, k8, ks, vt, lut, out, D, H * D), args.iters)
+        fl = 4.0 * qb * 128 * topk * 64 * D * H
+        by = H * qb * (128 * D + topk * 64 * D * 3 + 128 * D * 2)
+        rep(f"attn_i8 sparse topk={topk}/{kb}", t, bytes_=by, flops=fl, peak_f=(I8 + F16) / 2 * 0 + 1.0 / (0.5 / I8 + 0.5 / F16))
+        vtb = K.v_transpose(qkv[:, 2 * dim:], D, 3 * dim, L, H, D, torch.bfloat16)
+        t = timeit(lambda: K.attn_16(q, k, vtb, lut, out, D, H * D), args.iters)
+        by16 = H * qb * (128 * D * 2 + topk * 64 * D * 4 + 128 * D * 2)
+        rep(f"attn_16 sparse topk={topk}/{kb}", t, bytes_=by16, flops=fl, peak_f=F16)
+        kv_t, ksum = K.sla_linear_kv(k, vt)
+        t = timeit(lambda: K.sla_linear_kv(k, vt), args.iters)
+        rep("sla_linear_kv", t, bytes_=4 * L * dim)
+        wp = torch.randn(D, D, device=dev) * 0.05
+        bp = torch.zeros(D, device=dev)
+        t = timeit(lambda: K.sla_linear_out_(q, kv_t, ksum, wp, bp, out, D, H * D), args.iters)
+        rep("sla_linear_out", t, bytes_=6 * L * dim)
+        # cross attention shape: L x 512 dense, bf16
+        kc = torch.randn(H, 512, D, device=dev).bfloat16()
+        vtc = K.v_transpose(kc, 512 * D, D, 512, H, D, torch.bfloat16)
+        t = timeit(lambda: K.attn_16(q, kc, vtc, None, out, D, H * D), args.iters)
+        rep("attn_16 cross L x 512 dense", t, flops=4.0 * L * 512 * dim, peak_f=F16)
+        if args.dense:
+            t = timeit(lambda: K.attn_i8(q8, qs, k8, ks, vt, None, out, D, H * D), max(1, args.iters // 5), warm=1)
+            rep("attn_i8 dense", t, flops=4.0 * L * L * dim, peak_f=1.0 / (0.5 / I8 + 0.5 / F16))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/kbench.json", "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

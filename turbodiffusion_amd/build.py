@@ -1,0 +1,67 @@
+"""Build libturbodiffusion_amd.so (hand-written HIP for gfx950) in-tree.
+
+    python -m turbodiffusion_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  No fast-math: the quantiser's
+``128/amax`` and the norms' ``1/sqrt`` must be IEEE so scales are bit-exact with the
+oracle; ``-ffp-contract=off`` keeps mul+add sequences un-fused where the reference
+rounds twice (FMAs are written explicitly where the reference has one).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libturbodiffusion_amd.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs.append(os.path.join(HERE, "..", "include", "turbodiffusion_amd.h"))
+    objs, jobs = [], []
+    for s in sources():
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(CSRC, s[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(cc, jobs))
+    if jobs or force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

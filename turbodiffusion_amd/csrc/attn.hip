@@ -1,0 +1,321 @@
+// a9 / a12 / a13 / a4 — flash-style attention for gfx950, block-sparse (LUT) or dense.
+//
+// Two instantiations of one kernel:
+//   td_attn_i8 : SageAttention arithmetic — INT8 Q.K^T on v_mfma_i32_32x32x32_i8 with
+//                per-block scales, fp32 online softmax (exp2 domain), P rounded to fp16,
+//                P.V on v_mfma_f32_32x32x16_f16, fp32 accumulate
+//                (call site in the reference: SLA/core.py:211-216; arithmetic lives in the
+//                un-vendored SpargeAttn dependency — see oracle/sla_ref.py:sage_sparse_attn).
+//   td_attn_16 : bf16/f16 Q.K^T and P.V (SLA Triton kernel arithmetic, SLA/kernel.py:21-82;
+//                also the dense cross-attention, rcm/utils/attention.py:120-167).
+//
+// MI355X design: one 256-thread workgroup (4 wavefronts) per 128-row Q block; each wave
+// owns 32 Q rows and walks the selected 64-key K blocks.  Both GEMMs are issued TRANSPOSED
+// so that every per-row softmax quantity is lane-local:
+//   S^T[64 keys x 32 q] = K_tile . Q^T    (A operand = K rows from LDS, B operand = Q in VGPRs)
+//   O^T[128 d x 32 q]  += V^T_tile . P^T  (A operand = V^T rows from LDS, B operand = P^T —
+//        exactly the registers the first MFMA produced: lane = q row, registers = keys)
+// so the row max is a 31-op in-lane reduction plus ONE exchange with lane^32, the rescale
+// factor multiplies a lane's accumulators uniformly, and P never touches LDS.  V is
+// pre-transposed per 64-key block by td_v_transpose with the keys of each 16-group stored in
+// the order the MFMA B fragment delivers P (0-3,8-11 | 4-7,12-15), so a V^T A-fragment is one
+// ds_read_b128.  K and V^T tiles sit in LDS with the 16-B slot XOR-swizzled so the 16-lane
+// groups of ds_read_b128 are bank-conflict free; tiles are double buffered, the next tile's
+// global loads are issued before the current tile's MFMAs and written to LDS after them
+// (one barrier per K block).  Workgroup ids are XCD-remapped so one XCD's L2 serves one head's
+// K/V at a time.
+#include "td_common.h"
+
+struct AttnParams {
+  const void* q;       // int8 [H,L,128] or 16-bit [H,L,128]
+  const float* q_s;    // [H, Qb] (int8 only)
+  const void* k;       // int8 [H,Lk,128] or 16-bit
+  const float* k_s;    // [H, Kb] (int8 only)
+  const uint16_t* vt;  // [H, Kb, 128, 64] 16-bit
+  const int32_t* lut;  // [H, Qb, nsel] or null
+  uint16_t* o;
+  int64_t o_stride_h, o_stride_l;
+  float scale_log2;    // sm_scale * log2(e)
+  int64_t L, Lk;
+  int H, Qb, Kb, nsel;
+};
+
+template <bool QK_I8> struct KTile {
+  static constexpr int ROWB = QK_I8 ? 128 : 256;    // bytes per key row
+  static constexpr int BYTES = 64 * ROWB;
+  static constexpr int NVEC = BYTES / (256 * 16);   // 16-B vectors per thread
+  __device__ static __forceinline__ uint32_t off(uint32_t row, uint32_t slot) {
+    if constexpr (QK_I8) return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
+    else return row * 256u + ((slot ^ (row & 15u)) << 4);
+  }
+};
+#define VT_BYTES (128 * 128)
+__device__ __forceinline__ uint32_t vt_off(uint32_t row, uint32_t slot) {
+  return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
+}
+
+template <int DT> struct Mma16;
+template <> struct Mma16<TD_F16> {
+  typedef v8h frag;
+  __device__ static __forceinline__ v16f mma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma16<TD_BF16> {
+  typedef v8bf frag;
+  __device__ static __forceinline__ v16f mma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// QK_I8: int8 QK; PDT: dtype of P / V^T (and of q,k when !QK_I8); ODT: output dtype
+template <bool QK_I8, int PDT, int ODT>
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef KTile<QK_I8> KT;
+  constexpr int BUF = KT::BYTES + VT_BYTES;
+  typedef typename Mma16<PDT>::frag frag16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+
+  const uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int h = vid / p.Qb, qb = vid % p.Qb;
+
+  int64_t qrow = (int64_t)qb * 128 + wave * 32 + li;
+  const bool q_ok = qrow < p.L;
+  if (!q_ok) qrow = p.L - 1;
+
+  // ---- Q fragments (B operand): lane = q row, 16 B per 32-byte k-chunk half ----
+  constexpr int NQ = QK_I8 ? 4 : 8;
+  uint4 qf[NQ];
+  {
+    const char* qp = (const char*)p.q + ((int64_t)h * p.L + qrow) * (QK_I8 ? 128 : 256);
+#pragma unroll
+    for (int kc = 0; kc < NQ; ++kc) qf[kc] = *reinterpret_cast<const uint4*>(qp + kc * 32 + hi * 16);
+  }
+
+  const int32_t* lut = p.lut ? p.lut + ((int64_t)h * p.Qb + qb) * p.nsel : nullptr;
+  const int nsel = p.lut ? p.nsel : p.Kb;
+  const float qs = QK_I8 ? p.q_s[(int64_t)h * p.Qb + qb] : 1.0f;
+
+  // ---- staging: K tile KT::NVEC vectors/thread, V^T tile 4 vectors/thread ----
+  uint4 sk0, sk1, sk2, sk3, sv0, sv1, sv2, sv3;
+  uint32_t koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int v = tid + 256 * i;
+    if (i < KT::NVEC) koff[i] = KT::off(v / (KT::ROWB / 16), v % (KT::ROWB / 16));
+    voff[i] = vt_off(v >> 3, v & 7);
+  }
+#define KLOAD1(i_, kb_)                                                                    \
+  if (i_ < KT::NVEC) {                                                                     \
+    const int v_ = tid + 256 * i_;                                                         \
+    int64_t kr_ = (int64_t)(kb_) * 64 + v_ / (KT::ROWB / 16);                              \
+    if (kr_ > p.Lk - 1) kr_ = p.Lk - 1;                                                    \
+    sk##i_ = *reinterpret_cast<const uint4*>((const char*)p.k +                            \
+                 ((int64_t)h * p.Lk + kr_) * KT::ROWB + (v_ % (KT::ROWB / 16)) * 16);       \
+  }
+#define VLOAD1(i_, kb_)                                                                    \
+  sv##i_ = *reinterpret_cast<const uint4*>((const char*)p.vt +                             \
+               (((int64_t)h * p.Kb + (kb_)) * VT_BYTES) + (int64_t)(tid + 256 * i_) * 16);
+#define TLOAD(kb_) KLOAD1(0, kb_) KLOAD1(1, kb_) KLOAD1(2, kb_) KLOAD1(3, kb_) \
+                   VLOAD1(0, kb_) VLOAD1(1, kb_) VLOAD1(2, kb_) VLOAD1(3, kb_)
+#define KSTORE1(i_, base_) if (i_ < KT::NVEC) *reinterpret_cast<uint4*>((base_) + koff[i_]) = sk##i_;
+#define VSTORE1(i_, base_) *reinterpret_cast<uint4*>((base_) + KT::BYTES + voff[i_]) = sv##i_;
+#define TSTORE(buf_)                                                                       \
+  {                                                                                        \
+    char* base_ = smem + (buf_) * BUF;                                                     \
+    KSTORE1(0, base_) KSTORE1(1, base_) KSTORE1(2, base_) KSTORE1(3, base_)                \
+    VSTORE1(0, base_) VSTORE1(1, base_) VSTORE1(2, base_) VSTORE1(3, base_)                \
+  }
+
+  v16f oacc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
+  float m_run = -INFINITY, l_part = 0.f;
+
+  int kb_next = lut ? lut[0] : 0;
+  TLOAD(kb_next)
+  TSTORE(0)
+  __syncthreads();
+
+  for (int it = 0; it < nsel; ++it) {
+    const int cur = it & 1;
+    const int kb = kb_next;
+    if (it + 1 < nsel) {
+      kb_next = lut ? lut[it + 1] : it + 1;
+      TLOAD(kb_next)
+    }
+    const char* kt = smem + cur * BUF;
+    const char* vtile = kt + KT::BYTES;
+
+    // ---- S^T = K . Q^T : two 32-key groups ----
+    float s[2][16];
+    if constexpr (QK_I8) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        v16i acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+          const v4i kf = *reinterpret_cast<const v4i*>(kt + KT::off(32 * g + li, 2 * kc + hi));
+          v4i qv; qv[0] = qf[kc].x; qv[1] = qf[kc].y; qv[2] = qf[kc].z; qv[3] = qf[kc].w;
+          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qv, acc, 0, 0, 0);
+        }
+        const float mult = (qs * p.k_s[(int64_t)h * p.Kb + kb]) * p.scale_log2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[g][r] = (float)acc[r] * mult;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+          const frag16 kf = *reinterpret_cast<const frag16*>(kt + KT::off(32 * g + li, 2 * kc + hi));
+          frag16 qv = *reinterpret_cast<const frag16*>(&qf[kc]);
+          acc = Mma16<PDT>::mma(kf, qv, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[g][r] = acc[r] * p.scale_log2;
+      }
+    }
+    // ---- tail mask (only the last, partial K block) ----
+    if ((int64_t)(kb + 1) * 64 > p.Lk) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t key = (int64_t)kb * 64 + 32 * g + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= p.Lk) s[g][r] = -INFINITY;
+        }
+    }
+    // ---- online softmax, exp2 domain; lanes l and l^32 share a q row ----
+    float mx = s[0][0];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[g][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first block: exp2(-inf) = 0
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[g][r] = __builtin_amdgcn_exp2f(s[g][r] - m_new);
+        psum += s[g][r];
+      }
+    l_part = l_part * alpha + psum;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[c][r] *= alpha;
+    }
+    // ---- P^T fragments (B operand): step ks = 2g+t uses registers 8t..8t+7 of group g ----
+    uint4 pf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int g = ks >> 1, t = ks & 1;
+      pf[ks] = pack8<PDT>(&s[g][8 * t]);
+    }
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const frag16 vf = *reinterpret_cast<const frag16*>(vtile + vt_off(32 * c + li, 2 * ks + hi));
+        frag16 pv = *reinterpret_cast<const frag16*>(&pf[ks]);
+        oacc[c] = Mma16<PDT>::mma(vf, pv, oacc[c]);
+      }
+    }
+    if (it + 1 < nsel) TSTORE(cur ^ 1)
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane = q row; oacc[c][r] is d = 32c + (r&3) + 8(r>>2) + 4hi ----
+  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q_ok) {
+    uint16_t* op = p.o + (int64_t)h * p.o_stride_h + qrow * p.o_stride_l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        uint32_t b[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = f32_to_half_bits<ODT>(oacc[c][4 * g4 + e] * inv);
+        *reinterpret_cast<uint2*>(op + 32 * c + 8 * g4 + 4 * hi) =
+            make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+      }
+  }
+}
+
+template <bool QK_I8, int PDT, int ODT>
+static int launch_attn(const AttnParams& p, hipStream_t st) {
+  auto kern = attn_kernel<QK_I8, PDT, ODT>;
+  constexpr int lds = 2 * (KTile<QK_I8>::BYTES + VT_BYTES);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  const unsigned nwg = (unsigned)p.H * (unsigned)p.Qb;
+  kern<<<nwg, 256, lds, st>>>(p);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+static int attn_common_checks(const char* who, const void* q, const void* k, const void* vt, void* o,
+                              int nsel, int64_t L, int64_t Lk, int H, const int32_t* lut) {
+  TD_REQUIRE(q && k && vt && o, TD_ERR_INVALID, "%s: null pointer", who);
+  TD_REQUIRE(L > 0 && Lk > 0 && H > 0, TD_ERR_INVALID, "%s: L=%lld Lk=%lld H=%d", who, (long long)L,
+             (long long)Lk, H);
+  TD_REQUIRE(!lut || nsel >= 1, TD_ERR_INVALID, "%s: nsel=%d with a LUT", who, nsel);
+  return TD_OK;
+}
+
+extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                          const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
+                          int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+                          int64_t Lk, int H, td_stream_t stream) {
+  int rc = attn_common_checks("td_attn_i8", q_i8, k_i8, vt, o, nsel, L, Lk, H, lut);
+  if (rc) return rc;
+  TD_REQUIRE(q_s && k_s, TD_ERR_INVALID, "td_attn_i8: null scale pointer");
+  TD_REQUIRE(out_dtype == TD_F16 || out_dtype == TD_BF16, TD_ERR_UNSUPPORTED,
+             "td_attn_i8: out dtype %d", out_dtype);
+  AttnParams p;
+  p.q = q_i8; p.q_s = q_s; p.k = k_i8; p.k_s = k_s; p.vt = (const uint16_t*)vt; p.lut = lut;
+  p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
+  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == TD_BF16) return launch_attn<true, TD_F16, TD_BF16>(p, st);
+  return launch_attn<true, TD_F16, TD_F16>(p, st);
+}
+
+extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel,
+                          void* o, int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale,
+                          int64_t L, int64_t Lk, int H, td_stream_t stream) {
+  int rc = attn_common_checks("td_attn_16", q, k, vt, o, nsel, L, Lk, H, lut);
+  if (rc) return rc;
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_attn_16: dtype %d", dtype);
+  AttnParams p;
+  p.q = q; p.q_s = nullptr; p.k = k; p.k_s = nullptr; p.vt = (const uint16_t*)vt; p.lut = lut;
+  p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
+  p.scale_log2 = sm_scale * 1.4426950408889634f;
+  p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16) return launch_attn<false, TD_BF16, TD_BF16>(p, st);
+  return launch_attn<false, TD_F16, TD_F16>(p, st);
+}

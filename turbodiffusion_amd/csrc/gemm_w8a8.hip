@@ -1,0 +1,230 @@
+// a17 — block-scaled W8A8 INT8 GEMM on CDNA4 matrix cores (gfx950).
+//
+// Semantics (reference: turbodiffusion/ops/gemm/kernel.hpp:390-427, utils.hpp:116-121):
+//   acc_f32[m,n] = sum over 128-deep K blocks (ascending) of
+//                  fma( float(int32 sum_{k in block} a[m,k]*b[n,k]),  a_s[m/128,kb]*b_s[n/128,kb],  acc )
+//   d = cast(acc)  [ + bias, rounded again in the output dtype — Int8Linear.forward,
+//   ops/core.py:408-412 ]  [ GELU-tanh on the rounded value — the FFN, wan2pt1.py:375 ].
+//
+// MI355X design (not the reference's 4x2-warp m16n8k32 / cp.async CuTe pipeline):
+//   * 128(M) x 128(N) output tile per 256-thread workgroup (4 wavefronts in 2x2, 64x64 each),
+//     K step = 128 = one scale block, so ONE scalar a_s*b_s per tile per K step.
+//   * v_mfma_i32_32x32x32_i8: the WEIGHT fragment is the A operand (rows = n) and the
+//     ACTIVATION fragment the B operand (cols = m), so each lane ends up owning 4 consecutive
+//     n for one m-row per accumulator quad -> 8-byte row-contiguous stores, no LDS epilogue.
+//   * both operands are K-contiguous: a lane's 16 int8 are one ds_read_b128; LDS tiles are
+//     [128 rows][128 B] with the 16-B slot XOR-swizzled by (row>>1)&7 so the 16-lane groups of
+//     ds_read_b128 hit 16 distinct slots of the 256-B bank row (conflict-free).
+//   * double-buffered LDS, register-staged prefetch (global loads of K block kb+1 are issued
+//     before the MFMAs of block kb, written to the other buffer after them; one barrier per
+//     K block).  2 workgroups per CU (64 KB LDS each, <=256 VGPR) let one wave's int32->fp32
+//     dequant VALU work overlap the other's MFMAs.
+//   * 1-D grid with an XCD-aware, m-grouped tile order so an activation panel and the weight
+//     panel it meets stay in one XCD's L2.
+#include "td_common.h"
+
+#define G_BM 128
+#define G_BN 128
+#define G_BK 128
+#define G_TILE_BYTES (128 * 128)          // one operand tile, int8
+#define G_BUF_BYTES (2 * G_TILE_BYTES)    // A + B
+#define G_LDS_BYTES (2 * G_BUF_BYTES)     // double buffer = 64 KB
+
+__device__ __forceinline__ uint32_t g_swz(uint32_t row, uint32_t slot) {
+  return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
+  const float k1 = 0.044715f;
+  float inner = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanhf(inner));
+}
+
+template <int ODT, int EPI, bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(
+    const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
+    const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
+    int64_t M, int64_t N, int64_t K, int64_t ldd, int tiles_m, int tiles_n, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int wn = wave & 1, wm = wave >> 1;
+
+  // ---- tile assignment: XCD remap, then m-grouped raster ----
+  const uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_group = group_m * tiles_n;
+  const int gid = vid / per_group;
+  const int first_m = gid * group_m;
+  const int gsz = min(group_m, tiles_m - first_m);
+  const int in_g = vid % per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int64_t m0 = (int64_t)tm * G_BM, n0 = (int64_t)tn * G_BN;
+  const int nk = (int)(K / G_BK);
+
+  // ---- staging addresses: thread -> (row = i*32 + tid/8, slot = tid%8) ----
+  const int srow = tid >> 3, sslot = tid & 7;
+  const int8_t* ga[4];
+  const int8_t* gb[4];
+  uint32_t loff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 32 + srow;
+    int64_t am = m0 + row; if (am > M - 1) am = M - 1;   // tail rows: clamp (never stored)
+    int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
+    ga[i] = A + am * K + sslot * 16;
+    gb[i] = B + bn * K + sslot * 16;
+    loff[i] = g_swz(row, sslot);
+  }
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define GLOAD1(i_, kb_)                                                          \
+  ra##i_ = *reinterpret_cast<const uint4*>(ga[i_] + (int64_t)(kb_) * G_BK);      \
+  rb##i_ = *reinterpret_cast<const uint4*>(gb[i_] + (int64_t)(kb_) * G_BK);
+#define GLOAD(kb_) GLOAD1(0, kb_) GLOAD1(1, kb_) GLOAD1(2, kb_) GLOAD1(3, kb_)
+#define LSTORE1(i_, base_)                                                       \
+  *reinterpret_cast<uint4*>((base_) + loff[i_]) = ra##i_;                        \
+  *reinterpret_cast<uint4*>((base_) + G_TILE_BYTES + loff[i_]) = rb##i_;
+#define LSTORE(buf_)                                                             \
+  {                                                                              \
+    char* base_ = smem + (buf_) * G_BUF_BYTES;                                   \
+    LSTORE1(0, base_) LSTORE1(1, base_) LSTORE1(2, base_) LSTORE1(3, base_)      \
+  }
+
+  v16i acci[2][2];  // [i: m sub-tile][j: n sub-tile]
+  v16f accf[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acci[i][j][r] = 0; accf[i][j][r] = 0.f; }
+    }
+
+  const float* as_row = AS + (int64_t)tm * nk;
+  const float* bs_row = BS + (int64_t)tn * nk;
+
+  GLOAD(0)
+  LSTORE(0)
+  __syncthreads();
+
+  for (int kb = 0; kb < nk; ++kb) {
+    const int cur = kb & 1;
+    if (kb + 1 < nk) { GLOAD(kb + 1) }
+    const float sc = as_row[kb] * bs_row[kb];  // (sa*sb) formed first, kernel.hpp:418
+    const char* xa = smem + cur * G_BUF_BYTES;        // activation tile
+    const char* wb = xa + G_TILE_BYTES;               // weight tile
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      v4i xf[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        xf[i] = *reinterpret_cast<const v4i*>(xa + g_swz(wm * 64 + i * 32 + li, 2 * kc + hi));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wf[j] = *reinterpret_cast<const v4i*>(wb + g_swz(wn * 64 + j * 32 + li, 2 * kc + hi));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acci[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wf[j], xf[i], acci[i][j], 0, 0, 0);
+    }
+    // dequant this K block into the fp32 accumulators (one FMA per element, utils.hpp:116-121)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          accf[i][j][r] = fmaf((float)acci[i][j][r], sc, accf[i][j][r]);
+          acci[i][j][r] = 0;
+        }
+    if (kb + 1 < nk) { LSTORE(cur ^ 1) }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns m = ..+li; accumulator quad g4 holds n = ..+8*g4+4*hi+{0..3} ----
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t m = m0 + wm * 64 + i * 32 + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int64_t n = n0 + wn * 64 + j * 32 + 8 * g4 + 4 * hi;
+        if (n >= N) continue;  // N % 8 == 0 and n % 4 == 0: the quad is all-in or all-out
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = accf[i][j][4 * g4 + e];
+        uint32_t hb[4];
+        if constexpr (HAS_BIAS) {
+          const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
+          hb[0] = bb.x & 0xffffu; hb[1] = bb.x >> 16; hb[2] = bb.y & 0xffffu; hb[3] = bb.y >> 16;
+        }
+        uint32_t ob[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t o = f32_to_half_bits<ODT>(v[e]);
+          if constexpr (HAS_BIAS)
+            o = f32_to_half_bits<ODT>(half_bits_to_f32<ODT>(o) + half_bits_to_f32<ODT>(hb[e]));
+          if constexpr (EPI == TD_EPI_GELU_TANH)
+            o = f32_to_half_bits<ODT>(gelu_tanh_f(half_bits_to_f32<ODT>(o)));
+          ob[e] = o;
+        }
+        *reinterpret_cast<uint2*>(D + m * ldd + n) =
+            make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+      }
+    }
+  }
+}
+
+template <int ODT, int EPI, bool HAS_BIAS>
+static int launch_gemm(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                       const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
+                       hipStream_t st) {
+  auto kern = gemm_w8a8_kernel<ODT, EPI, HAS_BIAS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+    attr_set = true;
+  }
+  const int tiles_m = (int)td_cdiv(m, G_BM), tiles_n = (int)td_cdiv(n, G_BN);
+  const int group_m = 4;
+  const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;
+  kern<<<nwg, 256, G_LDS_BYTES, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k,
+                                      ldd, tiles_m, tiles_n, group_m);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                            const void* bias, void* d, int out_dtype, int epilogue, int64_t m,
+                            int64_t n, int64_t k, int64_t ldd, td_stream_t stream) {
+  TD_REQUIRE(a && a_s && b && b_s && d, TD_ERR_INVALID, "td_gemm_w8a8: null pointer");
+  TD_REQUIRE(m >= 0 && n >= 0 && k >= 0, TD_ERR_INVALID, "td_gemm_w8a8: negative size");
+  TD_REQUIRE(out_dtype == TD_F16 || out_dtype == TD_BF16, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8: out dtype %d (need f16|bf16)", out_dtype);
+  TD_REQUIRE(k % 128 == 0 && k > 0, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8: k=%lld must be a positive multiple of 128 (one scale block per K step)",
+             (long long)k);
+  TD_REQUIRE(n % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: n=%lld must be a multiple of 8",
+             (long long)n);
+  TD_REQUIRE(ldd >= n && ldd % 4 == 0, TD_ERR_INVALID, "td_gemm_w8a8: bad ldd=%lld", (long long)ldd);
+  TD_REQUIRE(epilogue == TD_EPI_NONE || epilogue == TD_EPI_GELU_TANH, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8: epilogue %d", epilogue);
+  if (m == 0 || n == 0) return TD_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define TD_GEMM_CASE(ODT)                                                                          \
+  if (epilogue == TD_EPI_GELU_TANH) {                                                              \
+    return bias ? launch_gemm<ODT, TD_EPI_GELU_TANH, true>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st) \
+                : launch_gemm<ODT, TD_EPI_GELU_TANH, false>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st); \
+  } else {                                                                                         \
+    return bias ? launch_gemm<ODT, TD_EPI_NONE, true>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st)   \
+                : launch_gemm<ODT, TD_EPI_NONE, false>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st); \
+  }
+  if (out_dtype == TD_BF16) { TD_GEMM_CASE(TD_BF16) } else { TD_GEMM_CASE(TD_F16) }
+#undef TD_GEMM_CASE
+}

@@ -1,0 +1,370 @@
+// a14 — SLA linear-attention branch on CDNA4 matrix cores (gfx950).
+// Reference: SLA/core.py:243-253 (feature_map = softmax):
+//   cq = softmax_D(q).to(dt); ck = softmax_D(k).to(dt)
+//   kvsum = ck^T @ v ; ksum = sum_L ck
+//   o_l = (cq @ kvsum) / (1e-5 + sum_D(cq*ksum)) ; o_l = proj_l(o_l) (autocast dt) ; o = o_s + o_l
+//
+// Two passes, both token-streaming (HBM-bound) with the small GEMMs on MFMA:
+//   td_sla_linear_kv : per head, 16 workgroups each reduce a range of 64-token K blocks:
+//        ck tile is written TRANSPOSED into LDS in the same key order as the V^T tiles produced
+//        by td_v_transpose, so kv[d1,d2] += ck^T[d1,tok] v[tok,d2] is a plain A.B MFMA with both
+//        operands read by ds_read_b128.  Partials go to a workspace (no atomics, deterministic),
+//        a finalize kernel sums them in order and rounds once.
+//   td_sla_linear_out: per 128-token block; lane = token (the two half-waves hold the two halves
+//        of the row), so softmax_D, the normaliser and the final divide are lane-local;
+//        num^T = kvsum^T.cq^T and out^T = Wp.o_l^T are chained MFMAs where the first one's
+//        accumulator registers ARE the second one's B fragments (Wp is stored in LDS in the
+//        matching k order).  The result is added to o_s in place.
+#include "td_common.h"
+
+#define LK_NCH 16  // partial-sum chunks per head
+
+__device__ __forceinline__ uint32_t sw128(uint32_t row, uint32_t slot) {  // 128-B rows
+  return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
+}
+__device__ __forceinline__ uint32_t sw256(uint32_t row, uint32_t slot) {  // 256-B rows
+  return row * 256u + ((slot ^ (row & 15u)) << 4);
+}
+// position inside a 16-group that holds offset tt (0..15): order 0-3, 8-11, 4-7, 12-15
+__device__ __forceinline__ int perm_pos(int tt) { return (tt & 3) + ((tt >> 3) & 1) * 4 + ((tt >> 2) & 1) * 8; }
+
+template <int DT> struct MmaT;
+template <> struct MmaT<TD_F16> {
+  typedef v8h frag;
+  __device__ static __forceinline__ v16f mma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct MmaT<TD_BF16> {
+  typedef v8bf frag;
+  __device__ static __forceinline__ v16f mma(frag a, frag b, v16f c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// pass 1a: partial kv / ksum over a range of K blocks
+//   KDT: dtype of k (and of the rounded softmax ck);  VDT: dtype of the V^T tiles / MFMA
+// ---------------------------------------------------------------------------------------
+template <int KDT, int VDT>
+__global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* __restrict__ k,
+                                                                const uint16_t* __restrict__ vt,
+                                                                float* __restrict__ ws_kv,
+                                                                float* __restrict__ ws_ks, int64_t L,
+                                                                int Kb) {
+  __shared__ __attribute__((aligned(16))) char ckT[128 * 128];  // [d1][64 positions] 16-bit
+  __shared__ __attribute__((aligned(16))) char vT[128 * 128];   // [d2][64 positions] 16-bit
+  __shared__ float ksred[16][128];
+  typedef typename MmaT<VDT>::frag frag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int c8 = tid & 15, r0 = tid >> 4;
+  const int ch = blockIdx.x, h = blockIdx.y;
+  const int per = (Kb + LK_NCH - 1) / LK_NCH;
+  const int kb_lo = ch * per, kb_hi = min(Kb, kb_lo + per);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float ks_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+  for (int kb = kb_lo; kb < kb_hi; ++kb) {
+    // V^T tile -> LDS (contiguous 16 KB, same swizzle as the attention kernel)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = tid + 256 * i;
+      *reinterpret_cast<uint4*>(vT + sw128(v >> 3, v & 7)) =
+          *reinterpret_cast<const uint4*>(vt + ((int64_t)h * Kb + kb) * (128 * 64) + (int64_t)v * 8);
+    }
+    // k rows: softmax over D (16 lanes share a row), rounded to KDT, written transposed
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int tok = it * 16 + r0;
+      const int64_t l = (int64_t)kb * 64 + tok;
+      float f[8];
+      if (l < L) {
+        unpack8<KDT>(*reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8), f);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = 0.f;
+      }
+      float mx = f[0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) mx = fmaxf(mx, f[j]);
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { f[j] = expf(f[j] - mx); sum += f[j]; }
+#pragma unroll
+      for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      const int g16 = tok >> 4, pos = perm_pos(tok & 15);
+      const uint32_t slot = (uint32_t)(g16 * 2 + (pos >> 3));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float ck = (l < L) ? f[j] / sum : 0.f;
+        ck = half_bits_to_f32<KDT>(f32_to_half_bits<KDT>(ck));  // softmax(...).to(dtype)
+        ks_acc[j] += ck;
+        const uint32_t d1 = (uint32_t)(c8 * 8 + j);
+        *reinterpret_cast<uint16_t*>(ckT + sw128(d1, slot) + (pos & 7) * 2) =
+            (uint16_t)f32_to_half_bits<VDT>(ck);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      frag a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = *reinterpret_cast<const frag*>(ckT + sw128(32 * (2 * wr + i) + li, 2 * ks + hi));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = *reinterpret_cast<const frag*>(vT + sw128(32 * (2 * wc + j) + li, 2 * ks + hi));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = MmaT<VDT>::mma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  // partial kv: D[d1][d2], lane = d2 column, registers = d1 rows
+  float* out = ws_kv + ((int64_t)h * LK_NCH + ch) * (128 * 128);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d1 = 32 * (2 * wr + i) + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int d2 = 32 * (2 * wc + j) + li;
+        out[d1 * 128 + d2] = acc[i][j][r];
+      }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ksred[r0][c8 * 8 + j] = ks_acc[j];
+  __syncthreads();
+  if (tid < 128) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += ksred[r][tid];
+    ws_ks[((int64_t)h * LK_NCH + ch) * 128 + tid] = s;
+  }
+}
+
+// pass 1b: sum partials in order, round once; kvsum is written TRANSPOSED ([d2][d1]) because
+// that is the A operand of pass 2.
+template <int DT>
+__global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __restrict__ ws_kv,
+                                                              const float* __restrict__ ws_ks,
+                                                              uint16_t* __restrict__ kvT,
+                                                              uint16_t* __restrict__ ksum) {
+  const int h = blockIdx.x;
+  for (int i = threadIdx.x; i < 128 * 128; i += 256) {
+    float s = 0.f;
+    for (int c = 0; c < LK_NCH; ++c) s += ws_kv[((int64_t)h * LK_NCH + c) * (128 * 128) + i];
+    const int d1 = i >> 7, d2 = i & 127;
+    kvT[(int64_t)h * 128 * 128 + d2 * 128 + d1] = (uint16_t)f32_to_half_bits<DT>(s);
+  }
+  if (threadIdx.x < 128) {
+    float s = 0.f;
+    for (int c = 0; c < LK_NCH; ++c) s += ws_ks[((int64_t)h * LK_NCH + c) * 128 + threadIdx.x];
+    ksum[h * 128 + threadIdx.x] = (uint16_t)f32_to_half_bits<DT>(s);
+  }
+}
+
+extern "C" int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
+                                float* ws_ks, void* kvsum_t, void* ksum, int64_t L, int H, int D,
+                                td_stream_t stream) {
+  TD_REQUIRE(k && vt && ws_kv && ws_ks && kvsum_t && ksum, TD_ERR_INVALID, "td_sla_linear_kv: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_linear_kv: D=%d (need 128)", D);
+  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sla_linear_kv: L=%lld H=%d", (long long)L, H);
+  const int Kb = (int)td_cdiv(L, 64);
+  dim3 grid(LK_NCH, H);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16 && vt_dtype == TD_F16) {
+    linear_kv_partial_kernel<TD_BF16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+    linear_kv_final_kernel<TD_BF16><<<H, 256, 0, st>>>(ws_kv, ws_ks, (uint16_t*)kvsum_t, (uint16_t*)ksum);
+  } else if (dtype == TD_BF16 && vt_dtype == TD_BF16) {
+    linear_kv_partial_kernel<TD_BF16, TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+    linear_kv_final_kernel<TD_BF16><<<H, 256, 0, st>>>(ws_kv, ws_ks, (uint16_t*)kvsum_t, (uint16_t*)ksum);
+  } else if (dtype == TD_F16 && vt_dtype == TD_F16) {
+    linear_kv_partial_kernel<TD_F16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+    linear_kv_final_kernel<TD_F16><<<H, 256, 0, st>>>(ws_kv, ws_ks, (uint16_t*)kvsum_t, (uint16_t*)ksum);
+  } else {
+    td_set_error("td_sla_linear_kv: unsupported dtypes k=%d vt=%d", dtype, vt_dtype);
+    return TD_ERR_UNSUPPORTED;
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// pass 2: o += proj_l( (cq @ kvsum) / (1e-5 + sum(cq*ksum)) )
+// ---------------------------------------------------------------------------------------
+#define LO_QB_PER_WG 4
+template <int DT>
+__global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restrict__ q,
+                                                         const uint16_t* __restrict__ kvT,
+                                                         const uint16_t* __restrict__ ksum,
+                                                         const float* __restrict__ wp,
+                                                         const float* __restrict__ bp,
+                                                         uint16_t* __restrict__ o, int64_t o_stride_h,
+                                                         int64_t o_stride_l, int64_t L, int Qb) {
+  extern __shared__ __attribute__((aligned(16))) char smem_lo[];
+  char* kvs = smem_lo;               // kvsum^T [d2][d1] DT, 256-B rows, swizzled
+  char* wps = smem_lo + 128 * 256;   // Wp [d3][d2 in MFMA k order] DT
+  typedef typename MmaT<DT>::frag frag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y;
+
+  for (int i = tid; i < 128 * 16; i += 256) {  // 16-B vectors of kvsum^T
+    const int row = i >> 4, slot = i & 15;
+    *reinterpret_cast<uint4*>(kvs + sw256(row, slot)) =
+        *reinterpret_cast<const uint4*>(kvT + (int64_t)h * 128 * 128 + row * 128 + slot * 8);
+  }
+  for (int i = tid; i < 128 * 128; i += 256) {  // Wp fp32 -> DT (autocast), permuted k order
+    const int d3 = i >> 7, d2 = i & 127;
+    const int pos = perm_pos(d2 & 15);
+    const uint32_t slot = (uint32_t)((d2 >> 4) * 2 + (pos >> 3));
+    *reinterpret_cast<uint16_t*>(wps + sw256(d3, slot) + (pos & 7) * 2) =
+        (uint16_t)f32_to_half_bits<DT>(wp[i]);
+  }
+  __syncthreads();
+
+  // this lane's half of ksum: d1 = 16*ks + 8*hi + e
+  float ksf[8][8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    unpack8<DT>(*reinterpret_cast<const uint4*>(ksum + h * 128 + 16 * ks + 8 * hi), ksf[ks]);
+
+  for (int qq = 0; qq < LO_QB_PER_WG; ++qq) {
+    const int qb = blockIdx.x * LO_QB_PER_WG + qq;
+    if (qb >= Qb) break;
+    int64_t tok = (int64_t)qb * 128 + wave * 32 + li;
+    const bool ok = tok < L;
+    if (!ok) tok = L - 1;
+    // ---- cq = softmax_D(q) rounded; lane holds d1 = 16ks + 8hi + e ----
+    float qf[8][8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      unpack8<DT>(*reinterpret_cast<const uint4*>(q + ((int64_t)h * L + tok) * 128 + 16 * ks + 8 * hi), qf[ks]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) mx = fmaxf(mx, qf[ks][e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { qf[ks][e] = expf(qf[ks][e] - mx); sum += qf[ks][e]; }
+    sum += __shfl_xor(sum, 32, 64);
+    float den = 0.f;
+    uint4 cqf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float cq = half_bits_to_f32<DT>(f32_to_half_bits<DT>(qf[ks][e] / sum));
+        qf[ks][e] = cq;
+        den += half_bits_to_f32<DT>(f32_to_half_bits<DT>(cq * ksf[ks][e]));  // (q * ksum) in dt
+      }
+      cqf[ks] = pack8<DT>(qf[ks]);
+    }
+    den += __shfl_xor(den, 32, 64);
+    den = half_bits_to_f32<DT>(f32_to_half_bits<DT>(den));            // .sum(-1) -> dt
+    den = half_bits_to_f32<DT>(f32_to_half_bits<DT>(1e-5f + den));    // 1e-5 + ... -> dt
+    // ---- num^T[d2][tok] = kvsum^T . cq^T ----
+    v16f a1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[c][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const frag af = *reinterpret_cast<const frag*>(kvs + sw256(32 * c + li, 2 * ks + hi));
+        const frag bf = *reinterpret_cast<const frag*>(&cqf[ks]);
+        a1[c] = MmaT<DT>::mma(af, bf, a1[c]);
+      }
+    }
+    // ---- o_l = dt(dt(num) / den); its registers are the B fragments of the projection ----
+    uint4 olf[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float num = half_bits_to_f32<DT>(f32_to_half_bits<DT>(a1[c][r]));
+        t[r] = num / den;
+      }
+      olf[2 * c] = pack8<DT>(&t[0]);
+      olf[2 * c + 1] = pack8<DT>(&t[8]);
+    }
+    // ---- out^T[d3][tok] = Wp . o_l^T ----
+    uint16_t* op = o + (int64_t)h * o_stride_h + tok * o_stride_l;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v16f a2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const frag af = *reinterpret_cast<const frag*>(wps + sw256(32 * c + li, 2 * ks + hi));
+        const frag bf = *reinterpret_cast<const frag*>(&olf[ks]);
+        a2 = MmaT<DT>::mma(af, bf, a2);
+      }
+      if (ok) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d3 = 32 * c + 8 * g4 + 4 * hi;
+          const float4 bb = *reinterpret_cast<const float4*>(bp + d3);
+          const float bias[4] = {bb.x, bb.y, bb.z, bb.w};
+          const uint2 ov = *reinterpret_cast<const uint2*>(op + d3);
+          const uint32_t ob[4] = {ov.x & 0xffffu, ov.x >> 16, ov.y & 0xffffu, ov.y >> 16};
+          uint32_t res[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float bdt = half_bits_to_f32<DT>(f32_to_half_bits<DT>(bias[e]));  // autocast bias
+            const float ol = half_bits_to_f32<DT>(f32_to_half_bits<DT>(a2[4 * g4 + e] + bdt));
+            res[e] = f32_to_half_bits<DT>(half_bits_to_f32<DT>(ob[e]) + ol);
+          }
+          *reinterpret_cast<uint2*>(op + d3) = make_uint2(res[0] | (res[1] << 16), res[2] | (res[3] << 16));
+        }
+      }
+    }
+  }
+}
+
+extern "C" int td_sla_linear_out(const void* q, int dtype, const void* kvsum_t, const void* ksum,
+                                 const float* wp, const float* bp, void* o, int64_t o_stride_h,
+                                 int64_t o_stride_l, int64_t L, int H, int D, td_stream_t stream) {
+  TD_REQUIRE(q && kvsum_t && ksum && wp && bp && o, TD_ERR_INVALID, "td_sla_linear_out: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_linear_out: D=%d (need 128)", D);
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_sla_linear_out: dtype %d", dtype);
+  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sla_linear_out: L=%lld H=%d", (long long)L, H);
+  TD_REQUIRE(o_stride_l % 4 == 0 && o_stride_h % 4 == 0, TD_ERR_UNSUPPORTED, "td_sla_linear_out: strides");
+  const int Qb = (int)td_cdiv(L, 128);
+  const int lds = 2 * 128 * 256;
+  dim3 grid((unsigned)td_cdiv(Qb, LO_QB_PER_WG), H);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16) {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_out_kernel<TD_BF16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
+    linear_out_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb);
+  } else {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_out_kernel<TD_F16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
+    linear_out_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb);
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}

@@ -1,0 +1,349 @@
+// a11 / a13 preparation kernels for gfx950 (all HBM-bound, one pass over their input):
+//   td_v_transpose     V -> per-64-key transposed tiles in MFMA operand order
+//   td_seq_mean        per-head sequence mean of K (smooth-K)
+//   td_sage_quant_pool block mean pool (+ smooth-K) and per-block INT8 quantisation
+//   td_sla_topk        pooled score + top-k -> ascending LUT
+// Reference: SLA/utils.py:21-67, SLA/core.py:197-204,213,221 (see include/turbodiffusion_amd.h).
+#include "td_common.h"
+
+// ---------------------------------------------------------------------------------------
+// V transpose: tile [64 keys][128 d] -> [128 d][64 positions], position p of a 16-key group
+// holds key (p&3) + 8*((p>>2)&1) + 4*(p>>3)  i.e. key order 0-3, 8-11, 4-7, 12-15.
+// ---------------------------------------------------------------------------------------
+template <int IDT, int ODT>
+__global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ v,
+                                                          int64_t stride_h, int64_t stride_l,
+                                                          uint16_t* __restrict__ vt, int64_t L, int Kb) {
+  // LDS tile [64 keys][128 d + 2 pad] 16-bit: the pad makes the column reads below conflict-light
+  __shared__ uint16_t tile[64][130];
+  const int tid = threadIdx.x;
+  const int kb = blockIdx.x, h = blockIdx.y;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vec = tid + 256 * i;          // 1024 vectors of 8 elements
+    const int key = vec >> 4, c8 = vec & 15;
+    const int64_t l = (int64_t)kb * 64 + key;
+    uint4 raw = make_uint4(0, 0, 0, 0);     // tail keys -> zeros (P is 0 there, V must be finite)
+    if (l < L) raw = *reinterpret_cast<const uint4*>(v + h * stride_h + l * stride_l + c8 * 8);
+    float f[8];
+    unpack8<IDT>(raw, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[key][c8 * 8 + j] = (uint16_t)f32_to_half_bits<ODT>(f[j]);
+  }
+  __syncthreads();
+  uint16_t* out = vt + ((int64_t)h * Kb + kb) * (128 * 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int vec = tid + 256 * i;          // output vector: row d = vec/8, slot = vec%8
+    const int d = vec >> 3, slot = vec & 7;
+    const int ks = slot >> 1, hi = slot & 1;
+    uint32_t w[4];
+#pragma unroll
+    for (int e2 = 0; e2 < 4; ++e2) {
+      uint32_t pr[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int e = 2 * e2 + q;
+        const int key = 16 * ks + 8 * (e >> 2) + 4 * hi + (e & 3);
+        pr[q] = tile[key][d];
+      }
+      w[e2] = pr[0] | (pr[1] << 16);
+    }
+    *reinterpret_cast<uint4*>(out + d * 64 + slot * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+extern "C" int td_v_transpose(const void* v, int in_dtype, int64_t stride_h, int64_t stride_l, void* vt,
+                              int out_dtype, int64_t L, int H, int D, td_stream_t stream) {
+  TD_REQUIRE(v && vt, TD_ERR_INVALID, "td_v_transpose: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_v_transpose: D=%d (need 128)", D);
+  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_v_transpose: L=%lld H=%d", (long long)L, H);
+  TD_REQUIRE(stride_l % 8 == 0 && stride_h % 8 == 0, TD_ERR_UNSUPPORTED, "td_v_transpose: strides");
+  const int Kb = (int)td_cdiv(L, 64);
+  dim3 grid(Kb, H);
+  hipStream_t st = (hipStream_t)stream;
+#define TD_VT(I_, O_)                                                                            \
+  v_transpose_kernel<I_, O_><<<grid, 256, 0, st>>>((const uint16_t*)v, stride_h, stride_l,       \
+                                                   (uint16_t*)vt, L, Kb)
+  if (in_dtype == TD_BF16 && out_dtype == TD_F16) TD_VT(TD_BF16, TD_F16);
+  else if (in_dtype == TD_BF16 && out_dtype == TD_BF16) TD_VT(TD_BF16, TD_BF16);
+  else if (in_dtype == TD_F16 && out_dtype == TD_F16) TD_VT(TD_F16, TD_F16);
+  else {
+    td_set_error("td_v_transpose: unsupported dtypes in=%d out=%d", in_dtype, out_dtype);
+    return TD_ERR_UNSUPPORTED;
+  }
+#undef TD_VT
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// sequence mean: two deterministic stages (no atomics): partial sums over 64 row chunks,
+// then a finalize that sums the chunks in order, divides by L and rounds once.
+// ---------------------------------------------------------------------------------------
+#define SM_CHUNKS 64
+template <int DT>
+__global__ __launch_bounds__(256) void seq_mean_partial_kernel(const uint16_t* __restrict__ k,
+                                                               float* __restrict__ ws, int64_t L) {
+  __shared__ float red[16][128];
+  const int tid = threadIdx.x, c8 = tid & 15, r0 = tid >> 4;
+  const int chunk = blockIdx.x, h = blockIdx.y;
+  const int64_t rows_per = td_cdiv(L, SM_CHUNKS);
+  const int64_t lo = chunk * rows_per, hi_ = (lo + rows_per < L) ? lo + rows_per : L;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t l = lo + r0; l < hi_; l += 16) {
+    float f[8];
+    unpack8<DT>(*reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += f[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[r0][c8 * 8 + j] = acc[j];
+  __syncthreads();
+  if (tid < 128) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][tid];
+    ws[((int64_t)h * SM_CHUNKS + chunk) * 128 + tid] = s;
+  }
+}
+template <int DT>
+__global__ __launch_bounds__(128) void seq_mean_final_kernel(const float* __restrict__ ws,
+                                                             uint16_t* __restrict__ km, int64_t L) {
+  const int h = blockIdx.x, d = threadIdx.x;
+  float s = 0.f;
+  for (int c = 0; c < SM_CHUNKS; ++c) s += ws[((int64_t)h * SM_CHUNKS + c) * 128 + d];
+  km[h * 128 + d] = (uint16_t)f32_to_half_bits<DT>(s / (float)L);
+}
+
+extern "C" int td_seq_mean(const void* k, void* km, float* ws, int dtype, int64_t L, int H, int D,
+                           td_stream_t stream) {
+  TD_REQUIRE(k && km && ws, TD_ERR_INVALID, "td_seq_mean: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_seq_mean: D=%d (need 128)", D);
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_seq_mean: dtype %d", dtype);
+  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_seq_mean: L=%lld H=%d", (long long)L, H);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(SM_CHUNKS, H);
+  if (dtype == TD_BF16) {
+    seq_mean_partial_kernel<TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, ws, L);
+    seq_mean_final_kernel<TD_BF16><<<H, 128, 0, st>>>(ws, (uint16_t*)km, L);
+  } else {
+    seq_mean_partial_kernel<TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, ws, L);
+    seq_mean_final_kernel<TD_F16><<<H, 128, 0, st>>>(ws, (uint16_t*)km, L);
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// fused mean-pool (+smooth-K) and per-block INT8 quantisation over one [BLK x 128] block
+// ---------------------------------------------------------------------------------------
+template <int DT, int BLK>
+__global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __restrict__ x,
+                                                              const uint16_t* __restrict__ km,
+                                                              uint16_t* __restrict__ pooled,
+                                                              int8_t* __restrict__ xq,
+                                                              float* __restrict__ xs, int64_t L, int nb) {
+  __shared__ float red[16][128];
+  __shared__ float wmax[4];
+  constexpr int NIT = BLK / 16;
+  const int tid = threadIdx.x, c8 = tid & 15, r0 = tid >> 4;
+  const int blk = blockIdx.x, h = blockIdx.y;
+  float kmf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (km != nullptr) unpack8<DT>(*reinterpret_cast<const uint4*>(km + h * 128 + c8 * 8), kmf);
+
+  uint4 raw[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t l = (int64_t)blk * BLK + it * 16 + r0;
+    raw[it] = make_uint4(0, 0, 0, 0);
+    if (l < L) raw[it] = *reinterpret_cast<const uint4*>(x + ((int64_t)h * L + l) * 128 + c8 * 8);
+  }
+  float psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t l = (int64_t)blk * BLK + it * 16 + r0;
+    if (l >= L) continue;
+    float f[8];
+    unpack8<DT>(raw[it], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xf = f[j] - kmf[j];                                   // fp32 (quant input)
+      amax = fmaxf(amax, fabsf(xf));
+      psum[j] += half_bits_to_f32<DT>(f32_to_half_bits<DT>(xf));        // dtype-rounded (pool input)
+    }
+  }
+  // pooled mean
+  if (pooled != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r0][c8 * 8 + j] = psum[j];
+  }
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) wmax[tid >> 6] = amax;
+  __syncthreads();
+  if (pooled != nullptr && tid < 128) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][tid];
+    const int64_t rem = L - (int64_t)blk * BLK;
+    const float cnt = (float)(rem < BLK ? rem : BLK);
+    pooled[((int64_t)h * nb + blk) * 128 + tid] = (uint16_t)f32_to_half_bits<DT>(s / cnt);
+  }
+  if (xq == nullptr) return;
+  amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  const float scale = amax / 127.0f + 1e-7f;
+  if (tid == 0) xs[(int64_t)h * nb + blk] = scale;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int64_t l = (int64_t)blk * BLK + it * 16 + r0;
+    if (l >= L) continue;
+    float f[8];
+    unpack8<DT>(raw[it], f);
+    uint32_t w[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = (f[j] - kmf[j]) / scale;          // IEEE division
+      y = y + (y >= 0.f ? 0.5f : -0.5f);
+      y = truncf(y);
+      y = fminf(fmaxf(y, -128.f), 127.f);
+      w[j >> 2] |= ((uint32_t)(int)y & 0xffu) << (8 * (j & 3));
+    }
+    *reinterpret_cast<uint2*>(xq + ((int64_t)h * L + l) * 128 + c8 * 8) = make_uint2(w[0], w[1]);
+  }
+}
+
+extern "C" int td_sage_quant_pool(const void* x, const void* km, int dtype, int pool_blk, void* pooled,
+                                  int8_t* xq, float* xs, int64_t L, int H, int D, td_stream_t stream) {
+  TD_REQUIRE(x, TD_ERR_INVALID, "td_sage_quant_pool: null input");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sage_quant_pool: D=%d (need 128)", D);
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_sage_quant_pool: dtype %d", dtype);
+  TD_REQUIRE(pool_blk == 64 || pool_blk == 128, TD_ERR_UNSUPPORTED, "td_sage_quant_pool: blk %d", pool_blk);
+  TD_REQUIRE((xq == nullptr) == (xs == nullptr), TD_ERR_INVALID, "td_sage_quant_pool: xq/xs mismatch");
+  TD_REQUIRE(pooled || xq, TD_ERR_INVALID, "td_sage_quant_pool: nothing to do");
+  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sage_quant_pool: L=%lld H=%d", (long long)L, H);
+  const int nb = (int)td_cdiv(L, pool_blk);
+  dim3 grid(nb, H);
+  hipStream_t st = (hipStream_t)stream;
+#define TD_SQP(DT_, B_)                                                                              \
+  sage_quant_pool_kernel<DT_, B_><<<grid, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)km,      \
+                                                        (uint16_t*)pooled, xq, xs, L, nb)
+  if (dtype == TD_BF16) { if (pool_blk == 64) TD_SQP(TD_BF16, 64); else TD_SQP(TD_BF16, 128); }
+  else { if (pool_blk == 64) TD_SQP(TD_F16, 64); else TD_SQP(TD_F16, 128); }
+#undef TD_SQP
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// pooled score + top-k.  One workgroup per 16 Q-block rows of one head:
+//   phase 1: thread t computes the 16 scores of K-block column j = c*256 + t (fp32 dot over
+//            D = 128, rounded to the 16-bit dtype like the reference's bf16 matmul)
+//   phase 2: each wave selects the top-k of 4 rows: binary search on the order-preserving
+//            16-bit key for the k-th largest value, then an ordered ballot compaction
+//            (ties at the threshold -> lowest index first) => ascending LUT.
+// ---------------------------------------------------------------------------------------
+#define TK_ROWS 16
+#define TK_MAXKB 2048
+template <int DT>
+__global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restrict__ pq,
+                                                       const uint16_t* __restrict__ pk,
+                                                       int32_t* __restrict__ lut, int Qb, int Kb,
+                                                       int topk) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tk[];
+  float* qs = reinterpret_cast<float*>(smem_tk);                           // [16][128] fp32
+  uint16_t* sc = reinterpret_cast<uint16_t*>(smem_tk + TK_ROWS * 128 * 4);  // [16][Kb] sortable keys
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.y, row0 = blockIdx.x * TK_ROWS;
+  for (int i = tid; i < TK_ROWS * 128; i += 256) {
+    const int r = i >> 7, d = i & 127;
+    const int qr = row0 + r < Qb ? row0 + r : Qb - 1;
+    qs[i] = half_bits_to_f32<DT>(pq[((int64_t)h * Qb + qr) * 128 + d]);
+  }
+  __syncthreads();
+  for (int j = tid; j < Kb; j += 256) {
+    float acc[TK_ROWS];
+#pragma unroll
+    for (int r = 0; r < TK_ROWS; ++r) acc[r] = 0.f;
+    const uint16_t* kr = pk + ((int64_t)h * Kb + j) * 128;
+#pragma unroll 4
+    for (int d8 = 0; d8 < 16; ++d8) {
+      float kf[8];
+      unpack8<DT>(*reinterpret_cast<const uint4*>(kr + d8 * 8), kf);
+#pragma unroll
+      for (int r = 0; r < TK_ROWS; ++r) {
+        const float* qrow = qs + r * 128 + d8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[r] = fmaf(qrow[e], kf[e], acc[r]);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < TK_ROWS; ++r) {
+      uint32_t b = f32_to_half_bits<DT>(acc[r]);
+      // order-preserving map of a 16-bit float to an unsigned key (larger value -> larger key)
+      b = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+      sc[r * Kb + j] = (uint16_t)b;
+    }
+  }
+  __syncthreads();
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = wave * 4 + rr;
+    if (row0 + r >= Qb) break;
+    const uint16_t* keys = sc + r * Kb;
+    // largest T with count(key >= T) >= topk
+    uint32_t lo = 0, hi = 0xffffu;  // invariant: count(>= lo) >= topk
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi + 1) >> 1;
+      int cnt = 0;
+      for (int j = lane; j < Kb; j += 64) cnt += keys[j] >= mid ? 1 : 0;
+      cnt = (int)wave_sum((float)cnt);
+      if (cnt >= topk) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t T = lo;
+    int gt = 0;
+    for (int j = lane; j < Kb; j += 64) gt += keys[j] > T ? 1 : 0;
+    gt = (int)wave_sum((float)gt);
+    int need_eq = topk - gt;  // how many ties at T to take (lowest index first)
+    int32_t* out = lut + ((int64_t)h * Qb + row0 + r) * topk;
+    int written = 0, eq_seen = 0;
+    for (int j0 = 0; j0 < Kb; j0 += 64) {
+      const int j = j0 + lane;
+      const uint32_t kv = j < Kb ? keys[j] : 0;
+      const bool is_gt = j < Kb && kv > T;
+      const bool is_eq = j < Kb && kv == T;
+      const unsigned long long meq = __ballot(is_eq);
+      const int eq_before = __popcll(meq & ((1ull << lane) - 1ull));
+      const bool take = is_gt || (is_eq && (eq_seen + eq_before) < need_eq);
+      const unsigned long long mt = __ballot(take);
+      if (take) out[written + __popcll(mt & ((1ull << lane) - 1ull))] = j;
+      written += __popcll(mt);
+      eq_seen += __popcll(meq);
+    }
+  }
+}
+
+extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb,
+                           int Kb, int D, int topk, td_stream_t stream) {
+  TD_REQUIRE(pq && pk && lut, TD_ERR_INVALID, "td_sla_topk: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_topk: D=%d (need 128)", D);
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_sla_topk: dtype %d", dtype);
+  TD_REQUIRE(Kb >= 1 && Kb <= TK_MAXKB, TD_ERR_UNSUPPORTED, "td_sla_topk: Kb=%d (max %d)", Kb, TK_MAXKB);
+  TD_REQUIRE(topk >= 1 && topk <= Kb, TD_ERR_INVALID, "td_sla_topk: topk=%d Kb=%d", topk, Kb);
+  TD_REQUIRE(H > 0 && Qb > 0, TD_ERR_INVALID, "td_sla_topk: H=%d Qb=%d", H, Qb);
+  const size_t lds = TK_ROWS * 128 * 4 + (size_t)TK_ROWS * Kb * 2;
+  dim3 grid((unsigned)td_cdiv(Qb, TK_ROWS), H);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16) {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<TD_BF16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2); a = true; }
+    sla_topk_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, topk);
+  } else {
+    static bool a = false;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<TD_F16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2); a = true; }
+    sla_topk_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, topk);
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}

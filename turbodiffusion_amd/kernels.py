@@ -1,0 +1,215 @@
+"""Functional wrappers: one Python function per C-ABI entry point.
+
+They allocate outputs with torch (device memory plumbing), pass raw pointers + the current
+HIP stream to libturbodiffusion_amd.so and return torch tensors.  Shapes/dtypes are checked
+here so that errors read like the reference's asserts; the library re-checks and returns a
+status for everything it cannot run.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from ._lib import call, dt_code, ptr, require_gpu, stream_ptr
+
+
+def cdiv(a: int, b: int) -> int:
+    return (a + b - 1) // b
+
+
+# ----------------------------------------------------------------------------- a16
+def quant_i8_block128(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """x [m,n] f16|bf16 -> (q int8 [m,n], s f32 [ceil(m/128), ceil(n/128)])."""
+    require_gpu(x)
+    assert x.dim() == 2 and x.is_contiguous(), "quant: need a contiguous 2-D tensor"
+    m, n = x.shape
+    q = torch.empty((m, n), dtype=torch.int8, device=x.device)
+    s = torch.empty((cdiv(m, 128), cdiv(n, 128)), dtype=torch.float32, device=x.device)
+    call("td_quant_i8_block128", ptr(x), dt_code(x.dtype), ptr(q), ptr(s), m, n, stream_ptr())
+    return q, s
+
+
+# ----------------------------------------------------------------------------- a17
+def gemm_w8a8(a_q, a_s, b_q, b_s, out_dtype=torch.bfloat16, bias=None, gelu_tanh=False, out=None):
+    require_gpu(a_q, a_s, b_q, b_s, bias)
+    assert a_q.dtype == torch.int8 and b_q.dtype == torch.int8
+    assert a_q.is_contiguous() and b_q.is_contiguous() and a_s.is_contiguous() and b_s.is_contiguous()
+    m, k = a_q.shape
+    n, k2 = b_q.shape
+    assert k == k2, "gemm_w8a8: K mismatch"
+    assert a_s.shape == (cdiv(m, 128), k // 128) and b_s.shape == (cdiv(n, 128), k // 128), "scale shapes"
+    if out is None:
+        out = torch.empty((m, n), dtype=out_dtype, device=a_q.device)
+    else:
+        assert out.shape == (m, n) and out.stride(1) == 1 and out.dtype == out_dtype
+    if bias is not None:
+        assert bias.dtype == out_dtype and bias.shape == (n,) and bias.is_contiguous()
+    call("td_gemm_w8a8", ptr(a_q), ptr(a_s), ptr(b_q), ptr(b_s), ptr(bias), ptr(out), dt_code(out_dtype),
+         L.TD_EPI_GELU_TANH if gelu_tanh else L.TD_EPI_NONE, m, n, k, out.stride(0), stream_ptr())
+    return out
+
+
+# ----------------------------------------------------------------------------- a5 / a6 / a7
+def rmsnorm(x, w, eps, out_dtype=None):
+    require_gpu(x, w)
+    assert x.is_contiguous(), "Input must be contiguous"
+    n = x.shape[-1]
+    x2 = x.reshape(-1, n)
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty(x2.shape, dtype=out_dtype, device=x.device)
+    w = w.float().contiguous()
+    call("td_rmsnorm", ptr(x2), dt_code(x.dtype), ptr(w), ptr(y), dt_code(out_dtype), float(eps),
+         x2.shape[0], n, stream_ptr())
+    return y.reshape(x.shape)
+
+
+def layernorm(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, out_dtype=None):
+    """LayerNorm over the last dim; optional fused AdaLN modulate (scale/shift f32 [B, n])."""
+    require_gpu(x, w, b, scale, shift)
+    assert x.is_contiguous(), "Input must be contiguous"
+    n = x.shape[-1]
+    x2 = x.reshape(-1, n)
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty(x2.shape, dtype=out_dtype, device=x.device)
+    if w is not None:
+        w = w.float().contiguous()
+        b = b.float().contiguous() if b is not None else torch.zeros_like(w)
+    if scale is not None:
+        scale = scale.float().contiguous().reshape(-1, n)
+        shift = shift.float().contiguous().reshape(-1, n)
+        if rows_per_batch == 0:
+            assert x2.shape[0] % scale.shape[0] == 0
+            rows_per_batch = x2.shape[0] // scale.shape[0]
+    call("td_layernorm", ptr(x2), dt_code(x.dtype), ptr(w), ptr(b), ptr(scale), ptr(shift), rows_per_batch,
+         ptr(y), dt_code(out_dtype), float(eps), x2.shape[0], n, stream_ptr())
+    return y.reshape(x.shape)
+
+
+def gated_residual_(x, y, gate=None):
+    """In place: x = x + y * gate.type_as(x)   (gate f32 [B, n] or None for a plain add)."""
+    require_gpu(x, y, gate)
+    assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape and x.dtype == y.dtype
+    n = x.shape[-1]
+    m = x.numel() // n
+    rpb = 0
+    if gate is not None:
+        gate = gate.float().contiguous().reshape(-1, n)
+        assert m % gate.shape[0] == 0
+        rpb = m // gate.shape[0]
+    call("td_gated_residual", ptr(x), ptr(y), ptr(gate), rpb, dt_code(x.dtype), m, n, stream_ptr())
+    return x
+
+
+# ----------------------------------------------------------------------------- a3 / a8
+def qk_norm_rope(src, col0, H, D, w, cos, sin, eps):
+    """src [L, ld] (a GEMM output); columns [col0, col0+H*D) -> [H, L, D] with RMSNorm over the
+    H*D columns (w f32 [H*D] or None) and interleaved RoPE (cos/sin f32 [L, D/2] or None)."""
+    require_gpu(src, w, cos, sin)
+    assert src.dim() == 2 and src.stride(1) == 1
+    Lr = src.shape[0]
+    dst = torch.empty((H, Lr, D), dtype=src.dtype, device=src.device)
+    view = src[:, col0:col0 + H * D]
+    call("td_qk_norm_rope", ptr(view), src.stride(0), ptr(w), ptr(cos), ptr(sin), ptr(dst), dt_code(src.dtype),
+         float(eps), Lr, H, D, stream_ptr())
+    return dst
+
+
+def v_transpose(v, stride_h, stride_l, L_, H, D, out_dtype):
+    """v: tensor whose element (h,l,d) is at data_ptr + h*stride_h + l*stride_l + d -> vt tiles."""
+    require_gpu(v)
+    kb = cdiv(L_, 64)
+    vt = torch.empty((H, kb, D, 64), dtype=out_dtype, device=v.device)
+    call("td_v_transpose", ptr(v), dt_code(v.dtype), stride_h, stride_l, ptr(vt), dt_code(out_dtype), L_, H, D,
+         stream_ptr())
+    return vt
+
+
+# ----------------------------------------------------------------------------- a11 / a13
+def seq_mean(k):
+    """k [H, L, D] -> km [H, D] (k.mean(dim=-2) in k's dtype)."""
+    require_gpu(k)
+    assert k.is_contiguous()
+    H, L_, D = k.shape
+    km = torch.empty((H, D), dtype=k.dtype, device=k.device)
+    ws = torch.empty((H, 64, D), dtype=torch.float32, device=k.device)
+    call("td_seq_mean", ptr(k), ptr(km), ptr(ws), dt_code(k.dtype), L_, H, D, stream_ptr())
+    return km
+
+
+def sage_quant_pool(x, km, blk, want_pool=True, want_quant=True):
+    """x [H, L, D] -> (pooled [H, nb, D] | None, xq int8 [H, L, D] | None, xs f32 [H, nb] | None)."""
+    require_gpu(x, km)
+    assert x.is_contiguous()
+    H, L_, D = x.shape
+    nb = cdiv(L_, blk)
+    pooled = torch.empty((H, nb, D), dtype=x.dtype, device=x.device) if want_pool else None
+    xq = torch.empty((H, L_, D), dtype=torch.int8, device=x.device) if want_quant else None
+    xs = torch.empty((H, nb), dtype=torch.float32, device=x.device) if want_quant else None
+    call("td_sage_quant_pool", ptr(x), ptr(km), dt_code(x.dtype), blk, ptr(pooled), ptr(xq), ptr(xs), L_, H, D,
+         stream_ptr())
+    return pooled, xq, xs
+
+
+def sla_topk(pq, pk, topk):
+    """pq [H, Qb, D], pk [H, Kb, D] -> lut int32 [H, Qb, topk] (ascending block ids)."""
+    require_gpu(pq, pk)
+    H, Qb, D = pq.shape
+    Kb = pk.shape[1]
+    lut = torch.empty((H, Qb, topk), dtype=torch.int32, device=pq.device)
+    call("td_sla_topk", ptr(pq), ptr(pk), dt_code(pq.dtype), ptr(lut), H, Qb, Kb, D, topk, stream_ptr())
+    return lut
+
+
+# ----------------------------------------------------------------------------- a9 / a12 / a13
+def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None):
+    """SageAttention INT8-QK/FP16-PV. q_i8 [H,L,128], k_i8 [H,Lk,128], vt f16 tiles; lut or None (dense).
+    out: preallocated 16-bit tensor addressed as out_ptr + h*o_stride_h + l*o_stride_l + d."""
+    require_gpu(q_i8, k_i8, vt, lut, out)
+    H, L_, D = q_i8.shape
+    Lk = k_i8.shape[1]
+    assert D == 128 and vt.dtype == torch.float16
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    nsel = 0 if lut is None else lut.shape[-1]
+    call("td_attn_i8", ptr(q_i8), ptr(q_s), ptr(k_i8), ptr(k_s), ptr(vt), ptr(lut), nsel, ptr(out),
+         dt_code(out.dtype), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, H, stream_ptr())
+    return out
+
+
+def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None):
+    """16-bit QK attention (q,k [H,L,128] bf16|f16, vt tiles same dtype)."""
+    require_gpu(q, k, vt, lut, out)
+    H, L_, D = q.shape
+    Lk = k.shape[1]
+    assert D == 128 and vt.dtype == q.dtype and out.dtype == q.dtype
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    nsel = 0 if lut is None else lut.shape[-1]
+    call("td_attn_16", ptr(q), ptr(k), ptr(vt), ptr(lut), nsel, ptr(out), dt_code(q.dtype), o_stride_h,
+         o_stride_l, float(sm_scale), L_, Lk, H, stream_ptr())
+    return out
+
+
+# ----------------------------------------------------------------------------- a14
+def sla_linear_kv(k, vt):
+    require_gpu(k, vt)
+    H, L_, D = k.shape
+    ws_kv = torch.empty((H, 16, D, D), dtype=torch.float32, device=k.device)
+    ws_ks = torch.empty((H, 16, D), dtype=torch.float32, device=k.device)
+    kv_t = torch.empty((H, D, D), dtype=k.dtype, device=k.device)
+    ksum = torch.empty((H, D), dtype=k.dtype, device=k.device)
+    call("td_sla_linear_kv", ptr(k), dt_code(k.dtype), ptr(vt), dt_code(vt.dtype), ptr(ws_kv), ptr(ws_ks),
+         ptr(kv_t), ptr(ksum), L_, H, D, stream_ptr())
+    return kv_t, ksum
+
+
+def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l):
+    require_gpu(q, kv_t, ksum, wp, bp, out)
+    H, L_, D = q.shape
+    assert wp.dtype == torch.float32 and bp.dtype == torch.float32 and wp.is_contiguous()
+    call("td_sla_linear_out", ptr(q), dt_code(q.dtype), ptr(kv_t), ptr(ksum), ptr(wp), ptr(bp), ptr(out),
+         o_stride_h, o_stride_l, L_, H, D, stream_ptr())
+    return out

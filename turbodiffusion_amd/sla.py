@@ -1,0 +1,119 @@
+"""Host-side mirror of the reference attention-module API ``turbodiffusion.SLA``
+(``/root/reference/turbodiffusion/SLA/__init__.py:16-24``, ``SLA/core.py``):
+``SparseLinearAttention`` and ``SageSparseLinearAttention`` with the same constructor
+arguments, the same ``forward(q, k, v, return_sparsity=False)`` on ``[B, L, H, D]`` tensors
+and the same trainable ``proj_l`` parameter (checkpoint key ``...local_attn.proj_l.{weight,bias}``).
+
+Everything below the module boundary is MI355X-native: block map, INT8 quantisation, the
+block-sparse attention and the linear branch are hand-written HIP kernels.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+
+__all__ = ["SparseLinearAttention", "SageSparseLinearAttention", "sparse_linear_attention_hld"]
+
+
+def _check_feature_map(feature_map):
+    if feature_map != "softmax":
+        # the published TurboDiffusion checkpoints use the default softmax map; elu/relu exist in
+        # the reference (SLA/core.py:59-75) for SLA fine-tuning only
+        raise NotImplementedError(f"Not supported feature map {feature_map}.")
+
+
+def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
+                                v_strides, blkq=128, blkk=64, dense=False):
+    """Core of both modules on head-major tensors.
+
+    q, k: [H, L, D] 16-bit (after RoPE); vt_src: tensor holding V with element (h,l,d) at
+    data_ptr + h*v_strides[0] + l*v_strides[1] + d; out: preallocated, element (h,l,d) at
+    out_ptr + h*o_stride_h + l*o_stride_l + d.  Returns (out, real_topk, Kb).
+    """
+    H, L_, D = q.shape
+    assert D == 128, "head_dim must be 128 on this build (SLA/core.py:207 allows 64|128)"
+    assert blkq == 128 and blkk == 64, "MI355X kernels are built for BLKQ=128, BLKK=64"
+    kb = K.cdiv(L_, blkk)
+    topk = min(kb, int(topk_ratio * kb))
+    pdt = torch.float16 if sage else q.dtype
+    vt = K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, pdt)
+    km = K.seq_mean(k)
+    if dense:
+        lut = None
+        pq = None
+    if sage:
+        pq, q_i8, q_s = K.sage_quant_pool(q, None, blkq, want_pool=not dense)
+        pk, k_i8, k_s = K.sage_quant_pool(k, km, blkk, want_pool=not dense)
+        if not dense:
+            lut = K.sla_topk(pq, pk, topk)
+        K.attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l)
+    else:
+        if not dense:
+            pq, _, _ = K.sage_quant_pool(q, None, blkq, want_quant=False)
+            pk, _, _ = K.sage_quant_pool(k, km, blkk, want_quant=False)
+            lut = K.sla_topk(pq, pk, topk)
+        K.attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l)
+    if proj_w is not None:
+        kv_t, ksum = K.sla_linear_kv(k, vt)
+        K.sla_linear_out_(q, kv_t, ksum, proj_w, proj_b, out, o_stride_h, o_stride_l)
+    return out, topk, kb
+
+
+class _SLABase(nn.Module):
+    def __init__(self, head_dim, topk, feature_map, use_bf16, tie_feature_map_qk):
+        super().__init__()
+        _check_feature_map(feature_map)
+        self.dtype = torch.bfloat16 if use_bf16 else torch.float16
+        self.topk = topk
+        self.head_dim = head_dim
+        self.proj_l = nn.Linear(head_dim, head_dim, dtype=torch.float32)
+        self.init_weights_()
+
+    def init_weights_(self):
+        with torch.no_grad():
+            nn.init.zeros_(self.proj_l.weight)
+            nn.init.zeros_(self.proj_l.bias)
+
+    def _forward(self, q, k, v, return_sparsity, sage, blkq, blkk):
+        dtype = q.dtype
+        B, L_, H, D = q.shape
+        outs = []
+        real = None
+        for b in range(B):  # num_samples is 1 in the reference scripts; batch = outer loop
+            qb = q[b].to(self.dtype).transpose(0, 1).contiguous()  # [H, L, D]
+            kb_ = k[b].to(self.dtype).transpose(0, 1).contiguous()
+            vb = v[b].to(self.dtype).contiguous()                  # [L, H, D]
+            out = torch.empty((L_, H, D), dtype=self.dtype, device=q.device)
+            _, real, kb_n = sparse_linear_attention_hld(
+                qb, kb_, vb, self.proj_l.weight.float().contiguous(), self.proj_l.bias.float().contiguous(),
+                self.topk, sage, out, D, H * D, (D, H * D), blkq, blkk)
+            outs.append(out)
+        o = torch.stack(outs, dim=0).to(dtype)  # [B, L, H, D]
+        if return_sparsity:
+            return o, real / kb_n
+        return o
+
+
+class SparseLinearAttention(_SLABase):
+    """SLA/core.py:38-119 — block-sparse softmax attention (16-bit QK) + linear branch."""
+
+    def __init__(self, head_dim, topk, feature_map="softmax", BLKQ=64, BLKK=64, use_bf16=True,
+                 tie_feature_map_qk=True):
+        super().__init__(head_dim, topk, feature_map, use_bf16, tie_feature_map_qk)
+        self.BLKQ = BLKQ
+        self.BLKK = BLKK
+
+    def forward(self, q, k, v, return_sparsity=False):
+        return self._forward(q, k, v, return_sparsity, sage=False, blkq=self.BLKQ, blkk=self.BLKK)
+
+
+class SageSparseLinearAttention(_SLABase):
+    """SLA/core.py:122-258 — SageAttention INT8-QK / FP16-PV sparse branch + linear branch."""
+
+    def __init__(self, head_dim, topk, feature_map="softmax", use_bf16=True, tie_feature_map_qk=True):
+        super().__init__(head_dim, topk, feature_map, use_bf16, tie_feature_map_qk)
+
+    def forward(self, q, k, v, return_sparsity=False):
+        return self._forward(q, k, v, return_sparsity, sage=True, blkq=128, blkk=64)
