@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Headline benchmark: end-to-end videos/sec of the 4-step rCM Wan-DiT denoising loop
+(BASELINE.json metric) on synthetic Wan2.1-T2V-1.3B 480p shapes, N MI355X GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload turbo|c2|c3|original]
+
+A "step" is one whole video: the 4 DiT forwards + sampler updates on latents already resident in
+HBM (text encoding / VAE are outside the metric, reference README.md:207).  For N > 1 launch with
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: the token sequence of
+every DiT step is sharded over the ranks (turbodiffusion_amd.seqpar), so total work is fixed
+("strong" scaling).  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs):
+  turbo    TurboWan2.1-T2V-1.3B-480P as published: SageSLA top-k 0.1 + W8A8 linears + fused norms
+           (the configuration the reference's 1.9 s / 0.526 video/s figure is quoted on)  [default]
+  c2       configs[1]: dense SageAttention INT8-QK (no sparsity), W8A8 linears, fused norms
+  c3       configs[2]: SageSLA top-k 0.1, bf16 library linears
+  original dense bf16 attention, bf16 library linears (the arithmetic of configs[0] on the GPU)
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BASELINE_VIDEOS_PER_S = 1.0 / 1.9  # README.md:32,298 — TurboWan2.1-T2V-1.3B-480P, 1x RTX 5090
+HBM_PEAK = 8.0e12                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+I8_PEAK = 5.0e15                   # dense INT8 MFMA (= dense FP8 rate), MI355X_MICROARCH.md
+RES = {"480p": (832, 480), "720p": (1280, 720)}
+WORKLOADS = {
+    "turbo": dict(attention_type="sagesla", quant_linear=True,
+                  desc="TurboWan2.1-T2V-1.3B-480P 4-step: SageSLA top-k 0.1 + W8A8 + fused norms"),
+    "c2": dict(attention_type="sage", quant_linear=True,
+               desc="Wan2.1-T2V-1.3B 480p 4-step: dense SageAttention INT8-QK + W8A8 + fused norms"),
+    "c3": dict(attention_type="sagesla", quant_linear=False,
+               desc="Wan2.1-T2V-1.3B 480p 4-step: SageSLA top-k 0.1, bf16 linears"),
+    "original": dict(attention_type="original", quant_linear=False,
+                     desc="Wan2.1-T2V-1.3B 480p 4-step: dense bf16 attention, bf16 linears"),
+}
+
+
+def build_model(name, wl, dev, topk, num_layers=None):
+    from turbodiffusion_amd.wan import MODEL_CONFIGS, WanModel
+    from turbodiffusion_amd import kernels as K
+
+    cfg = dict(MODEL_CONFIGS[name])
+    if num_layers:
+        cfg["num_layers"] = num_layers
+    with torch.device(dev):
+        net = WanModel(attention_type=wl["attention_type"], sla_topk=topk, quant_linear=wl["quant_linear"], **cfg)
+    g = torch.Generator(device=dev).manual_seed(0)
+    dim = cfg["dim"]
+    with torch.no_grad():
+        for name_, mod in net.named_modules():
+            if hasattr(mod, "int8_weight"):  # Int8Linear: seeded bf16 weight -> HIP block quantiser
+                o, i = mod.int8_weight.shape
+                w = (torch.randn(o, i, device=dev, generator=g) * (1.0 / math.sqrt(i))).bfloat16()
+                mod.int8_weight, mod.scale = K.quant_i8_block128(w)
+                mod.bias = (torch.randn(o, device=dev, generator=g) * 0.02).bfloat16()
+            elif isinstance(mod, torch.nn.Linear):
+                std = 0.02 if ("proj_l" in name_ or "embedding" in name_ or "projection" in name_ or "head" in name_) \
+                    else 1.0 / math.sqrt(mod.in_features)
+                mod.weight.copy_((torch.randn(mod.weight.shape, device=dev, generator=g) * std).to(mod.weight.dtype))
+                mod.bias.copy_((torch.randn(mod.bias.shape, device=dev, generator=g) * 0.02).to(mod.bias.dtype))
+            elif hasattr(mod, "weight") and isinstance(getattr(mod, "weight"), torch.Tensor) and mod.weight is not None \
+                    and mod.weight.dim() == 1:
+                mod.weight = (1 + 0.1 * torch.randn(mod.weight.shape, device=dev, generator=g)).to(mod.weight.dtype)
+                if getattr(mod, "bias", None) is not None:
+                    mod.bias = (0.02 * torch.randn(mod.bias.shape, device=dev, generator=g)).to(mod.bias.dtype)
+        for blk in net.blocks:
+            blk.modulation.copy_(torch.randn(1, 6, dim, device=dev, generator=g) / math.sqrt(dim))
+        net.head.modulation.copy_(torch.randn(1, 2, dim, device=dev, generator=g) / math.sqrt(dim))
+    return net.eval(), cfg
+
+
+def cpu_baseline(cfg, lat_shape, topk):
+    """Oracle port of the reference's ORIGINAL eager path (config C1: SDPA, plain Linear, eager norms)
+    timed on the host cores on a bounded sample: ONE of the 30 blocks (+ embeddings) of ONE DiT step at
+    the full token count; extrapolated to 4 steps x num_layers blocks."""
+    from oracle import wan_ref as W
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    c1 = dict(cfg, num_layers=1)
+    sd = W.make_state_dict(c1, seed=0, with_proj_l=False)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(lat_shape, generator=g)
+    ctx = torch.randn(1, 512, cfg.get("text_dim", 4096), generator=g).bfloat16()
+    t = torch.tensor([[987.654]]).bfloat16()
+    t0 = time.time()
+    with torch.no_grad():
+        W.wan_forward(sd, c1, x, t, ctx, mode="eager", act_dtype=torch.bfloat16, return_tokens=True)
+    dt_blk = time.time() - t0
+    video_s = 4 * cfg["num_layers"] * dt_blk
+    return {"value": 1.0 / video_s, "unit": "videos/s", "cores": cores, "kind": "port",
+            "sample": f"oracle eager bf16 DiT (SDPA + nn.Linear), 1 of {cfg['num_layers']} blocks of 1 of 4 steps at "
+                      f"full L, {dt_blk:.1f} s measured, x{4 * cfg['num_layers']} extrapolated"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3, help="timed videos (each = 4 DiT steps)")
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="turbo", choices=sorted(WORKLOADS))
+    ap.add_argument("--model", default="Wan2.1-1.3B")
+    ap.add_argument("--res", default="480p", choices=sorted(RES))
+    ap.add_argument("--num-steps", type=int, default=4, help="sampler steps per video")
+    ap.add_argument("--topk", type=float, default=0.1)
+    ap.add_argument("--layers", type=int, default=0, help="debug: override num_layers (INVALID as a bench number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from turbodiffusion_amd import kernels as K
+    from turbodiffusion_amd.sampler import rcm_sample
+
+    wl = WORKLOADS[args.workload]
+    net, cfg = build_model(args.model, wl, dev, args.topk, args.layers or None)
+    if world > 1:
+        from turbodiffusion_amd import seqpar
+        seqpar.enable(net, dist.group.WORLD)
+
+    w, h = RES[args.res]
+    lat_shape = (1, 16, 21, h // 8, w // 8)  # 81 frames -> 21 latent frames, VAE 8x spatial
+    L_tok = 21 * (h // 16) * (w // 16)
+    g = torch.Generator(device=dev).manual_seed(0)
+    init_noise = torch.randn(lat_shape, dtype=torch.float32, device=dev, generator=g)
+    text = torch.randn(1, 512, cfg.get("text_dim", 4096), device=dev, generator=g).bfloat16()
+    y = None
+    if cfg["model_type"] == "i2v":
+        y = torch.cat([torch.zeros(1, 4, *lat_shape[2:], device=dev),
+                       torch.randn(1, 16, *lat_shape[2:], device=dev, generator=g)], 1)
+        y[:, :4, 0] = 1.0
+
+    def one_video():
+        return rcm_sample(net, init_noise, text, num_steps=args.num_steps, generator=g, y=y)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_video()
+    timer = K.KernelTimer({"td_gemm_w8a8", "td_attn_i8"})
+    K.set_timer(timer)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_video()
+    sync()
+    elapsed = time.perf_counter() - t0
+    K.set_timer(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(out).all(), "non-finite latents"
+
+    if rank == 0:
+        per_video = elapsed / args.steps
+        value = 1.0 / per_video
+        summ = timer.summary()
+        roof = None
+        if "td_gemm_w8a8" in summ and wl["quant_linear"]:
+            gs = summ["td_gemm_w8a8"]
+            flops = sum(2.0 * m * n * k for (m, n, k) in gs["metas"]) / gs["launches"]
+            ach = flops / (gs["avg_ms"] * 1e-3)
+            roof = {"kernel": "gemm_w8a8_kernel (W8A8 block-scaled INT8 GEMM)", "bound": "mfma",
+                    "achieved": ach / 1e12, "peak": I8_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / I8_PEAK,
+                    "traffic": None, "avg_launch_ms": gs["avg_ms"], "launches": gs["launches"],
+                    "share_of_step": gs["total_ms"] * 1e-3 / elapsed}
+        roof_attn = None
+        if "td_attn_i8" in summ:
+            a = summ["td_attn_i8"]
+            by = 0.0
+            for (H, L_, Lk, nsel) in a["metas"]:
+                qb, kb = (L_ + 127) // 128, (Lk + 63) // 64
+                ns = nsel if nsel else kb
+                by += H * qb * (128 * 128 * 1 + ns * 64 * 128 * 3 + 128 * 128 * 2)
+            by /= a["launches"]
+            ach = by / (a["avg_ms"] * 1e-3)
+            roof_attn = {"kernel": "attn_kernel<int8 QK, fp16 PV>", "bound": "hbm", "achieved": ach / 1e9,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                         "avg_launch_ms": a["avg_ms"], "launches": a["launches"],
+                         "share_of_step": a["total_ms"] * 1e-3 / elapsed}
+        if roof is None:
+            roof = roof_attn
+        res = {
+            "metric": "end-to-end videos/sec (4-step rCM denoising loop, Wan2.1-1.3B 480p)",
+            "value": value, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": per_video * 1e3, "dit_step_ms": per_video * 1e3 / args.num_steps,
+            "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": (value / BASELINE_VIDEOS_PER_S) if (args.workload == "turbo" and args.model == "Wan2.1-1.3B"
+                                                              and args.res == "480p" and not args.layers) else None,
+            "dtype": "int8 (W8A8 linears, QK^T) + fp16 PV + bf16 activations" if wl["quant_linear"] else "bf16 (+int8 QK^T)",
+            "data": "synthetic (seeded N(0,1) latents/text embedding, random-init weights of the named architecture)",
+            "config": {"workload": wl["desc"], "model": args.model, "resolution": args.res, "tokens": L_tok,
+                       "sampler_steps": args.num_steps, "sla_topk": args.topk,
+                       "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (RCCL all-gather of K/V)"},
+            "roofline": roof, "roofline_attention": roof_attn,
+        }
+        if args.layers:
+            res["config"]["DEBUG_num_layers_override"] = args.layers
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, lat_shape, args.topk)
+            except Exception as e:  # the baseline is reported, never required for the GPU number
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,12 @@ int td_v_transpose(const void* v, int in_dtype, int64_t stride_h, int64_t stride
  * ws: f32 workspace [H, 64, D] (deterministic two-stage sum, no atomics). */
 int td_seq_mean(const void* k, void* km, float* ws, int dtype, int64_t L, int H, int D,
                 td_stream_t stream);
+/* the two stages of td_seq_mean, exposed for sequence parallelism: each rank computes the 64 partial
+ * sums of ITS tokens (ws [H, 64, D]); after an all-gather the final stage sums `nch` partials found at
+ * ws + h*stride_h + c*stride_c (+d) in order, divides by the GLOBAL length and rounds once. */
+int td_seq_sum_partial(const void* k, float* ws, int dtype, int64_t L, int H, int D, td_stream_t stream);
+int td_seq_mean_final(const float* ws, int nch, int64_t stride_h, int64_t stride_c, void* km, int dtype,
+                      int64_t L_total, int H, int D, td_stream_t stream);
 
 /* ---- a11 + a13 fused pass over Q or K [H, L, D] (D == 128):
  *  - block mean pool (mean_pool, SLA/utils.py:43-52) of x (Q) or of cast(x - km) (K, smooth-K
@@ -131,27 +137,30 @@ int td_sage_quant_pool(const void* x, const void* km, int dtype, int pool_blk, v
 /* ---- a11: pooled score + top-k block selection (SLA/utils.py:59-66) ----
  * score[h,i,j] = cast(sum_d pq[h,i,d]*pk[h,j,d]) (16-bit rounding like the reference's
  * bf16 matmul); select the `topk` largest per row (ties -> lower index), write ascending
- * block ids to lut [H, Qb, topk] int32. Kb <= 2048. */
+ * block ids to lut [H, Qb, topk] int32. Kb <= 2048. pk is [H, Kb_alloc, D] (Kb_alloc >= Kb rows
+ * allocated per head; 0 means Kb). */
 int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb, int Kb,
-                int D, int topk, td_stream_t stream);
+                int Kb_alloc, int D, int topk, td_stream_t stream);
 
 /* ---- a13 / a9: SageAttention INT8-QK, FP16-PV, fp32 softmax+accumulate ----
  * q_i8 [H, L, 128] int8, q_s [H, ceil(L/128)], k_i8 [H, Lk, 128] int8, k_s [H, ceil(Lk/64)],
  * vt from td_v_transpose (f16) [H, ceil(Lk/64), 128, 64].
  * lut [H, Qb, nsel] ascending K-block ids, or NULL for dense attention (all K blocks).
  * o: 16-bit, element (h, l, d) at o + h*o_stride_h + l*o_stride_l + d.
- * sm_scale: softmax scale (D^-0.5). */
+ * sm_scale: softmax scale (D^-0.5).
+ * Lk_alloc: K rows ALLOCATED per head in k_i8 (and Lk_alloc/64 blocks per head in k_s / vt); 0 = Lk.
+ * (> Lk for the rank-padded gathered layout of sequence parallelism; must then be a multiple of 64.) */
 int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
                const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
                int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
-               int H, td_stream_t stream);
+               int64_t Lk_alloc, int H, td_stream_t stream);
 
 /* ---- a12 / a9 / a4: 16-bit QK attention (SLA Triton arithmetic; dense cross-attention) ----
  * q [H, L, 128], k [H, Lk, 128] dtype (bf16|f16); vt [H, ceil(Lk/64), 128, 64] same dtype;
  * P is rounded to dtype before P@V (SLA/kernel.py:68). lut as above. */
 int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
                int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
-               int64_t Lk, int H, td_stream_t stream);
+               int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream);
 
 /* ---- a14: linear-attention branch (SLA/core.py:243-253, feature_map = softmax) ----
  * pass 1: ck = cast(softmax_D(k)); kvsum[h] = cast(ck^T @ v) ; ksum[h] = cast(sum_L ck)
@@ -161,6 +170,15 @@ int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut,
 int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
                      float* ws_ks, void* kvsum_t, void* ksum, int64_t L, int H, int D,
                      td_stream_t stream);
+/* the two stages of pass 1 (sequence parallelism: partial on each rank's tokens, all-gather, final).
+ * final sums `nch` partials found at ws_kv + h*kv_stride_h + c*kv_stride_c (+i) [same for ks] and writes
+ * out_dtype f16|bf16: kvsum_t TRANSPOSED + rounded, ksum rounded;  out_dtype f32: the un-rounded,
+ * un-transposed fp32 sums [H,D,D] / [H,D] (a rank's contribution to the gather). */
+int td_sla_linear_kv_partial(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
+                             float* ws_ks, int64_t L, int H, int D, td_stream_t stream);
+int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, int nch, int64_t kv_stride_h,
+                           int64_t kv_stride_c, int64_t ks_stride_h, int64_t ks_stride_c, void* kv_out,
+                           void* ks_out, int out_dtype, int H, int D, td_stream_t stream);
 /* pass 2: cq = cast(softmax_D(q)); o_l = cast(cast(cq@kvsum)/cast(1e-5 + cast(sum_D cast(cq*ksum))));
  *   o_l = cast(o_l @ cast(Wp)^T + cast(bp)) (proj_l under autocast); o[h,l,:] = cast(o[h,l,:] + o_l)
  *   (o addressed with the same strides as td_attn_*; updated in place).

@@ -144,3 +144,36 @@ def make_reference_wan(cfg: dict, seed: int = 0, dtype=None):
     if dtype is not None:
         net = net.to(dtype)
     return net
+
+
+FP32_ISLANDS = ("time_embedding", "time_projection", "head.head", "norm3")
+
+
+def reference_wan_from_sd(cfg: dict, sd: dict, act_dtype=None):
+    """Reference WanModel (wan2pt1) holding exactly the weights of ``sd`` (reference key names).
+
+    ``act_dtype=torch.bfloat16`` emulates the CUDA run of a bf16 checkpoint on the CPU: CUDA's
+    ``amp.autocast("cuda", dtype=float32)`` islands (wan2pt1.py:211,399,405,412,451,671) run
+    Linear / LayerNorm in fp32 with the bf16 weights up-cast; CPU autocast cannot target fp32, so
+    the parameters those islands touch (time_embedding, time_projection, head.head, norm3.{weight,
+    bias}) are KEPT in fp32 (their values are bf16-representable) while everything else is cast to
+    bf16 — the arithmetic is then identical.  act_dtype=None keeps a plain fp32 model."""
+    import torch
+
+    mod = load("wan2pt1")
+    ref_cfg = {k: v for k, v in cfg.items() if k in (
+        "model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim", "freq_dim", "text_dim", "out_dim",
+        "num_heads", "num_layers", "qk_norm", "cross_attn_norm", "eps")}
+    net = mod.WanModel(**ref_cfg)
+    own = net.state_dict()
+    load_sd = {k: v for k, v in sd.items() if k in own}
+    missing = [k for k in own if k not in load_sd]
+    assert not missing, f"missing {missing[:4]}"
+    net.load_state_dict(load_sd)
+    net.eval()
+    if act_dtype is not None:
+        for name, p in net.named_parameters():
+            clean = name.replace("_checkpoint_wrapped_module.", "")
+            if not any(isl in clean for isl in FP32_ISLANDS):
+                p.data = p.data.to(act_dtype)
+    return net

@@ -33,9 +33,13 @@ SIGNATURES = {
     "td_v_transpose": [_vp, _i32, _i64, _i64, _vp, _i32, _i64, _i32, _i32, _vp],
     "td_seq_mean": [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
     "td_sage_quant_pool": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
-    "td_sla_topk": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
-    "td_attn_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _vp],
-    "td_attn_16": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _vp],
+    "td_seq_sum_partial": [_vp, _vp, _i32, _i64, _i32, _i32, _vp],
+    "td_seq_mean_final": [_vp, _i32, _i64, _i64, _vp, _i32, _i64, _i32, _i32, _vp],
+    "td_sla_topk": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "td_attn_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
+    "td_attn_16": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
+    "td_sla_linear_kv_partial": [_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
+    "td_sla_linear_kv_final": [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _vp],
     "td_sla_linear_kv": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_out": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
 }

@@ -38,6 +38,8 @@ struct AttnParams {
   float scale_log2;    // sm_scale * log2(e)
   int64_t L, Lk;
   int H, Qb, Kb, nsel;
+  int64_t k_rows_alloc;  // K rows allocated per head (>= Lk; gathered sequence-parallel layout)
+  int kb_alloc;          // K blocks allocated per head in vt / k_s
 };
 
 template <bool QK_I8> struct KTile {
@@ -114,11 +116,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     int64_t kr_ = (int64_t)(kb_) * 64 + v_ / (KT::ROWB / 16);                              \
     if (kr_ > p.Lk - 1) kr_ = p.Lk - 1;                                                    \
     sk##i_ = *reinterpret_cast<const uint4*>((const char*)p.k +                            \
-                 ((int64_t)h * p.Lk + kr_) * KT::ROWB + (v_ % (KT::ROWB / 16)) * 16);       \
+                 ((int64_t)h * p.k_rows_alloc + kr_) * KT::ROWB + (v_ % (KT::ROWB / 16)) * 16);       \
   }
 #define VLOAD1(i_, kb_)                                                                    \
   sv##i_ = *reinterpret_cast<const uint4*>((const char*)p.vt +                             \
-               (((int64_t)h * p.Kb + (kb_)) * VT_BYTES) + (int64_t)(tid + 256 * i_) * 16);
+               (((int64_t)h * p.kb_alloc + (kb_)) * VT_BYTES) + (int64_t)(tid + 256 * i_) * 16);
 #define TLOAD(kb_) KLOAD1(0, kb_) KLOAD1(1, kb_) KLOAD1(2, kb_) KLOAD1(3, kb_) \
                    VLOAD1(0, kb_) VLOAD1(1, kb_) VLOAD1(2, kb_) VLOAD1(3, kb_)
 #define KSTORE1(i_, base_) if (i_ < KT::NVEC) *reinterpret_cast<uint4*>((base_) + koff[i_]) = sk##i_;
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
           v4i qv; qv[0] = qf[kc].x; qv[1] = qf[kc].y; qv[2] = qf[kc].z; qv[3] = qf[kc].w;
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qv, acc, 0, 0, 0);
         }
-        const float mult = (qs * p.k_s[(int64_t)h * p.Kb + kb]) * p.scale_log2;
+        const float mult = (qs * p.k_s[(int64_t)h * p.kb_alloc + kb]) * p.scale_log2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[g][r] = (float)acc[r] * mult;
       }
@@ -288,7 +290,7 @@ static int attn_common_checks(const char* who, const void* q, const void* k, con
 extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
                           const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
                           int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
-                          int64_t Lk, int H, td_stream_t stream) {
+                          int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream) {
   int rc = attn_common_checks("td_attn_i8", q_i8, k_i8, vt, o, nsel, L, Lk, H, lut);
   if (rc) return rc;
   TD_REQUIRE(q_s && k_s, TD_ERR_INVALID, "td_attn_i8: null scale pointer");
@@ -299,6 +301,9 @@ extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
+  if (Lk_alloc == 0) Lk_alloc = Lk;
+  TD_REQUIRE(Lk_alloc >= Lk && (Lk_alloc == Lk || Lk_alloc % 64 == 0), TD_ERR_INVALID, "attn: Lk_alloc=%lld", (long long)Lk_alloc);
+  p.k_rows_alloc = Lk_alloc; p.kb_alloc = (int)td_cdiv(Lk_alloc, 64);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == TD_BF16) return launch_attn<true, TD_F16, TD_BF16>(p, st);
   return launch_attn<true, TD_F16, TD_F16>(p, st);
@@ -306,7 +311,7 @@ extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_
 
 extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel,
                           void* o, int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale,
-                          int64_t L, int64_t Lk, int H, td_stream_t stream) {
+                          int64_t L, int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream) {
   int rc = attn_common_checks("td_attn_16", q, k, vt, o, nsel, L, Lk, H, lut);
   if (rc) return rc;
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_attn_16: dtype %d", dtype);
@@ -315,6 +320,9 @@ extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const in
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
+  if (Lk_alloc == 0) Lk_alloc = Lk;
+  TD_REQUIRE(Lk_alloc >= Lk && (Lk_alloc == Lk || Lk_alloc % 64 == 0), TD_ERR_INVALID, "attn: Lk_alloc=%lld", (long long)Lk_alloc);
+  p.k_rows_alloc = Lk_alloc; p.kb_alloc = (int)td_cdiv(Lk_alloc, 64);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16) return launch_attn<false, TD_BF16, TD_BF16>(p, st);
   return launch_attn<false, TD_F16, TD_F16>(p, st);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const void* __restrict__
         load8f(shift + bi * n + col, hv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float xn = RowIO<ODT>::rnd(o[j]);  // the norm's own cast to x.dtype
+          const float xn = RowIO<IDT>::rnd(o[j]);  // the norm's own cast back to x.dtype (.type_as(x))
           const float t = xn * (1.0f + sv[j]);
           o[j] = t + hv[j];
         }
@@ -167,6 +167,10 @@ static int dispatch_norm(const char* who, const void* x, int idt, const float* w
     return launch_norm<TD_F32, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
   if (idt == TD_F32 && odt == TD_BF16)
     return launch_norm<TD_F32, TD_BF16, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
+  if (idt == TD_BF16 && odt == TD_F32)  // the head: fp32 modulate of the bf16-rounded norm (wan2pt1.py:453)
+    return launch_norm<TD_BF16, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
+  if (idt == TD_F16 && odt == TD_F32)
+    return launch_norm<TD_F16, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
   td_set_error("%s: unsupported dtype pair in=%d out=%d", who, idt, odt);
   return TD_ERR_UNSUPPORTED;
 }

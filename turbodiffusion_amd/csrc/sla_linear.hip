@@ -156,50 +156,85 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
 }
 
 // pass 1b: sum partials in order, round once; kvsum is written TRANSPOSED ([d2][d1]) because
-// that is the A operand of pass 2.
-template <int DT>
+// that is the A operand of pass 2.  Partial (h, c) lives at ws + h*stride_h + c*stride_c, so the
+// same kernel finishes the single-GPU workspace [H,16,..] and a rank-major gathered [N,H,..] one.
+template <int DT, bool ROUND>
 __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __restrict__ ws_kv,
-                                                              const float* __restrict__ ws_ks,
-                                                              uint16_t* __restrict__ kvT,
-                                                              uint16_t* __restrict__ ksum) {
+                                                              const float* __restrict__ ws_ks, int nch,
+                                                              int64_t kv_sh, int64_t kv_sc, int64_t ks_sh,
+                                                              int64_t ks_sc, void* __restrict__ kv_out,
+                                                              void* __restrict__ ks_out) {
   const int h = blockIdx.x;
   for (int i = threadIdx.x; i < 128 * 128; i += 256) {
     float s = 0.f;
-    for (int c = 0; c < LK_NCH; ++c) s += ws_kv[((int64_t)h * LK_NCH + c) * (128 * 128) + i];
-    const int d1 = i >> 7, d2 = i & 127;
-    kvT[(int64_t)h * 128 * 128 + d2 * 128 + d1] = (uint16_t)f32_to_half_bits<DT>(s);
+    for (int c = 0; c < nch; ++c) s += ws_kv[h * kv_sh + c * kv_sc + i];
+    if constexpr (ROUND) {
+      const int d1 = i >> 7, d2 = i & 127;
+      ((uint16_t*)kv_out)[(int64_t)h * 128 * 128 + d2 * 128 + d1] = (uint16_t)f32_to_half_bits<DT>(s);
+    } else {
+      ((float*)kv_out)[(int64_t)h * 128 * 128 + i] = s;  // fp32, NOT transposed: still a partial
+    }
   }
   if (threadIdx.x < 128) {
     float s = 0.f;
-    for (int c = 0; c < LK_NCH; ++c) s += ws_ks[((int64_t)h * LK_NCH + c) * 128 + threadIdx.x];
-    ksum[h * 128 + threadIdx.x] = (uint16_t)f32_to_half_bits<DT>(s);
+    for (int c = 0; c < nch; ++c) s += ws_ks[h * ks_sh + c * ks_sc + threadIdx.x];
+    if constexpr (ROUND) ((uint16_t*)ks_out)[h * 128 + threadIdx.x] = (uint16_t)f32_to_half_bits<DT>(s);
+    else ((float*)ks_out)[h * 128 + threadIdx.x] = s;
   }
+}
+
+extern "C" int td_sla_linear_kv_partial(const void* k, int dtype, const void* vt, int vt_dtype,
+                                        float* ws_kv, float* ws_ks, int64_t L, int H, int D,
+                                        td_stream_t stream) {
+  TD_REQUIRE(k && vt && ws_kv && ws_ks, TD_ERR_INVALID, "td_sla_linear_kv_partial: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_linear_kv_partial: D=%d (need 128)", D);
+  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sla_linear_kv_partial: L=%lld H=%d", (long long)L, H);
+  const int Kb = (int)td_cdiv(L, 64);
+  dim3 grid(LK_NCH, H);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16 && vt_dtype == TD_F16)
+    linear_kv_partial_kernel<TD_BF16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+  else if (dtype == TD_BF16 && vt_dtype == TD_BF16)
+    linear_kv_partial_kernel<TD_BF16, TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+  else if (dtype == TD_F16 && vt_dtype == TD_F16)
+    linear_kv_partial_kernel<TD_F16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+  else {
+    td_set_error("td_sla_linear_kv_partial: unsupported dtypes k=%d vt=%d", dtype, vt_dtype);
+    return TD_ERR_UNSUPPORTED;
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+extern "C" int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, int nch, int64_t kv_stride_h,
+                                      int64_t kv_stride_c, int64_t ks_stride_h, int64_t ks_stride_c,
+                                      void* kv_out, void* ks_out, int out_dtype, int H, int D,
+                                      td_stream_t stream) {
+  TD_REQUIRE(ws_kv && ws_ks && kv_out && ks_out, TD_ERR_INVALID, "td_sla_linear_kv_final: null pointer");
+  TD_REQUIRE(D == 128 && nch > 0 && H > 0, TD_ERR_UNSUPPORTED, "td_sla_linear_kv_final: D=%d nch=%d", D, nch);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == TD_BF16)
+    linear_kv_final_kernel<TD_BF16, true><<<H, 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+  else if (out_dtype == TD_F16)
+    linear_kv_final_kernel<TD_F16, true><<<H, 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+  else if (out_dtype == TD_F32)
+    linear_kv_final_kernel<TD_F32, false><<<H, 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+  else {
+    td_set_error("td_sla_linear_kv_final: out dtype %d", out_dtype);
+    return TD_ERR_UNSUPPORTED;
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
 }
 
 extern "C" int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
                                 float* ws_ks, void* kvsum_t, void* ksum, int64_t L, int H, int D,
                                 td_stream_t stream) {
-  TD_REQUIRE(k && vt && ws_kv && ws_ks && kvsum_t && ksum, TD_ERR_INVALID, "td_sla_linear_kv: null pointer");
-  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_linear_kv: D=%d (need 128)", D);
-  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sla_linear_kv: L=%lld H=%d", (long long)L, H);
-  const int Kb = (int)td_cdiv(L, 64);
-  dim3 grid(LK_NCH, H);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == TD_BF16 && vt_dtype == TD_F16) {
-    linear_kv_partial_kernel<TD_BF16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
-    linear_kv_final_kernel<TD_BF16><<<H, 256, 0, st>>>(ws_kv, ws_ks, (uint16_t*)kvsum_t, (uint16_t*)ksum);
-  } else if (dtype == TD_BF16 && vt_dtype == TD_BF16) {
-    linear_kv_partial_kernel<TD_BF16, TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
-    linear_kv_final_kernel<TD_BF16><<<H, 256, 0, st>>>(ws_kv, ws_ks, (uint16_t*)kvsum_t, (uint16_t*)ksum);
-  } else if (dtype == TD_F16 && vt_dtype == TD_F16) {
-    linear_kv_partial_kernel<TD_F16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
-    linear_kv_final_kernel<TD_F16><<<H, 256, 0, st>>>(ws_kv, ws_ks, (uint16_t*)kvsum_t, (uint16_t*)ksum);
-  } else {
-    td_set_error("td_sla_linear_kv: unsupported dtypes k=%d vt=%d", dtype, vt_dtype);
-    return TD_ERR_UNSUPPORTED;
-  }
-  TD_CHECK_LAUNCH();
-  return TD_OK;
+  TD_REQUIRE(kvsum_t && ksum, TD_ERR_INVALID, "td_sla_linear_kv: null pointer");
+  int rc = td_sla_linear_kv_partial(k, dtype, vt, vt_dtype, ws_kv, ws_ks, L, H, D, stream);
+  if (rc) return rc;
+  return td_sla_linear_kv_final(ws_kv, ws_ks, LK_NCH, (int64_t)LK_NCH * 128 * 128, 128 * 128,
+                                (int64_t)LK_NCH * 128, 128, kvsum_t, ksum, dtype, H, D, stream);
 }
 
 // ---------------------------------------------------------------------------------------

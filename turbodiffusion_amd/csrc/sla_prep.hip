@@ -108,31 +108,47 @@ __global__ __launch_bounds__(256) void seq_mean_partial_kernel(const uint16_t* _
   }
 }
 template <int DT>
-__global__ __launch_bounds__(128) void seq_mean_final_kernel(const float* __restrict__ ws,
+__global__ __launch_bounds__(128) void seq_mean_final_kernel(const float* __restrict__ ws, int nch,
+                                                             int64_t stride_h, int64_t stride_c,
                                                              uint16_t* __restrict__ km, int64_t L) {
   const int h = blockIdx.x, d = threadIdx.x;
   float s = 0.f;
-  for (int c = 0; c < SM_CHUNKS; ++c) s += ws[((int64_t)h * SM_CHUNKS + c) * 128 + d];
+  for (int c = 0; c < nch; ++c) s += ws[h * stride_h + c * stride_c + d];
   km[h * 128 + d] = (uint16_t)f32_to_half_bits<DT>(s / (float)L);
+}
+
+extern "C" int td_seq_sum_partial(const void* k, float* ws, int dtype, int64_t L, int H, int D,
+                                  td_stream_t stream) {
+  TD_REQUIRE(k && ws, TD_ERR_INVALID, "td_seq_sum_partial: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_seq_sum_partial: D=%d (need 128)", D);
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_seq_sum_partial: dtype %d", dtype);
+  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_seq_sum_partial: L=%lld H=%d", (long long)L, H);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(SM_CHUNKS, H);
+  if (dtype == TD_BF16) seq_mean_partial_kernel<TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, ws, L);
+  else seq_mean_partial_kernel<TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, ws, L);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+extern "C" int td_seq_mean_final(const float* ws, int nch, int64_t stride_h, int64_t stride_c, void* km,
+                                 int dtype, int64_t L_total, int H, int D, td_stream_t stream) {
+  TD_REQUIRE(ws && km, TD_ERR_INVALID, "td_seq_mean_final: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_seq_mean_final: D=%d (need 128)", D);
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_seq_mean_final: dtype %d", dtype);
+  TD_REQUIRE(nch > 0 && L_total > 0 && H > 0, TD_ERR_INVALID, "td_seq_mean_final: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16) seq_mean_final_kernel<TD_BF16><<<H, 128, 0, st>>>(ws, nch, stride_h, stride_c, (uint16_t*)km, L_total);
+  else seq_mean_final_kernel<TD_F16><<<H, 128, 0, st>>>(ws, nch, stride_h, stride_c, (uint16_t*)km, L_total);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
 }
 
 extern "C" int td_seq_mean(const void* k, void* km, float* ws, int dtype, int64_t L, int H, int D,
                            td_stream_t stream) {
-  TD_REQUIRE(k && km && ws, TD_ERR_INVALID, "td_seq_mean: null pointer");
-  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_seq_mean: D=%d (need 128)", D);
-  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_seq_mean: dtype %d", dtype);
-  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_seq_mean: L=%lld H=%d", (long long)L, H);
-  hipStream_t st = (hipStream_t)stream;
-  dim3 grid(SM_CHUNKS, H);
-  if (dtype == TD_BF16) {
-    seq_mean_partial_kernel<TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, ws, L);
-    seq_mean_final_kernel<TD_BF16><<<H, 128, 0, st>>>(ws, (uint16_t*)km, L);
-  } else {
-    seq_mean_partial_kernel<TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, ws, L);
-    seq_mean_final_kernel<TD_F16><<<H, 128, 0, st>>>(ws, (uint16_t*)km, L);
-  }
-  TD_CHECK_LAUNCH();
-  return TD_OK;
+  int rc = td_seq_sum_partial(k, ws, dtype, L, H, D, stream);
+  if (rc) return rc;
+  return td_seq_mean_final(ws, SM_CHUNKS, (int64_t)SM_CHUNKS * 128, 128, km, dtype, L, H, D, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -249,7 +265,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restrict__ pq,
                                                        const uint16_t* __restrict__ pk,
                                                        int32_t* __restrict__ lut, int Qb, int Kb,
-                                                       int topk) {
+                                                       int Kb_alloc, int topk) {
   extern __shared__ __attribute__((aligned(16))) char smem_tk[];
   float* qs = reinterpret_cast<float*>(smem_tk);                           // [16][128] fp32
   uint16_t* sc = reinterpret_cast<uint16_t*>(smem_tk + TK_ROWS * 128 * 4);  // [16][Kb] sortable keys
@@ -265,7 +281,7 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
     float acc[TK_ROWS];
 #pragma unroll
     for (int r = 0; r < TK_ROWS; ++r) acc[r] = 0.f;
-    const uint16_t* kr = pk + ((int64_t)h * Kb + j) * 128;
+    const uint16_t* kr = pk + ((int64_t)h * Kb_alloc + j) * 128;
 #pragma unroll 4
     for (int d8 = 0; d8 < 16; ++d8) {
       float kf[8];
@@ -323,7 +339,9 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
 }
 
 extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb,
-                           int Kb, int D, int topk, td_stream_t stream) {
+                           int Kb, int Kb_alloc, int D, int topk, td_stream_t stream) {
+  if (Kb_alloc == 0) Kb_alloc = Kb;
+  TD_REQUIRE(Kb_alloc >= Kb, TD_ERR_INVALID, "td_sla_topk: Kb_alloc=%d < Kb=%d", Kb_alloc, Kb);
   TD_REQUIRE(pq && pk && lut, TD_ERR_INVALID, "td_sla_topk: null pointer");
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_topk: D=%d (need 128)", D);
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_sla_topk: dtype %d", dtype);
@@ -337,12 +355,12 @@ extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* l
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<TD_BF16>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2); a = true; }
-    sla_topk_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, topk);
+    sla_topk_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk);
   } else {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<TD_F16>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2); a = true; }
-    sla_topk_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, topk);
+    sla_topk_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk);
   }
   TD_CHECK_LAUNCH();
   return TD_OK;

@@ -20,6 +20,43 @@ def cdiv(a: int, b: int) -> int:
     return (a + b - 1) // b
 
 
+class KernelTimer:
+    """Times selected entry points with HIP events recorded on the stream the kernel is launched on
+    (torch's current stream).  Used by bench.py for the roofline numbers; off by default."""
+
+    def __init__(self, names):
+        self.names = set(names)
+        self.records = {}  # name -> list of (start_event, end_event, meta)
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / max(1, len(ms)), "total_ms": sum(ms),
+                         "metas": [m for _, _, m in recs]}
+        return out
+
+
+_timer = None
+
+
+def set_timer(t):
+    global _timer
+    _timer = t
+
+
+def _timed(name, meta, fn):
+    if _timer is None or name not in _timer.names:
+        return fn()
+    st = torch.cuda.current_stream()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(st)
+    r = fn()
+    b.record(st)
+    _timer.records.setdefault(name, []).append((a, b, meta))
+    return r
+
+
 # ----------------------------------------------------------------------------- a16
 def quant_i8_block128(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """x [m,n] f16|bf16 -> (q int8 [m,n], s f32 [ceil(m/128), ceil(n/128)])."""
@@ -47,8 +84,9 @@ def gemm_w8a8(a_q, a_s, b_q, b_s, out_dtype=torch.bfloat16, bias=None, gelu_tanh
         assert out.shape == (m, n) and out.stride(1) == 1 and out.dtype == out_dtype
     if bias is not None:
         assert bias.dtype == out_dtype and bias.shape == (n,) and bias.is_contiguous()
-    call("td_gemm_w8a8", ptr(a_q), ptr(a_s), ptr(b_q), ptr(b_s), ptr(bias), ptr(out), dt_code(out_dtype),
-         L.TD_EPI_GELU_TANH if gelu_tanh else L.TD_EPI_NONE, m, n, k, out.stride(0), stream_ptr())
+    _timed("td_gemm_w8a8", (m, n, k), lambda: call(
+        "td_gemm_w8a8", ptr(a_q), ptr(a_s), ptr(b_q), ptr(b_s), ptr(bias), ptr(out), dt_code(out_dtype),
+        L.TD_EPI_GELU_TANH if gelu_tanh else L.TD_EPI_NONE, m, n, k, out.stride(0), stream_ptr()))
     return out
 
 
@@ -153,43 +191,48 @@ def sage_quant_pool(x, km, blk, want_pool=True, want_quant=True):
     return pooled, xq, xs
 
 
-def sla_topk(pq, pk, topk):
-    """pq [H, Qb, D], pk [H, Kb, D] -> lut int32 [H, Qb, topk] (ascending block ids)."""
+def sla_topk(pq, pk, topk, kb=None):
+    """pq [H, Qb, D], pk [H, Kb_alloc, D] (first ``kb`` blocks valid) -> lut int32 [H, Qb, topk]
+    (ascending block ids)."""
     require_gpu(pq, pk)
     H, Qb, D = pq.shape
-    Kb = pk.shape[1]
+    kb_alloc = pk.shape[1]
+    kb = kb_alloc if kb is None else kb
     lut = torch.empty((H, Qb, topk), dtype=torch.int32, device=pq.device)
-    call("td_sla_topk", ptr(pq), ptr(pk), dt_code(pq.dtype), ptr(lut), H, Qb, Kb, D, topk, stream_ptr())
+    call("td_sla_topk", ptr(pq), ptr(pk), dt_code(pq.dtype), ptr(lut), H, Qb, kb, kb_alloc, D, topk, stream_ptr())
     return lut
 
 
 # ----------------------------------------------------------------------------- a9 / a12 / a13
-def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None):
+def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
     """SageAttention INT8-QK/FP16-PV. q_i8 [H,L,128], k_i8 [H,Lk,128], vt f16 tiles; lut or None (dense).
     out: preallocated 16-bit tensor addressed as out_ptr + h*o_stride_h + l*o_stride_l + d."""
     require_gpu(q_i8, k_i8, vt, lut, out)
     H, L_, D = q_i8.shape
-    Lk = k_i8.shape[1]
-    assert D == 128 and vt.dtype == torch.float16
+    lk_alloc = k_i8.shape[1]
+    Lk = lk_alloc if lk is None else lk  # lk < allocation: rank-padded gathered layout
+    assert D == 128 and vt.dtype == torch.float16 and vt.shape[1] * 64 >= lk_alloc
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]
-    call("td_attn_i8", ptr(q_i8), ptr(q_s), ptr(k_i8), ptr(k_s), ptr(vt), ptr(lut), nsel, ptr(out),
-         dt_code(out.dtype), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, H, stream_ptr())
+    _timed("td_attn_i8", (H, L_, Lk, nsel), lambda: call(
+        "td_attn_i8", ptr(q_i8), ptr(q_s), ptr(k_i8), ptr(k_s), ptr(vt), ptr(lut), nsel, ptr(out),
+        dt_code(out.dtype), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc, H, stream_ptr()))
     return out
 
 
-def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None):
+def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
     """16-bit QK attention (q,k [H,L,128] bf16|f16, vt tiles same dtype)."""
     require_gpu(q, k, vt, lut, out)
     H, L_, D = q.shape
-    Lk = k.shape[1]
+    lk_alloc = k.shape[1]
+    Lk = lk_alloc if lk is None else lk
     assert D == 128 and vt.dtype == q.dtype and out.dtype == q.dtype
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]
     call("td_attn_16", ptr(q), ptr(k), ptr(vt), ptr(lut), nsel, ptr(out), dt_code(q.dtype), o_stride_h,
-         o_stride_l, float(sm_scale), L_, Lk, H, stream_ptr())
+         o_stride_l, float(sm_scale), L_, Lk, lk_alloc, H, stream_ptr())
     return out
 
 
@@ -203,6 +246,45 @@ def sla_linear_kv(k, vt):
     ksum = torch.empty((H, D), dtype=k.dtype, device=k.device)
     call("td_sla_linear_kv", ptr(k), dt_code(k.dtype), ptr(vt), dt_code(vt.dtype), ptr(ws_kv), ptr(ws_ks),
          ptr(kv_t), ptr(ksum), L_, H, D, stream_ptr())
+    return kv_t, ksum
+
+
+def seq_sum_partial(k, out=None):
+    """k [H, L, D] -> f32 partial sums [H, 64, D] of this rank's tokens."""
+    require_gpu(k)
+    H, L_, D = k.shape
+    ws = out if out is not None else torch.empty((H, 64, D), dtype=torch.float32, device=k.device)
+    call("td_seq_sum_partial", ptr(k), ptr(ws), dt_code(k.dtype), L_, H, D, stream_ptr())
+    return ws
+
+
+def seq_mean_final(ws, nch, stride_h, stride_c, L_total, H, D, dtype):
+    km = torch.empty((H, D), dtype=dtype, device=ws.device)
+    call("td_seq_mean_final", ptr(ws), nch, stride_h, stride_c, ptr(km), dt_code(dtype), L_total, H, D, stream_ptr())
+    return km
+
+
+def sla_linear_kv_partial_f32(k, vt, kv_out=None, ks_out=None):
+    """This rank's un-rounded contribution: (kv f32 [H, D, D] (d1,d2), ks f32 [H, D])."""
+    require_gpu(k, vt)
+    H, L_, D = k.shape
+    ws_kv = torch.empty((H, 16, D, D), dtype=torch.float32, device=k.device)
+    ws_ks = torch.empty((H, 16, D), dtype=torch.float32, device=k.device)
+    call("td_sla_linear_kv_partial", ptr(k), dt_code(k.dtype), ptr(vt), dt_code(vt.dtype), ptr(ws_kv), ptr(ws_ks),
+         L_, H, D, stream_ptr())
+    kv = kv_out if kv_out is not None else torch.empty((H, D, D), dtype=torch.float32, device=k.device)
+    ks = ks_out if ks_out is not None else torch.empty((H, D), dtype=torch.float32, device=k.device)
+    call("td_sla_linear_kv_final", ptr(ws_kv), ptr(ws_ks), 16, 16 * D * D, D * D, 16 * D, D, ptr(kv), ptr(ks),
+         L.TD_F32, H, D, stream_ptr())
+    return kv, ks
+
+
+def sla_linear_kv_final(kv_parts, ks_parts, nch, kv_sh, kv_sc, ks_sh, ks_sc, H, D, dtype):
+    """Sum ``nch`` fp32 partials (strided) and round: -> (kvsum_t [H, D, D] dtype, ksum [H, D] dtype)."""
+    kv_t = torch.empty((H, D, D), dtype=dtype, device=kv_parts.device)
+    ksum = torch.empty((H, D), dtype=dtype, device=kv_parts.device)
+    call("td_sla_linear_kv_final", ptr(kv_parts), ptr(ks_parts), nch, kv_sh, kv_sc, ks_sh, ks_sc, ptr(kv_t),
+         ptr(ksum), dt_code(dtype), H, D, stream_ptr())
     return kv_t, ksum
 
 

@@ -1,0 +1,49 @@
+"""The few-step rCM sampler loop of the reference (``inference/wan2.1_t2v_infer.py:111-140``;
+I2V variant with the high/low-noise expert switch ``wan2.2_i2v_infer.py:173-213``), state in fp64 on
+the GPU, the DiT step = ``turbodiffusion_amd.wan.WanModel.forward``."""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional
+
+import torch
+
+
+def rcm_timesteps(num_steps: int = 4, sigma_max: float = 80.0, device="cuda") -> torch.Tensor:
+    """TrigFlow times [atan(sigma_max), 1.5, 1.4, 1.0, 0] -> rectified-flow t = sin/(cos+sin)  (:111-122)."""
+    mid_t = [1.5, 1.4, 1.0][: num_steps - 1]
+    t = torch.tensor([math.atan(sigma_max), *mid_t, 0], dtype=torch.float64, device=device)
+    return torch.sin(t) / (torch.cos(t) + torch.sin(t))
+
+
+@torch.no_grad()
+def rcm_sample(net: Callable, init_noise: torch.Tensor, crossattn_emb: torch.Tensor, num_steps: int = 4,
+               sigma_max: float = 80.0, generator: Optional[torch.Generator] = None,
+               noises: Optional[List[torch.Tensor]] = None, y: Optional[torch.Tensor] = None,
+               net_low: Optional[Callable] = None, boundary: float = 0.9, ode: bool = False,
+               dtype=torch.bfloat16, step_hook: Optional[Callable] = None) -> torch.Tensor:
+    """x <- (1-t_next)(x - t_cur v) + t_next * N(0,1)   (SDE, :134-139) or x - (t_cur-t_next) v (ODE).
+
+    ``noises`` (list of per-step N(0,1) tensors) overrides the generator — used by the parity tests so
+    CPU oracle and GPU runs see identical noise.  ``net_low``/``boundary``: Wan2.2 expert switch
+    (use ``net`` while t_cur >= boundary, ``net_low`` after: wan2.2_i2v_infer.py:191-197)."""
+    dev = init_noise.device
+    t_steps = rcm_timesteps(num_steps, sigma_max, dev)
+    x = init_noise.to(torch.float64) * t_steps[0]
+    ones = torch.ones(x.size(0), 1, device=dev, dtype=x.dtype)
+    for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
+        model = net if (net_low is None or t_cur.item() >= boundary) else net_low
+        kw = {} if y is None else {"y_B_C_T_H_W": y.to(dtype)}
+        v = model(x_B_C_T_H_W=x.to(dtype), timesteps_B_T=(t_cur.float() * ones * 1000).to(dtype),
+                  crossattn_emb=crossattn_emb, **kw).to(torch.float64)
+        if ode:
+            x = x - (t_cur - t_next) * v
+        else:
+            if noises is not None:
+                eps = noises[i].to(dev)
+            else:
+                eps = torch.randn(*x.shape, dtype=torch.float32, device=dev, generator=generator)
+            x = (1 - t_next) * (x - t_cur * v) + t_next * eps
+        if step_hook is not None:
+            step_hook(i, x)
+    return x.float()

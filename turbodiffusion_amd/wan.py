@@ -1,0 +1,353 @@
+"""MI355X-native Wan DiT forward — the reference's ``WanModel.forward`` surface
+(``rcm/networks/wan2pt1.py:598-721``; ``wan2pt2.py`` = same + ``y`` concatenated on channels and a
+plain text cross-attention) re-built as a fused HIP kernel pipeline.
+
+Drop-in properties kept:
+  * constructor arguments and ``forward(x_B_C_T_H_W, timesteps_B_T, crossattn_emb,
+    frame_cond_crossattn_emb_B_L_D=None, y_B_C_T_H_W=None, **kw)`` -> ``[B, C_out, T, H, W]`` velocity,
+    so the reference sampler loop (``inference/wan2.1_t2v_infer.py:129-139``) can call it unchanged;
+  * module tree / state-dict keys identical to the reference model *after* ``modify_model.replace_*``
+    (``blocks.N.self_attn.q.int8_weight|scale|bias``, ``...norm_q.weight``,
+    ``...self_attn.attn_op.local_attn.proj_l.*``, ``blocks.N.modulation``, ``head.head.*`` ...), so
+    published ``*-quant.pth`` checkpoints load with ``load_state_dict``.
+
+What is different underneath (one pass per arrow, all hand-written HIP unless marked torch):
+  x --LayerNorm+AdaLN-modulate--> h --quant--> int8 --W8A8 GEMM (q|k|v fused, bias in epilogue)-->
+  qkv --RMSNorm(dim)+RoPE+head-major--> q,k ; v --transposed MFMA tiles--> vt ;
+  smooth-K mean, block pool + INT8 quant, top-k LUT, block-sparse Sage attention, linear branch (+=),
+  --quant + W8A8 GEMM(o)--> gated residual ; norm3 -> cross-attention (dense, 512 keys) -> residual ;
+  LayerNorm+modulate -> W8A8 GEMM (+bias+GELU-tanh epilogue) -> W8A8 GEMM -> gated residual.
+Embeddings and the head (outside ``blocks``; not quantised by the reference either,
+``modify_model.py:63``) are plain library GEMMs through torch.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import kernels as K
+from .ops import FastLayerNorm, FastRMSNorm, Int8Linear
+from .sla import SageSparseLinearAttention, SparseLinearAttention, sparse_linear_attention_hld
+
+ATTENTION_TYPES = ("original", "sage", "sla", "sagesla")
+
+
+class AttnOp(nn.Module):
+    """Stands in for ``MinimalA2AAttnOp`` (rcm/utils/a2a_cp.py:189-200): only its ``local_attn``
+    attribute is part of the contract (``modify_model.py:50-52``)."""
+
+    def __init__(self, local_attn: Optional[nn.Module] = None):
+        super().__init__()
+        if local_attn is not None:
+            self.local_attn = local_attn
+
+
+def _linear(in_f, out_f, quant, dtype):
+    if quant:
+        return Int8Linear(in_f, out_f, bias=True, dtype=dtype)
+    return nn.Linear(in_f, out_f, dtype=dtype)
+
+
+class WanSelfAttention(nn.Module):
+    def __init__(self, dim, num_heads, eps, quant, dtype, attention_type=None, sla_topk=0.1):
+        super().__init__()
+        self.dim, self.num_heads, self.head_dim, self.eps = dim, num_heads, dim // num_heads, eps
+        self.q = _linear(dim, dim, quant, dtype)
+        self.k = _linear(dim, dim, quant, dtype)
+        self.v = _linear(dim, dim, quant, dtype)
+        self.o = _linear(dim, dim, quant, dtype)
+        self.norm_q = FastRMSNorm(dim, eps=eps)
+        self.norm_k = FastRMSNorm(dim, eps=eps)
+        local = None
+        if attention_type == "sla":
+            local = SparseLinearAttention(self.head_dim, sla_topk, BLKQ=128, BLKK=64)
+        elif attention_type == "sagesla":
+            local = SageSparseLinearAttention(self.head_dim, sla_topk)
+        self.attn_op = AttnOp(local)
+
+
+class WanAttentionBlock(nn.Module):
+    def __init__(self, dim, ffn_dim, num_heads, cross_attn_norm, eps, quant, dtype, attention_type, sla_topk):
+        super().__init__()
+        self.norm1 = FastLayerNorm(dim, eps)
+        self.self_attn = WanSelfAttention(dim, num_heads, eps, quant, dtype, attention_type, sla_topk)
+        self.norm3 = FastLayerNorm(dim, eps, elementwise_affine=True) if cross_attn_norm else nn.Identity()
+        self.cross_attn = WanSelfAttention(dim, num_heads, eps, quant, dtype)
+        self.norm2 = FastLayerNorm(dim, eps)
+        self.ffn = nn.Sequential(_linear(dim, ffn_dim, quant, dtype), nn.GELU(approximate="tanh"),
+                                 _linear(ffn_dim, dim, quant, dtype))
+        self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+
+
+class Head(nn.Module):
+    def __init__(self, dim, out_dim, patch_size, eps, dtype):
+        super().__init__()
+        self.norm = FastLayerNorm(dim, eps)
+        self.head = nn.Linear(dim, math.prod(patch_size) * out_dim, dtype=dtype)
+        self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
+
+
+def sinusoidal_embedding_1d(dim, position):
+    """wan2pt1.py:144-153 (fp64)."""
+    half = dim // 2
+    position = position.type(torch.float64)
+    sinusoid = torch.outer(position, torch.pow(10000, -torch.arange(half).to(position).div(half)))
+    return torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1)
+
+
+def rope_angles(T, H, W, head_dim, device, theta=10000.0):
+    """VideoRopePosition3DEmb.generate_embeddings (wan2pt1.py:86-137), default ntk factors."""
+    dim_h = head_dim // 6 * 2
+    dim_t = head_dim - 2 * dim_h
+    seq = torch.arange(max(T, H, W), device=device).float()
+    sp = torch.arange(0, dim_h, 2, device=device)[: dim_h // 2].float() / dim_h
+    tp = torch.arange(0, dim_t, 2, device=device)[: dim_t // 2].float() / dim_t
+    fh = torch.outer(seq[:H], 1.0 / (theta ** sp))
+    fw = torch.outer(seq[:W], 1.0 / (theta ** sp))
+    ft = torch.outer(seq[:T], 1.0 / (theta ** tp))
+    f = torch.cat([ft[:, None, None, :].expand(T, H, W, -1), fh[None, :, None, :].expand(T, H, W, -1),
+                   fw[None, None, :, :].expand(T, H, W, -1)], dim=-1)
+    return f.reshape(T * H * W, -1).float().contiguous()
+
+
+class WanModel(nn.Module):
+    """Wan2.1 T2V (1.3B / 14B) and Wan2.2 A14B I2V (``y`` concatenated on channels) denoiser."""
+
+    def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, qk_norm=True,
+                 cross_attn_norm=True, eps=1e-6, attention_type="sagesla", sla_topk=0.1, quant_linear=True,
+                 dtype=torch.bfloat16, **_unused):
+        super().__init__()
+        assert model_type in ("t2v", "i2v") and qk_norm
+        assert attention_type in ATTENTION_TYPES
+        assert (dim // num_heads) == 128, "the MI355X attention kernels are built for head_dim 128"
+        self.model_type, self.patch_size, self.text_len = model_type, patch_size, text_len
+        self.in_dim, self.dim, self.ffn_dim, self.freq_dim = in_dim, dim, ffn_dim, freq_dim
+        self.text_dim, self.out_dim, self.num_heads, self.num_layers = text_dim, out_dim, num_heads, num_layers
+        self.eps, self.attention_type, self.sla_topk, self.quant_linear = eps, attention_type, sla_topk, quant_linear
+        self.dtype = dtype
+        self.patch_embedding = nn.Linear(in_dim * math.prod(patch_size), dim, dtype=dtype)
+        self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim, dtype=dtype), nn.GELU(approximate="tanh"),
+                                            nn.Linear(dim, dim, dtype=dtype))
+        self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim, dtype=dtype), nn.SiLU(),
+                                            nn.Linear(dim, dim, dtype=dtype))
+        self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6, dtype=dtype))
+        self.blocks = nn.ModuleList([
+            WanAttentionBlock(dim, ffn_dim, num_heads, cross_attn_norm, eps, quant_linear, dtype, attention_type,
+                              sla_topk) for _ in range(num_layers)])
+        self.head = Head(dim, out_dim, patch_size, eps, dtype)
+        self._fused = {}
+        self._rope_cache = {}
+        self.seq_parallel = None  # set by turbodiffusion_amd.seqpar.enable(...)
+
+    # ------------------------------------------------------------------ weights
+    @torch.no_grad()
+    def load_from_float_state_dict(self, sd: dict):
+        """Take an UNQUANTISED reference state dict (keys of rcm.networks.wan2pt1.WanModel) and do what
+        ``modify_model.py:156-183`` does offline: per-128x128-block INT8 quantisation of every Linear
+        inside ``blocks`` except ``proj_l`` — with the HIP quantiser."""
+        dev = next(self.parameters()).device
+        own = self.state_dict()
+        new = {}
+        for k, v in sd.items():
+            if k in own:
+                new[k] = v
+                continue
+            if k.endswith(".weight") and k[:-7] + ".int8_weight" in own:
+                w = v.to(dev)
+                if w.dtype == torch.float32:
+                    w = w.to(self.dtype)
+                q, s = K.quant_i8_block128(w.contiguous())
+                new[k[:-7] + ".int8_weight"] = q
+                new[k[:-7] + ".scale"] = s
+                continue
+            raise KeyError(f"unexpected key {k}")
+        missing = [k for k in own if k not in new]
+        if missing:
+            raise KeyError(f"missing keys {missing[:5]} ...")
+        self.load_state_dict(new, assign=False)
+        self._fused.clear()
+
+    def _lin(self, mod, x, gelu=False):
+        """One Linear of a block on a [M, K] activation: W8A8 (HIP) or the plain bf16 library GEMM."""
+        if isinstance(mod, Int8Linear):
+            xq, xs = K.quant_i8_block128(x)
+            return K.gemm_w8a8(xq, xs, mod.int8_weight, mod.scale, x.dtype, bias=mod.bias, gelu_tanh=gelu)
+        y = F.linear(x, mod.weight, mod.bias)
+        return F.gelu(y, approximate="tanh") if gelu else y
+
+    def _fused_weights(self, i, blk):
+        """q|k|v of self-attention and k|v of cross-attention share their input: concatenate the
+        weights (and block scales — 128-row aligned, so the concatenation keeps the block structure)
+        once, so each input is quantised once and multiplied once."""
+        f = self._fused.get(i)
+        if f is not None:
+            return f
+        sa, ca = blk.self_attn, blk.cross_attn
+        f = {}
+        if isinstance(sa.q, Int8Linear):
+            assert self.dim % 128 == 0
+            f["qkv_w"] = torch.cat([sa.q.int8_weight, sa.k.int8_weight, sa.v.int8_weight], 0).contiguous()
+            f["qkv_s"] = torch.cat([sa.q.scale, sa.k.scale, sa.v.scale], 0).contiguous()
+            f["qkv_b"] = torch.cat([sa.q.bias, sa.k.bias, sa.v.bias], 0).contiguous()
+            f["ckv_w"] = torch.cat([ca.k.int8_weight, ca.v.int8_weight], 0).contiguous()
+            f["ckv_s"] = torch.cat([ca.k.scale, ca.v.scale], 0).contiguous()
+            f["ckv_b"] = torch.cat([ca.k.bias, ca.v.bias], 0).contiguous()
+        else:
+            f["qkv_w"] = torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).contiguous()
+            f["qkv_b"] = torch.cat([sa.q.bias, sa.k.bias, sa.v.bias], 0).contiguous()
+            f["ckv_w"] = torch.cat([ca.k.weight, ca.v.weight], 0).contiguous()
+            f["ckv_b"] = torch.cat([ca.k.bias, ca.v.bias], 0).contiguous()
+        la = getattr(sa.attn_op, "local_attn", None)
+        if la is not None:
+            f["proj_w"] = la.proj_l.weight.detach().float().contiguous()
+            f["proj_b"] = la.proj_l.bias.detach().float().contiguous()
+        self._fused[i] = f
+        return f
+
+    def _fused_lin(self, x, w, s, b):
+        if s is not None:
+            xq, xs = K.quant_i8_block128(x)
+            return K.gemm_w8a8(xq, xs, w, s, x.dtype, bias=b)
+        return F.linear(x, w, b)
+
+    # ------------------------------------------------------------------ one transformer block
+    def _self_attention(self, i, blk, h, cos, sin, L_loc):
+        """h: [L_loc, dim] modulated input of this rank's tokens -> [L_loc, dim] attention output."""
+        f = self._fused_weights(i, blk)
+        sa = blk.self_attn
+        H, D, dim = self.num_heads, 128, self.dim
+        qkv = self._fused_lin(h, f["qkv_w"], f.get("qkv_s"), f["qkv_b"])  # [L, 3*dim]
+        q = K.qk_norm_rope(qkv, 0, H, D, sa.norm_q.weight, cos, sin, self.eps)
+        k = K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
+        out = torch.empty((L_loc, dim), dtype=h.dtype, device=h.device)
+        if self.seq_parallel is not None:
+            return self.seq_parallel.self_attention(self, f, q, k, qkv, out)
+        at = self.attention_type
+        sage = at in ("sage", "sagesla")
+        dense = at in ("original", "sage")
+        sparse_linear_attention_hld(q, k, qkv[:, 2 * dim:], f.get("proj_w") if not dense else None,
+                                    f.get("proj_b") if not dense else None, self.sla_topk, sage, out, D, dim,
+                                    (D, 3 * dim), dense=dense)
+        return out
+
+    def _cross_attention(self, i, blk, xn, context):
+        """xn [L, dim] (norm3 output), context [Lc, dim] -> [L, dim] (before the o projection)."""
+        f = self._fused_weights(i, blk)
+        ca = blk.cross_attn
+        H, D, dim = self.num_heads, 128, self.dim
+        L_ = xn.shape[0]
+        Lc = context.shape[0]
+        qc = self._lin(ca.q, xn)
+        q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
+        kv = self._fused_lin(context, f["ckv_w"], f.get("ckv_s"), f["ckv_b"])  # [Lc, 2*dim]
+        k = K.qk_norm_rope(kv, 0, H, D, ca.norm_k.weight, None, None, self.eps)
+        vt = K.v_transpose(kv[:, dim:], D, 2 * dim, Lc, H, D, xn.dtype)
+        out = torch.empty((L_, dim), dtype=xn.dtype, device=xn.device)
+        K.attn_16(q, k, vt, None, out, D, dim)
+        return out
+
+    def _block(self, i, blk, x, e0_B_6_D, cos, sin, context):
+        """x: [B, L_loc, dim] (updated in place); e0 fp32 [B, 6, dim]; context [B, Lc, dim]."""
+        B, L_loc, dim = x.shape
+        e = (blk.modulation.float() + e0_B_6_D)  # fp32 [B, 6, dim]  (wan2pt1.py:400)
+        ec = [e[:, j].contiguous() for j in range(6)]
+        x2 = x.view(B * L_loc, dim)
+        # ---- self attention ----
+        h = K.layernorm(x2, None, None, self.eps, scale=ec[1], shift=ec[0], rows_per_batch=L_loc)
+        ys = [self._self_attention(i, blk, h[b * L_loc:(b + 1) * L_loc], cos, sin, L_loc) for b in range(B)]
+        y = ys[0] if B == 1 else torch.cat(ys, 0)
+        o = self._lin(blk.self_attn.o, y)
+        K.gated_residual_(x2, o, ec[2])
+        # ---- cross attention ----
+        if isinstance(blk.norm3, FastLayerNorm):
+            xn = K.layernorm(x2, blk.norm3.weight, blk.norm3.bias, self.eps)
+        else:
+            xn = x2
+        cs = [self._cross_attention(i, blk, xn[b * L_loc:(b + 1) * L_loc], context[b]) for b in range(B)]
+        c = cs[0] if B == 1 else torch.cat(cs, 0)
+        K.gated_residual_(x2, self._lin(blk.cross_attn.o, c), None)
+        # ---- FFN ----
+        h2 = K.layernorm(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
+        f1 = self._lin(blk.ffn[0], h2, gelu=True)
+        f2 = self._lin(blk.ffn[2], f1)
+        K.gated_residual_(x2, f2, ec[5])
+        return x
+
+    # ------------------------------------------------------------------ forward
+    def _rope(self, T, H, W, device):
+        key = (T, H, W, str(device))
+        if key not in self._rope_cache:
+            ang = rope_angles(T, H, W, 128, device)
+            self._rope_cache[key] = (torch.cos(ang).float().contiguous(), torch.sin(ang).float().contiguous())
+        return self._rope_cache[key]
+
+    @torch.no_grad()
+    def forward(self, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, frame_cond_crossattn_emb_B_L_D=None,
+                y_B_C_T_H_W=None, **kwargs):
+        del kwargs
+        K.require_gpu(x_B_C_T_H_W)
+        if frame_cond_crossattn_emb_B_L_D is not None:
+            raise NotImplementedError("CLIP image-context branch (Wan2.1 I2V) is outside the hot path; "
+                                      "Wan2.2-A14B I2V conditions through y_B_C_T_H_W only")
+        assert timesteps_B_T.shape[1] == 1
+        t_B = timesteps_B_T[:, 0]
+        if y_B_C_T_H_W is not None:
+            x_B_C_T_H_W = torch.cat([x_B_C_T_H_W, y_B_C_T_H_W], dim=1)
+        kt, kh, kw = self.patch_size
+        B, C, T_in, H_in, W_in = x_B_C_T_H_W.shape
+        assert T_in % kt == 0 and H_in % kh == 0 and W_in % kw == 0
+        T, H, W = T_in // kt, H_in // kh, W_in // kw
+        L_ = T * H * W
+        dt = self.dtype
+        # patchify "b c (t kt) (h kh) (w kw) -> b (t h w) (c kt kh kw)"   (wan2pt1.py:653-660)
+        x = x_B_C_T_H_W.to(dt).view(B, C, T, kt, H, kh, W, kw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+        x = x.reshape(B, L_, C * kt * kh * kw)
+        cos, sin = self._rope(T, H, W, x.device)
+        sp = self.seq_parallel
+        if sp is not None:
+            x, cos, sin = sp.shard_tokens(x, cos, sin)
+        x = self.patch_embedding(x).contiguous()  # [B, L_loc, dim]
+        # time embeddings in fp32 (the reference's autocast(float32) island, wan2pt1.py:671-674)
+        te, tp = self.time_embedding, self.time_projection
+        e = sinusoidal_embedding_1d(self.freq_dim, t_B).float()
+        e = F.linear(e, te[0].weight.float(), te[0].bias.float())
+        e_B_D = F.linear(F.silu(e), te[2].weight.float(), te[2].bias.float())
+        e0 = F.linear(F.silu(e_B_D), tp[1].weight.float(), tp[1].bias.float()).unflatten(1, (6, self.dim))
+        context = self.text_embedding(crossattn_emb.to(dt)).contiguous()  # [B, Lc, dim]
+        for i, blk in enumerate(self.blocks):
+            x = self._block(i, blk, x, e0, cos, sin, context)
+        # head (wan2pt1.py:444-454): fp32 modulate of the (bf16) norm, fp32 Linear
+        em = (self.head.modulation.float() + e_B_D.unsqueeze(1))  # [B, 2, dim]
+        L_loc = x.shape[1]
+        hn = K.layernorm(x.view(B * L_loc, self.dim), None, None, self.eps, scale=em[:, 1].contiguous(),
+                         shift=em[:, 0].contiguous(), rows_per_batch=L_loc, out_dtype=torch.float32)
+        out = F.linear(hn, self.head.head.weight.float(), self.head.head.bias.float()).view(B, L_loc, -1)
+        if sp is not None:
+            out = sp.gather_tokens(out, L_)
+        # unpatchify "b (t h w) (kt kh kw d) -> b d (t kt) (h kh) (w kw)"   (wan2pt1.py:710-721)
+        out = out.view(B, T, H, W, kt, kh, kw, self.out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
+        return out.reshape(B, self.out_dim, T * kt, H * kh, W * kw)
+
+
+MODEL_CONFIGS = {  # inference/modify_model.py:86-127
+    "Wan2.1-1.3B": dict(dim=1536, eps=1e-6, ffn_dim=8960, freq_dim=256, in_dim=16, model_type="t2v",
+                        num_heads=12, num_layers=30, out_dim=16, text_len=512),
+    "Wan2.1-14B": dict(dim=5120, eps=1e-6, ffn_dim=13824, freq_dim=256, in_dim=16, model_type="t2v",
+                       num_heads=40, num_layers=40, out_dim=16, text_len=512),
+    "Wan2.2-A14B": dict(dim=5120, eps=1e-6, ffn_dim=13824, freq_dim=256, in_dim=36, model_type="i2v",
+                        num_heads=40, num_layers=40, out_dim=16, text_len=512),
+}
+
+
+def select_model(model_name: str, **overrides) -> WanModel:
+    """inference/modify_model.py:86-127."""
+    if model_name not in MODEL_CONFIGS:
+        raise ValueError(f"Unknown model name: {model_name}")
+    cfg = dict(MODEL_CONFIGS[model_name])
+    cfg.update(overrides)
+    return WanModel(**cfg)
