@@ -11,15 +11,15 @@
  *   quant_cuda      ops/quant/quant.cu:28-75      -> td_quant_i8_block128
  *   gemm_cuda       ops/gemm/gemm.cu:27-72        -> td_gemm_w8a8
  *   rms_norm_cuda   ops/norm/rmsnorm.cu:12-59     -> td_rmsnorm
- *   layer_norm_cuda ops/norm/layernorm.cu:10-62   -> td_layernorm (+ fused modulate)
+ *   layer_norm_cuda ops/norm/layernorm.cu:10-62   -> td_layernorm [+ fused modulate]
  *   Triton norms    ops/core.py:96-136,193-335    -> td_rmsnorm / td_layernorm
- *   AdaLN glue      rcm/networks/wan2pt1.py:404-413 -> td_layernorm (modulate), td_gated_residual
+ *   AdaLN glue      rcm/networks/wan2pt1.py:404-413 -> td_layernorm [modulate], td_gated_residual
  *   rope_apply      rcm/networks/wan2pt1.py:156-178 -> td_qk_norm_rope
- *   SLA/utils.py get_block_map :55-67, mean_pool :43-52 -> td_sla_pool, td_sla_topk
- *   spas_sage_attn.utils.get_vanilla_qk_quant (SLA/core.py:201-203) -> td_sage_quant
+ *   SLA/utils.py get_block_map :55-67, mean_pool :43-52 -> td_seq_mean, td_sage_quant_pool, td_sla_topk
+ *   spas_sage_attn.utils.get_vanilla_qk_quant (SLA/core.py:201-203) -> td_sage_quant_pool
  *   spas_sage_attn._qattn.qk_int8_sv_f16_*_block_sparse_attn (SLA/core.py:214)
- *                                              -> td_attn_i8 (sparse via LUT / dense)
- *   Triton _attn_fwd SLA/kernel.py:21-82       -> td_attn_bf16 (sparse via LUT / dense)
+ *                                              -> td_attn_i8   [sparse via LUT / dense]
+ *   Triton _attn_fwd SLA/kernel.py:21-82       -> td_attn_16   [sparse via LUT / dense]
  *   SLA linear branch SLA/core.py:243-253      -> td_sla_linear_kv, td_sla_linear_out
  *
  * Tensor conventions: row-major contiguous unless a stride argument says otherwise;

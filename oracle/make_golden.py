@@ -1,0 +1,52 @@
+"""Generate tests/golden/*.pt from the REAL reference (imported on CPU via oracle/ref_harness.py).
+
+    python -m oracle.make_golden
+
+Run in the build container only (needs /root/reference).  The fixtures travel to the GPU box; the
+reference does not.  Contents of wan_tiny.pt:
+  cfg, x, t, ctx                      seeded inputs (BASELINE.md §3 conventions, tiny shapes)
+  sd_seed                             the state dict is re-created with oracle.wan_ref.make_state_dict(cfg, sd_seed)
+  ref_fp32, ref_bf16                  reference WanModel outputs (fp32 model / bf16-checkpoint emulation)
+  ref_sample_bf16                     latents after the 4-step rCM sampler driven by the reference net
+  noises                              the per-step N(0,1) tensors used by that sampler run
+"""
+import os
+import warnings
+
+import torch
+
+from . import ref_harness as rh
+from . import wan_ref as W
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+TINY = dict(dim=256, eps=1e-6, ffn_dim=512, freq_dim=256, in_dim=16, model_type="t2v", num_heads=2, num_layers=2,
+            out_dim=16, text_len=512, text_dim=128)
+
+
+def main():
+    warnings.filterwarnings("ignore")
+    os.makedirs(OUT, exist_ok=True)
+    cfg, seed = TINY, 0
+    sd = W.make_state_dict(cfg, seed)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 16, 5, 16, 24, generator=g)       # L = 5*8*12 = 480 tokens
+    ctx = torch.randn(1, 512, cfg["text_dim"], generator=g)
+    t = torch.tensor([[933.781]])
+    out = {"cfg": cfg, "sd_seed": seed, "x": x, "t": t, "ctx": ctx}
+    with torch.no_grad():
+        net32 = rh.reference_wan_from_sd(cfg, sd, None)
+        out["ref_fp32"] = net32(x, t, ctx)
+        netbf = rh.reference_wan_from_sd(cfg, sd, torch.bfloat16)
+        out["ref_bf16"] = netbf(x.bfloat16(), t.bfloat16(), ctx.bfloat16())
+        noises = [torch.randn(x.shape, generator=g) for _ in range(4)]
+        out["noises"] = noises
+        out["ref_sample_bf16"] = W.rcm_sample(lambda xx, tt: netbf(xx, tt, ctx.bfloat16()), x, noises)
+    torch.save(out, os.path.join(OUT, "wan_tiny.pt"))
+    print("wrote", os.path.join(OUT, "wan_tiny.pt"), {k: (tuple(v.shape) if hasattr(v, "shape") else type(v).__name__)
+                                                       for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -83,11 +83,12 @@ def sla_sparse_attn(q, k, v, lut, blkq=128, blkk=64, qk_scale=None, p_dtype=None
     masked to -inf (:57-58), online softmax in the exp2 domain (:60-72), P cast to
     V's dtype before P@V (:68), O / l at the end (:74).  Returns O in V's dtype."""
     b, h, l, d = q.shape
+    lk = k.shape[2]  # keys may outnumber queries (sequence-parallel shard / cross attention)
     if qk_scale is None:
         qk_scale = d ** -0.5
     p_dtype = p_dtype or v.dtype
     qb_n = _cdiv(l, blkq)
-    out = torch.empty_like(v)
+    out = torch.empty(b, h, l, d, dtype=v.dtype)
     sc = qk_scale * LOG2E
     for bi in range(b):
         for hi in range(h):
@@ -98,7 +99,7 @@ def sla_sparse_attn(q, k, v, lut, blkq=128, blkk=64, qk_scale=None, p_dtype=None
                 l_i = torch.zeros(q1 - q0)
                 o = torch.zeros(q1 - q0, d)
                 for kb in lut[bi, hi, qb].tolist():
-                    k0, k1 = kb * blkk, min(l, (kb + 1) * blkk)
+                    k0, k1 = kb * blkk, min(lk, (kb + 1) * blkk)
                     s = (qt @ k[bi, hi, k0:k1].float().t()) * sc
                     new_m = torch.maximum(m_i, s.max(dim=1).values)
                     p = torch.exp2(s - new_m[:, None])
@@ -155,6 +156,7 @@ def sage_sparse_attn(q_i8, q_s, k_i8, k_s, v, lut, blkq=128, blkk=64, sm_scale=N
 
     lut: [B,H,Qb,topk] ascending block ids (nvalid: optional [B,H,Qb] counts)."""
     b, h, l, d = q_i8.shape
+    lk = k_i8.shape[2]  # keys may outnumber queries (sequence-parallel shard)
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(d)
     qb_n = _cdiv(l, blkq)
@@ -173,7 +175,7 @@ def sage_sparse_attn(q_i8, q_s, k_i8, k_s, v, lut, blkq=128, blkk=64, sm_scale=N
                 if nvalid is not None:
                     sel = sel[: int(nvalid[bi, hi, qb])]
                 for kb in sel:
-                    k0, k1 = kb * blkk, min(l, (kb + 1) * blkk)
+                    k0, k1 = kb * blkk, min(lk, (kb + 1) * blkk)
                     mult = (q_s[bi, hi, qb] * k_s[bi, hi, kb]) * c  # fp32
                     s = (qf[bi, hi, q0:q1] @ kf[bi, hi, k0:k1].t()) * mult
                     new_m = torch.maximum(m_i, s.max(dim=1).values)

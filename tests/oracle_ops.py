@@ -1,0 +1,137 @@
+"""CPU stand-in for ``turbodiffusion_amd.kernels`` built from the oracle — TEST ONLY.
+
+Lets the world_size-2 gloo tests drive ``turbodiffusion_amd.seqpar.SeqParallel`` (sharding, packing,
+all-gathers, rank-padded layouts) on CPU.  Same call signatures and memory layouts as the HIP wrappers.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import sla_ref as S
+
+_PERM = torch.tensor([0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15])
+_POS2KEY = (torch.arange(4)[:, None] * 16 + _PERM[None, :]).reshape(-1)  # position -> key in a 64-block
+
+
+def _strided(t, shape, strides):
+    return torch.as_strided(t, shape, strides, t.storage_offset())
+
+
+def seq_sum_partial(k, out=None):
+    H, L, D = k.shape
+    ws = torch.zeros(H, 64, D)
+    rows = math.ceil(L / 64)
+    for c in range(64):
+        ws[:, c] = k[:, c * rows:(c + 1) * rows].float().sum(1)
+    return ws
+
+
+def seq_mean_final(ws, nch, stride_h, stride_c, L_total, H, D, dtype):
+    v = _strided(ws, (H, nch, D), (stride_h, stride_c, 1))
+    s = torch.zeros(H, D)
+    for c in range(nch):
+        s = s + v[:, c]
+    return (s / float(L_total)).to(dtype)
+
+
+def v_transpose(v, stride_h, stride_l, L, H, D, out_dtype):
+    vv = _strided(v, (H, L, D), (stride_h, stride_l, 1))
+    kb = (L + 63) // 64
+    pad = torch.zeros(H, kb * 64, D, dtype=out_dtype)
+    pad[:, :L] = vv.to(out_dtype)
+    return pad.view(H, kb, 64, D)[:, :, _POS2KEY, :].permute(0, 1, 3, 2).contiguous()
+
+
+def _v_from_tiles(vt, L):
+    H, kb, D, _ = vt.shape
+    inv = torch.empty(64, dtype=torch.long)
+    inv[_POS2KEY] = torch.arange(64)
+    v = vt.permute(0, 1, 3, 2)[:, :, inv, :].reshape(H, kb * 64, D)
+    return v[:, :L]
+
+
+def sage_quant_pool(x, km, blk, want_pool=True, want_quant=True):
+    xb = x[None]
+    kmb = None if km is None else km[None, :, None, :]
+    pooled = xq = xs = None
+    if want_pool:
+        pooled = S.mean_pool(xb if kmb is None else xb - kmb, blk)[0]
+    if want_quant:
+        q, s = S.quant_per_block_int8(xb, blk, kmb)
+        xq, xs = q[0], s[0]
+    return pooled, xq, xs
+
+
+def sla_topk(pq, pk, topk, kb=None):
+    kb = pk.shape[1] if kb is None else kb
+    score = (pq.float() @ pk[:, :kb].float().transpose(-1, -2)).to(pq.dtype)
+    return S.select_topk(score, topk).int()
+
+
+def _write(out, o_stride_h, o_stride_l, val):
+    H, L, D = val.shape
+    _strided(out, (H, L, D), (o_stride_h, o_stride_l, 1)).copy_(val)
+
+
+def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
+    H, L, D = q_i8.shape
+    lk = k_i8.shape[1] if lk is None else lk
+    kb = (lk + 63) // 64
+    v = _v_from_tiles(vt, lk)
+    lutb = S.dense_lut(1, H, L, 128, 64)[..., :kb] if lut is None else lut[None].long()
+    if lut is None:
+        lutb = torch.arange(kb).expand(1, H, (L + 127) // 128, kb)
+    o = S.sage_sparse_attn(q_i8[None], q_s[None], k_i8[None, :, :lk], k_s[None, :, :kb], v[None].float(), lutb,
+                           out_dtype=out.dtype)[0]
+    _write(out, o_stride_h, o_stride_l, o)
+    return out
+
+
+def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
+    H, L, D = q.shape
+    lk = k.shape[1] if lk is None else lk
+    kb = (lk + 63) // 64
+    v = _v_from_tiles(vt, lk)
+    lutb = torch.arange(kb).expand(1, H, (L + 127) // 128, kb) if lut is None else lut[None].long()
+    o = S.sla_sparse_attn(q[None], k[None, :, :lk], v[None], lutb, 128, 64)[0]
+    _write(out, o_stride_h, o_stride_l, o)
+    return out
+
+
+def sla_linear_kv_partial_f32(k, vt, kv_out=None, ks_out=None):
+    H, L, D = k.shape
+    v = _v_from_tiles(vt, L).float()
+    ck = F.softmax(k, dim=-1).to(k.dtype).float()
+    return ck.transpose(-1, -2) @ v, ck.sum(-2)
+
+
+def sla_linear_kv_final(kv_parts, ks_parts, nch, kv_sh, kv_sc, ks_sh, ks_sc, H, D, dtype):
+    kv = _strided(kv_parts, (H, nch, D, D), (kv_sh, kv_sc, D, 1))
+    ks = _strided(ks_parts, (H, nch, D), (ks_sh, ks_sc, 1))
+    kvs, kss = torch.zeros(H, D, D), torch.zeros(H, D)
+    for c in range(nch):
+        kvs, kss = kvs + kv[:, c], kss + ks[:, c]
+    return kvs.to(dtype).transpose(-1, -2).contiguous(), kss.to(dtype)
+
+
+def sla_linear_kv(k, vt):
+    kv, ks = sla_linear_kv_partial_f32(k, vt)
+    return kv.to(k.dtype).transpose(-1, -2).contiguous(), ks.to(k.dtype)
+
+
+def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l):
+    H, L, D = q.shape
+    dt = q.dtype
+    cq = F.softmax(q, dim=-1).contiguous().to(dt)
+    kvsum = kv_t.transpose(-1, -2).contiguous()
+    o_l = (cq @ kvsum) / (1e-5 + (cq * ksum[:, None, :]).sum(dim=-1, keepdim=True))
+    with torch.amp.autocast("cpu", dtype=dt):
+        o_l = F.linear(o_l, wp, bp)
+    view = _strided(out, (H, L, D), (o_stride_h, o_stride_l, 1))
+    view.copy_(view + o_l)
+    return out
+
+
+def seq_mean(k):
+    return S.seq_mean(k[None])[0, :, 0]

@@ -1,0 +1,212 @@
+"""Sequence-parallel DiT step over the GPUs of one node (BASELINE.json north star).
+
+One process per GPU, ``torch.distributed`` backend ``nccl`` (= RCCL over xGMI).  The flattened
+(t h w) token axis is sharded in contiguous, 128-token-aligned ranges (a rank owns whole Q blocks and
+therefore whole 64-key K blocks).  Everything in a transformer block is token-local except
+self-attention, which needs the K side of every rank.  Per self-attention layer:
+
+  1. tiny all-gather of the per-head K column sums (-> the global smooth-K mean, SLA/core.py:197);
+  2. ONE all-gather of a packed per-rank buffer holding the rank's *quantised* K-side state:
+         K int8 [H, per, 128] | V^T fp16 MFMA tiles [H, per/64, 128, 64] | K scales | pooled K blocks |
+         fp32 linear-branch partials (ck^T v [H,128,128], sum ck [H,128])
+     (3 B per token-channel instead of the reference Ulysses path's 4 all-to-alls of bf16 q,k,v,o:
+     rcm/utils/a2a_cp.py:146-182 — and no head-count divisibility constraint: 12 heads shard 8 ways);
+  3. every rank builds the LUT for ITS Q blocks against the global pooled K, runs the block-sparse
+     Sage attention of its Q blocks against the gathered K/V, and finishes the linear branch from the
+     summed partials.
+
+The DiT output is all-gathered once per step (``cat_outputs_cp``, rcm/utils/context_parallel.py:60-91).
+xGMI is a full mesh, so an all-gather is one hop: each rank pushes its shard to the 7 peers in parallel.
+
+The compute backend is injectable (``ops``): production uses the HIP kernels (``kernels``); the
+world_size-2 gloo tests on CPU inject the oracle so the sharding / packing / gather logic is covered
+without a GPU.  There is no silent fallback: ``ops=None`` means HIP.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+class SeqParallel:
+    def __init__(self, group=None, ops=None):
+        self.group = group if group is not None else dist.group.WORLD
+        self.rank = dist.get_rank(self.group)
+        self.world = dist.get_world_size(self.group)
+        if ops is None:
+            from . import kernels as ops  # HIP; raises on CPU tensors
+        self.ops = ops
+        self.L = None
+
+    # ------------------------------------------------------------------ token sharding
+    def plan(self, L: int):
+        qb = _cdiv(L, 128)
+        self.per = _cdiv(qb, self.world) * 128          # padded tokens per rank
+        self.start = min(L, self.rank * self.per)
+        self.stop = min(L, self.start + self.per)
+        self.L = L
+        assert self.stop > self.start, (
+            f"rank {self.rank} owns no tokens (L={L}, world={self.world}); use fewer ranks")
+        return self.start, self.stop
+
+    def shard_tokens(self, x, cos, sin):
+        """x [B, L, C] (replicated on every rank) -> this rank's [B, L_loc, C]; RoPE tables alike
+        (split_inputs_cp, wan2pt1.py:662-664,685-686)."""
+        s, e = self.plan(x.shape[1])
+        return x[:, s:e].contiguous(), cos[s:e].contiguous(), sin[s:e].contiguous()
+
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """[...] -> [world, ...] (rank-major)."""
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
+        return out
+
+    def gather_tokens(self, out_loc, L):
+        """[B, L_loc, C] -> [B, L, C] on every rank (cat_outputs_cp)."""
+        B, L_loc, C = out_loc.shape
+        buf = torch.zeros((B, self.per, C), dtype=out_loc.dtype, device=out_loc.device)
+        buf[:, :L_loc] = out_loc
+        allb = self.all_gather(buf)  # [W, B, per, C]
+        return allb.permute(1, 0, 2, 3).reshape(B, self.world * self.per, C)[:, :L].contiguous()
+
+    # ------------------------------------------------------------------ self attention
+    def self_attention(self, q, k, v_src, v_strides, out, o_stride_h, o_stride_l, attention_type, topk_ratio,
+                       proj_w=None, proj_b=None):
+        """q, k: [H, L_loc, D] (after RoPE); V element (h,l,d) at v_src + h*v_strides[0] + l*v_strides[1] + d;
+        out: element (h,l,d) at out + h*o_stride_h + l*o_stride_l + d (this rank's rows)."""
+        ops, W = self.ops, self.world
+        H, L_loc, D = q.shape
+        L, per = self.L, self.per
+        kbp = per // 64
+        kb_loc = _cdiv(L_loc, 64)
+        kb_tot = _cdiv(L, 64)
+        sage = attention_type in ("sage", "sagesla")
+        dense = attention_type in ("original", "sage")
+        linear = not dense
+        dt = q.dtype
+        dev = q.device
+        pdt = torch.float16 if sage else dt
+
+        # ---- (1) global smooth-K mean ----
+        km = None
+        if sage or not dense:
+            part = ops.seq_sum_partial(k).sum(dim=1)           # [H, D] f32, this rank's column sums
+            allp = self.all_gather(part)                       # [W, H, D]
+            km = ops.seq_mean_final(allp, W, D, H * D, L, H, D, dt)
+
+        # ---- (2) local K-side state -> packed buffer -> ONE all-gather ----
+        vt = ops.v_transpose(v_src, v_strides[0], v_strides[1], L_loc, H, D, pdt)   # [H, kb_loc, D, 64]
+        pk = k_q = k_s = None
+        if sage:
+            pk, k_q, k_s = ops.sage_quant_pool(k, km, 64, want_pool=not dense)
+        elif not dense:
+            pk, _, _ = ops.sage_quant_pool(k, km, 64, want_quant=False)
+        kv32 = ks32 = None
+        if linear:
+            kv32, ks32 = ops.sla_linear_kv_partial_f32(k, vt)
+
+        k_elem = 1 if sage else 2
+        sizes = {
+            "k": H * per * D * k_elem,
+            "vt": H * kbp * D * 64 * 2,
+            "ks": H * kbp * 4 if sage else 0,
+            "pk": H * kbp * D * 2 if not dense else 0,
+            "kv": H * D * D * 4 if linear else 0,
+            "kss": H * D * 4 if linear else 0,
+        }
+        offs, o = {}, 0
+        for name, sz in sizes.items():
+            offs[name] = o
+            o += _cdiv(sz, 256) * 256
+        pack = torch.zeros(o, dtype=torch.uint8, device=dev)
+
+        def slot(name, dtype, shape):
+            n = sizes[name]
+            return pack[offs[name]:offs[name] + n].view(dtype).view(shape)
+
+        if sage:
+            slot("k", torch.int8, (H, per, D))[:, :L_loc] = k_q
+            slot("ks", torch.float32, (H, kbp))[:, :kb_loc] = k_s
+        else:
+            slot("k", dt, (H, per, D))[:, :L_loc] = k
+        slot("vt", pdt, (H, kbp, D, 64))[:, :kb_loc] = vt
+        if not dense:
+            slot("pk", dt, (H, kbp, D))[:, :kb_loc] = pk
+        if linear:
+            slot("kv", torch.float32, (H, D, D)).copy_(kv32)
+            slot("kss", torch.float32, (H, D)).copy_(ks32)
+
+        allb = self.all_gather(pack)  # [W, bytes]
+
+        def gathered(name, dtype, shape):  # [W, *shape] strided VIEW of one field (no copy)
+            n = sizes[name]
+            return allb[:, offs[name]:offs[name] + n].view(dtype).view((W,) + shape)
+
+        def seq_major(t):  # [W, H, n, ...] -> [H, W*n, ...]
+            return t.permute(1, 0, 2, *range(3, t.dim())).reshape(t.shape[1], W * t.shape[2], *t.shape[3:]).contiguous()
+
+        vt_all = seq_major(gathered("vt", pdt, (H, kbp, D, 64)))                  # [H, W*kbp, D, 64]
+        if sage:
+            k_all = seq_major(gathered("k", torch.int8, (H, per, D)))              # [H, W*per, D]
+            ks_all = seq_major(gathered("ks", torch.float32, (H, kbp)))            # [H, W*kbp]
+        else:
+            k_all = seq_major(gathered("k", dt, (H, per, D)))
+
+        # ---- (3) this rank's Q blocks against the global K/V ----
+        lut = None
+        if not dense:
+            pk_all = seq_major(gathered("pk", dt, (H, kbp, D)))                    # [H, W*kbp, D]
+            topk = min(kb_tot, int(topk_ratio * kb_tot))
+        if sage:
+            pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
+            if not dense:
+                lut = ops.sla_topk(pq, pk_all, topk, kb=kb_tot)
+            ops.attn_i8(q_q, q_s, k_all, ks_all, vt_all, lut, out, o_stride_h, o_stride_l, lk=L)
+        else:
+            if not dense:
+                pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
+                lut = ops.sla_topk(pq, pk_all, topk, kb=kb_tot)
+            ops.attn_16(q, k_all, vt_all, lut, out, o_stride_h, o_stride_l, lk=L)
+        if linear:
+            kv_parts = gathered("kv", torch.float32, (H, D, D))   # [W, H, D, D]
+            ks_parts = gathered("kss", torch.float32, (H, D))     # [W, H, D]
+            kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D,
+                                                 ks_parts.stride(0), H, D, dt)
+            ops.sla_linear_out_(q, kv_t, ksum, proj_w, proj_b, out, o_stride_h, o_stride_l)
+        return out
+
+
+class _ModelAdapter:
+    """What ``WanModel._self_attention`` calls when ``model.seq_parallel`` is set."""
+
+    def __init__(self, sp: SeqParallel):
+        self.sp = sp
+
+    def shard_tokens(self, x, cos, sin):
+        return self.sp.shard_tokens(x, cos, sin)
+
+    def gather_tokens(self, out, L):
+        return self.sp.gather_tokens(out, L)
+
+    def self_attention(self, model, fused, q, k, qkv, out):
+        dim, D = model.dim, 128
+        return self.sp.self_attention(q, k, qkv[:, 2 * dim:], (D, 3 * dim), out, D, dim, model.attention_type,
+                                      model.sla_topk, fused.get("proj_w"), fused.get("proj_b"))
+
+
+def enable(model, group=None, ops=None):
+    """Mirror of ``WanModel.enable_context_parallel`` (wan2pt1.py:786-792)."""
+    model.seq_parallel = _ModelAdapter(SeqParallel(group, ops))
+    return model
+
+
+def disable(model):
+    model.seq_parallel = None
+    return model
