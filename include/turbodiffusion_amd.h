@@ -55,6 +55,15 @@ typedef void* td_stream_t; /* hipStream_t */
 int td_abi_version(void);
 const char* td_last_error(void);
 
+/* Kernel-selection knobs for benchmarking (results never depend on them: every variant of an
+ * operator is bit-identical).  value 0 = automatic. */
+#define TD_TUNE_GEMM_VARIANT 0 /* 1 = 128x128-tile kernel, 2 = 256x256-tile LDS-DMA kernel, 3 = 256x256 ping-pong */
+#define TD_TUNE_GEMM_ABLATE 1  /* profiling only, WRONG results: 1 no dequant, 2 no MFMA, 3 no LDS-DMA */
+#define TD_TUNE_COUNT 8
+int td_set_tuning(int key, int value);
+/* profiling: copy the n (<= 256) 64-bit s_memtime stamps of the last TD_TUNE_GEMM_ABLATE == 9 launch to host */
+int td_debug_read(unsigned long long* host_dst, int n);
+
 /* ---- a16: per-128x128-block INT8 quantiser (quant_cuda, ops/quant/quant.cu:28-71) ----
  * x [m,n] f16|bf16 -> q [m,n] int8, s [ceil(m/128), ceil(n/128)] f32.
  * amax = max(1e-8, max|x|) over the block's valid elements; q = sat_s8(rne(x*(128/amax)));

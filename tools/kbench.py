@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--dim", type=int, default=1536)
     ap.add_argument("--ffn", type=int, default=8960)
     ap.add_argument("--topk", type=float, default=0.1)
+    ap.add_argument("--ablate", action="store_true")
     ap.add_argument("--dense", action="store_true", help="also time dense attention (slow)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
@@ -82,8 +83,22 @@ def main():
             aq, as_ = K.quant_i8_block128(a)
             wq, ws = K.quant_i8_block128((torch.randn(n, k, device=dev) / math.sqrt(k)).bfloat16())
             b = torch.zeros(n, device=dev).bfloat16()
-            t = timeit(lambda: K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=(nm == "ffn1")), args.iters)
-            rep(f"gemm_w8a8 {nm} M={L} N={n} K={k}", t, bytes_=L * k + n * k + 2 * L * n, flops=2.0 * L * n * k, peak_f=I8)
+            outs = {}
+            for var in (1, 2, 3):
+                K.set_tuning(K.TUNE_GEMM_VARIANT, var)
+                outs[var] = K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=(nm == "ffn1"))
+                t = timeit(lambda: K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=(nm == "ffn1")), args.iters)
+                rep(f"gemm_w8a8[v{var}] {nm} M={L} N={n} K={k}", t, bytes_=L * k + n * k + 2 * L * n, flops=2.0 * L * n * k, peak_f=I8)
+            if args.ablate and nm != "ffn1":
+                K.set_tuning(K.TUNE_GEMM_VARIANT, 2)
+                for abl in (1, 2, 3):
+                    K.set_tuning(1, abl)
+                    t = timeit(lambda: K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b), args.iters)
+                    rep(f"gemm_w8a8[v2 ABLATE {abl}] {nm}", t, flops=2.0 * L * n * k, peak_f=I8)
+                K.set_tuning(1, 0)
+            K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
+            print(json.dumps({"gemm_variants_bit_identical": bool(torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3]))}), flush=True)
+            del outs
             del a, aq, wq
     if not only or "prep" in only:
         qkv = torch.randn(L, 3 * dim, device=dev).bfloat16()

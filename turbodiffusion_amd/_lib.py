@@ -24,6 +24,8 @@ _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_v
 SIGNATURES = {
     "td_abi_version": [],
     "td_last_error": [],
+    "td_set_tuning": [_i32, _i32],
+    "td_debug_read": [_vp, _i32],
     "td_quant_i8_block128": [_vp, _i32, _vp, _vp, _i64, _i64, _vp],
     "td_gemm_w8a8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _vp],
     "td_rmsnorm": [_vp, _i32, _vp, _vp, _i32, _f32, _i64, _i64, _vp],

@@ -18,7 +18,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libturbodiffusion_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+# -fno-slp-vectorize: hipcc otherwise packs adjacent fp32 adds/FMAs into v_pk_*_f32, which measured ~4x
+# slower than the plain forms beside MFMAs on gfx950 (the GEMM dequant segments: 600 -> ~300 cycles)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
          "-Wno-unused-result"]
 
 

@@ -34,12 +34,6 @@ __device__ __forceinline__ uint32_t g_swz(uint32_t row, uint32_t slot) {
   return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
 }
 
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-  const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
-  const float k1 = 0.044715f;
-  float inner = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanhf(inner));
-}
 
 template <int ODT, int EPI, bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(
@@ -155,26 +149,18 @@ __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(
       for (int g4 = 0; g4 < 4; ++g4) {
         const int64_t n = n0 + wn * 64 + j * 32 + 8 * g4 + 4 * hi;
         if (n >= N) continue;  // N % 8 == 0 and n % 4 == 0: the quad is all-in or all-out
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = accf[i][j][4 * g4 + e];
-        uint32_t hb[4];
+        float bf[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (HAS_BIAS) {
           const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
-          hb[0] = bb.x & 0xffffu; hb[1] = bb.x >> 16; hb[2] = bb.y & 0xffffu; hb[3] = bb.y >> 16;
+          unpack2<ODT>(bb.x, bf[0], bf[1]);
+          unpack2<ODT>(bb.y, bf[2], bf[3]);
         }
-        uint32_t ob[4];
+        uint32_t ob[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t o = f32_to_half_bits<ODT>(v[e]);
-          if constexpr (HAS_BIAS)
-            o = f32_to_half_bits<ODT>(half_bits_to_f32<ODT>(o) + half_bits_to_f32<ODT>(hb[e]));
-          if constexpr (EPI == TD_EPI_GELU_TANH)
-            o = f32_to_half_bits<ODT>(gelu_tanh_f(half_bits_to_f32<ODT>(o)));
-          ob[e] = o;
-        }
-        *reinterpret_cast<uint2*>(D + m * ldd + n) =
-            make_uint2(ob[0] | (ob[1] << 16), ob[2] | (ob[3] << 16));
+        for (int e = 0; e < 2; ++e)
+          ob[e] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][4 * g4 + 2 * e], accf[i][j][4 * g4 + 2 * e + 1],
+                                                         bf[2 * e], bf[2 * e + 1]);
+        *reinterpret_cast<uint2*>(D + m * ldd + n) = make_uint2(ob[0], ob[1]);
       }
     }
   }
@@ -217,6 +203,14 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
              "td_gemm_w8a8: epilogue %d", epilogue);
   if (m == 0 || n == 0) return TD_OK;
   hipStream_t st = (hipStream_t)stream;
+  // large problems: 256x256 LDS-DMA kernel (gemm_w8a8_256.hip), bit-identical results
+  const int variant = td_tuning(TD_TUNE_GEMM_VARIANT);
+  if (variant == 3 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0)) {
+    TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 3 needs ldd %% 8 == 0");
+    return td_gemm_w8a8_pp(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
+  }
+  if (variant == 2)
+    return td_gemm_w8a8_256(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
 #define TD_GEMM_CASE(ODT)                                                                          \
   if (epilogue == TD_EPI_GELU_TANH) {                                                              \
     return bias ? launch_gemm<ODT, TD_EPI_GELU_TANH, true>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st) \

@@ -35,6 +35,16 @@ void td_set_error(const char* fmt, ...);
     }                                                                  \
   } while (0)
 
+// tuning knobs (td_set_tuning); 0 = automatic choice
+int td_tuning(int key);
+// internal kernel entry points shared between translation units
+int td_gemm_w8a8_pp(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                    const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
+                    int64_t k, int64_t ldd, hipStream_t st);
+int td_gemm_w8a8_256(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                     const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
+                     int64_t k, int64_t ldd, hipStream_t st);
+
 __host__ __device__ static inline int64_t td_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // ---- scalar conversions (device) ------------------------------------------
@@ -91,6 +101,41 @@ template <int DT> __device__ __forceinline__ uint32_t pack2(float a, float b) {
 template <int DT> __device__ __forceinline__ uint4 pack8(const float* f) {
   return make_uint4(pack2<DT>(f[0], f[1]), pack2<DT>(f[2], f[3]), pack2<DT>(f[4], f[5]),
                     pack2<DT>(f[6], f[7]));
+}
+
+// GELU-tanh (wan2pt1.py:375 nn.GELU(approximate="tanh")) on a value already rounded to the output dtype:
+// 0.5*x*(1+tanh(u)), u = sqrt(2/pi)*(x + 0.044715 x^3), with tanh(u) = sign(u)*(1 - 2/(exp(2|u|)+1)) on
+// v_exp_f32 / v_rcp_f32 (|u| form: no cancellation, |error| of tanh <~ 2 ulp(1)).  Shared by every GEMM
+// kernel so that all variants are bit-identical.
+__device__ __forceinline__ float td_gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
+  const float k1 = 0.044715f;
+  const float u = k0 * (x + k1 * x * x * x);
+  const float e = __builtin_amdgcn_exp2f(fabsf(u) * 2.8853900817779268f);  // exp(2|u|)
+  const float th = copysignf(1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f), u);
+  return 0.5f * x * (1.0f + th);
+}
+
+// unpack one packed 32-bit word of two 16-bit values to floats
+template <int DT> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+  if constexpr (DT == TD_BF16) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+  else { lo = f16_bits_to_f32(w & 0xffffu); hi = f16_bits_to_f32(w >> 16); }
+}
+// GEMM epilogue for two adjacent outputs (Int8Linear.forward, ops/core.py:408-412 and the FFN GELU):
+// cast(acc) -> [+ bias, cast] -> [gelu_tanh, cast]; every cast is the hardware RNE pack (v_cvt_pk_*).
+// b0,b1: the bias values already widened to fp32.  Returns the packed 16-bit pair.
+template <int ODT, int EPI, bool HAS_BIAS>
+__device__ __forceinline__ uint32_t td_gemm_epilogue2(float a0, float a1, float b0, float b1) {
+  uint32_t w = pack2<ODT>(a0, a1);
+  if constexpr (HAS_BIAS) {
+    float x0, x1; unpack2<ODT>(w, x0, x1);
+    w = pack2<ODT>(x0 + b0, x1 + b1);
+  }
+  if constexpr (EPI == TD_EPI_GELU_TANH) {
+    float x0, x1; unpack2<ODT>(w, x0, x1);
+    w = pack2<ODT>(td_gelu_tanh(x0), td_gelu_tanh(x1));
+  }
+  return w;
 }
 
 // ---- wave-level reductions (64 lanes) --------------------------------------

@@ -57,6 +57,14 @@ def _timed(name, meta, fn):
     return r
 
 
+TUNE_GEMM_VARIANT = 0
+
+
+def set_tuning(key: int, value: int):
+    """Kernel-selection knob (benchmarking only; every variant of an operator is bit-identical)."""
+    call("td_set_tuning", key, value)
+
+
 # ----------------------------------------------------------------------------- a16
 def quant_i8_block128(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """x [m,n] f16|bf16 -> (q int8 [m,n], s f32 [ceil(m/128), ceil(n/128)])."""
