@@ -171,10 +171,12 @@ int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut,
                int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
                int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream);
 
+#define TD_SLA_NCH 32 /* partial-sum chunks per head of td_sla_linear_kv* (workspace leading extent) */
+
 /* ---- a14: linear-attention branch (SLA/core.py:243-253, feature_map = softmax) ----
  * pass 1: ck = cast(softmax_D(k)); kvsum[h] = cast(ck^T @ v) ; ksum[h] = cast(sum_L ck)
- *   k [H, L, D] dtype; vt = the V^T tiles of td_v_transpose (vt_dtype); ws_kv f32 [H,16,D,D] and
- *   ws_ks f32 [H,16,D] are scratch (partials summed in order: deterministic);
+ *   k [H, L, D] dtype; vt = the V^T tiles of td_v_transpose (vt_dtype); ws_kv f32 [H,TD_SLA_NCH,D,D] and
+ *   ws_ks f32 [H,TD_SLA_NCH,D] are scratch (partials summed in order: deterministic);
  *   outputs kvsum_t [H, D(d2), D(d1)] dtype (TRANSPOSED: the A operand of pass 2), ksum [H, D]. */
 int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
                      float* ws_ks, void* kvsum_t, void* ksum, int64_t L, int H, int D,

@@ -17,7 +17,7 @@
 //        matching k order).  The result is added to o_s in place.
 #include "td_common.h"
 
-#define LK_NCH 16  // partial-sum chunks per head
+#define LK_NCH TD_SLA_NCH  // partial-sum chunks per head (include/turbodiffusion_amd.h)
 
 __device__ __forceinline__ uint32_t sw128(uint32_t row, uint32_t slot) {  // 128-B rows
   return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
@@ -42,9 +42,16 @@ template <> struct MmaT<TD_BF16> {
   }
 };
 
+// softmax over D in the exp2 domain with v_exp_f32 / v_rcp_f32 (1 ulp each; the result is rounded to a
+// 16-bit type right after, so this agrees with expf()/division to that rounding except in ~1e-4 of cases)
+#define TD_LOG2E 1.4426950408889634f
+
 // ---------------------------------------------------------------------------------------
 // pass 1a: partial kv / ksum over a range of K blocks
 //   KDT: dtype of k (and of the rounded softmax ck);  VDT: dtype of the V^T tiles / MFMA
+// Thread (tg = tid/16, c8 = tid%16) owns tokens 4tg..4tg+3 x channels 8c8..8c8+7 of each 64-token block:
+// 4 coalesced 16-B row loads, the row softmax is a 16-lane butterfly, and the transposed image ck^T[d][tok]
+// is written as 8-byte pieces (4 consecutive tokens of one channel are 4 consecutive MFMA positions).
 // ---------------------------------------------------------------------------------------
 template <int KDT, int VDT>
 __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* __restrict__ k,
@@ -58,11 +65,15 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
   typedef typename MmaT<VDT>::frag frag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hi = lane >> 5;
-  const int c8 = tid & 15, r0 = tid >> 4;
+  const int c8 = tid & 15, tg = tid >> 4;
   const int ch = blockIdx.x, h = blockIdx.y;
   const int per = (Kb + LK_NCH - 1) / LK_NCH;
   const int kb_lo = ch * per, kb_hi = min(Kb, kb_lo + per);
   const int wr = wave >> 1, wc = wave & 1;
+  // tokens 4tg..4tg+3 sit at positions p0..p0+3 of 16-group tg/4: 8-byte piece (p0/4) of slot 2*(tg/4) + p0/8
+  const int p0 = perm_pos((4 * tg) & 15);
+  const uint32_t ck_slot = (uint32_t)((tg >> 2) * 2 + (p0 >> 3));
+  const uint32_t ck_sub = (uint32_t)((p0 & 7) * 2);
 
   v16f acc[2][2];
 #pragma unroll
@@ -74,46 +85,55 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
   float ks_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   for (int kb = kb_lo; kb < kb_hi; ++kb) {
-    // V^T tile -> LDS (contiguous 16 KB, same swizzle as the attention kernel)
+    // global loads first: the V^T tile (contiguous 16 KB) and this thread's 4 K rows
+    uint4 vv[4], kr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      vv[i] = *reinterpret_cast<const uint4*>(vt + ((int64_t)h * Kb + kb) * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int64_t l = (int64_t)kb * 64 + 4 * tg + t;
+      kr[t] = make_uint4(0, 0, 0, 0);
+      if (l < L) kr[t] = *reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int v = tid + 256 * i;
-      *reinterpret_cast<uint4*>(vT + sw128(v >> 3, v & 7)) =
-          *reinterpret_cast<const uint4*>(vt + ((int64_t)h * Kb + kb) * (128 * 64) + (int64_t)v * 8);
+      *reinterpret_cast<uint4*>(vT + sw128(v >> 3, v & 7)) = vv[i];
     }
-    // k rows: softmax over D (16 lanes share a row), rounded to KDT, written transposed
+    // softmax over D (16 lanes share a row), rounded to KDT; ck[t][j]
+    float ck[4][8];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int tok = it * 16 + r0;
-      const int64_t l = (int64_t)kb * 64 + tok;
+    for (int t = 0; t < 4; ++t) {
+      const bool ok = (int64_t)kb * 64 + 4 * tg + t < L;
       float f[8];
-      if (l < L) {
-        unpack8<KDT>(*reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8), f);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) f[j] = 0.f;
-      }
+      unpack8<KDT>(kr[t], f);
       float mx = f[0];
 #pragma unroll
       for (int j = 1; j < 8; ++j) mx = fmaxf(mx, f[j]);
 #pragma unroll
       for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      const float mb = mx * TD_LOG2E;
       float sum = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { f[j] = expf(f[j] - mx); sum += f[j]; }
+      for (int j = 0; j < 8; ++j) { f[j] = __builtin_amdgcn_exp2f(fmaf(f[j], TD_LOG2E, -mb)); sum += f[j]; }
 #pragma unroll
       for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      const int g16 = tok >> 4, pos = perm_pos(tok & 15);
-      const uint32_t slot = (uint32_t)(g16 * 2 + (pos >> 3));
+      const float inv = ok ? __builtin_amdgcn_rcpf(sum) : 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float ck = (l < L) ? f[j] / sum : 0.f;
-        ck = half_bits_to_f32<KDT>(f32_to_half_bits<KDT>(ck));  // softmax(...).to(dtype)
-        ks_acc[j] += ck;
-        const uint32_t d1 = (uint32_t)(c8 * 8 + j);
-        *reinterpret_cast<uint16_t*>(ckT + sw128(d1, slot) + (pos & 7) * 2) =
-            (uint16_t)f32_to_half_bits<VDT>(ck);
+      for (int j = 0; j < 8; j += 2) {
+        const uint32_t w = pack2<KDT>(f[j] * inv, f[j + 1] * inv);  // softmax(...).to(dtype)
+        unpack2<KDT>(w, ck[t][j], ck[t][j + 1]);
+        ks_acc[j] += ck[t][j];
+        ks_acc[j + 1] += ck[t][j + 1];
       }
+    }
+    // transposed write: for channel d1 = 8c8+j the 4 tokens are one 8-byte piece
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t d1 = (uint32_t)(c8 * 8 + j);
+      *reinterpret_cast<uint2*>(ckT + sw128(d1, ck_slot) + ck_sub) =
+          make_uint2(pack2<VDT>(ck[0][j], ck[1][j]), pack2<VDT>(ck[2][j], ck[3][j]));
     }
     __syncthreads();
 #pragma unroll
@@ -145,7 +165,7 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
         out[d1 * 128 + d2] = acc[i][j][r];
       }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) ksred[r0][c8 * 8 + j] = ks_acc[j];
+  for (int j = 0; j < 8; ++j) ksred[tg][c8 * 8 + j] = ks_acc[j];
   __syncthreads();
   if (tid < 128) {
     float s = 0.f;
@@ -164,10 +184,12 @@ __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __res
                                                               int64_t kv_sh, int64_t kv_sc, int64_t ks_sh,
                                                               int64_t ks_sc, void* __restrict__ kv_out,
                                                               void* __restrict__ ks_out) {
-  const int h = blockIdx.x;
-  for (int i = threadIdx.x; i < 128 * 128; i += 256) {
+  const int h = blockIdx.x, part = blockIdx.y;  // 16 workgroups per head, 1024 kv elements each
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int i = part * 1024 + e * 256 + threadIdx.x;
     float s = 0.f;
-    for (int c = 0; c < nch; ++c) s += ws_kv[h * kv_sh + c * kv_sc + i];
+    for (int c = 0; c < nch; ++c) s += ws_kv[h * kv_sh + c * kv_sc + i];  // in order: deterministic
     if constexpr (ROUND) {
       const int d1 = i >> 7, d2 = i & 127;
       ((uint16_t*)kv_out)[(int64_t)h * 128 * 128 + d2 * 128 + d1] = (uint16_t)f32_to_half_bits<DT>(s);
@@ -175,7 +197,7 @@ __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __res
       ((float*)kv_out)[(int64_t)h * 128 * 128 + i] = s;  // fp32, NOT transposed: still a partial
     }
   }
-  if (threadIdx.x < 128) {
+  if (part == 0 && threadIdx.x < 128) {
     float s = 0.f;
     for (int c = 0; c < nch; ++c) s += ws_ks[h * ks_sh + c * ks_sc + threadIdx.x];
     if constexpr (ROUND) ((uint16_t*)ks_out)[h * 128 + threadIdx.x] = (uint16_t)f32_to_half_bits<DT>(s);
@@ -214,11 +236,11 @@ extern "C" int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, in
   TD_REQUIRE(D == 128 && nch > 0 && H > 0, TD_ERR_UNSUPPORTED, "td_sla_linear_kv_final: D=%d nch=%d", D, nch);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == TD_BF16)
-    linear_kv_final_kernel<TD_BF16, true><<<H, 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_BF16, true><<<dim3(H, 16), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
   else if (out_dtype == TD_F16)
-    linear_kv_final_kernel<TD_F16, true><<<H, 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_F16, true><<<dim3(H, 16), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
   else if (out_dtype == TD_F32)
-    linear_kv_final_kernel<TD_F32, false><<<H, 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_F32, false><<<dim3(H, 16), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
   else {
     td_set_error("td_sla_linear_kv_final: out dtype %d", out_dtype);
     return TD_ERR_UNSUPPORTED;
@@ -240,7 +262,7 @@ extern "C" int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt
 // ---------------------------------------------------------------------------------------
 // pass 2: o += proj_l( (cq @ kvsum) / (1e-5 + sum(cq*ksum)) )
 // ---------------------------------------------------------------------------------------
-#define LO_QB_PER_WG 4
+#define LO_QB_PER_WG 8
 template <int DT>
 __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restrict__ q,
                                                          const uint16_t* __restrict__ kvT,
@@ -262,12 +284,13 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
     *reinterpret_cast<uint4*>(kvs + sw256(row, slot)) =
         *reinterpret_cast<const uint4*>(kvT + (int64_t)h * 128 * 128 + row * 128 + slot * 8);
   }
-  for (int i = tid; i < 128 * 128; i += 256) {  // Wp fp32 -> DT (autocast), permuted k order
-    const int d3 = i >> 7, d2 = i & 127;
-    const int pos = perm_pos(d2 & 15);
-    const uint32_t slot = (uint32_t)((d2 >> 4) * 2 + (pos >> 3));
-    *reinterpret_cast<uint16_t*>(wps + sw256(d3, slot) + (pos & 7) * 2) =
-        (uint16_t)f32_to_half_bits<DT>(wp[i]);
+  for (int i = tid; i < 128 * 16; i += 256) {  // Wp fp32 -> DT (autocast), permuted k order, 16 B per item
+    const int d3 = i >> 4, slot = i & 15;         // slot = 2*(16-group) + half: d2 = 16g + 4*half + {0-3, 8-11}
+    const float* src = wp + d3 * 128 + (slot >> 1) * 16 + (slot & 1) * 4;
+    const float4 lo = *reinterpret_cast<const float4*>(src);
+    const float4 hi4 = *reinterpret_cast<const float4*>(src + 8);
+    *reinterpret_cast<uint4*>(wps + sw256(d3, slot)) =
+        make_uint4(pack2<DT>(lo.x, lo.y), pack2<DT>(lo.z, lo.w), pack2<DT>(hi4.x, hi4.y), pack2<DT>(hi4.z, hi4.w));
   }
   __syncthreads();
 
@@ -293,27 +316,37 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
       for (int e = 0; e < 8; ++e) mx = fmaxf(mx, qf[ks][e]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mb = mx * TD_LOG2E;
     float sum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { qf[ks][e] = expf(qf[ks][e] - mx); sum += qf[ks][e]; }
+      for (int e = 0; e < 8; ++e) {
+        qf[ks][e] = __builtin_amdgcn_exp2f(fmaf(qf[ks][e], TD_LOG2E, -mb));
+        sum += qf[ks][e];
+      }
     sum += __shfl_xor(sum, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(sum);
     float den = 0.f;
     uint4 cqf[8];
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
+      uint32_t w[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float cq = half_bits_to_f32<DT>(f32_to_half_bits<DT>(qf[ks][e] / sum));
-        qf[ks][e] = cq;
-        den += half_bits_to_f32<DT>(f32_to_half_bits<DT>(cq * ksf[ks][e]));  // (q * ksum) in dt
+      for (int e = 0; e < 8; e += 2) {
+        w[e >> 1] = pack2<DT>(qf[ks][e] * inv, qf[ks][e + 1] * inv);  // cq = softmax(...).to(dt)
+        float c0, c1;
+        unpack2<DT>(w[e >> 1], c0, c1);
+        float p0, p1;
+        unpack2<DT>(pack2<DT>(c0 * ksf[ks][e], c1 * ksf[ks][e + 1]), p0, p1);  // (q * ksum) in dt
+        den += p0 + p1;
       }
-      cqf[ks] = pack8<DT>(qf[ks]);
+      cqf[ks] = make_uint4(w[0], w[1], w[2], w[3]);
     }
     den += __shfl_xor(den, 32, 64);
-    den = half_bits_to_f32<DT>(f32_to_half_bits<DT>(den));            // .sum(-1) -> dt
-    den = half_bits_to_f32<DT>(f32_to_half_bits<DT>(1e-5f + den));    // 1e-5 + ... -> dt
+    den = round_half<DT>(den);            // .sum(-1) -> dt
+    den = round_half<DT>(1e-5f + den);    // 1e-5 + ... -> dt
+    const float rden = __builtin_amdgcn_rcpf(den);
     // ---- num^T[d2][tok] = kvsum^T . cq^T ----
     v16f a1[4];
 #pragma unroll
@@ -333,9 +366,11 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
     for (int c = 0; c < 4; ++c) {
       float t[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float num = half_bits_to_f32<DT>(f32_to_half_bits<DT>(a1[c][r]));
-        t[r] = num / den;
+      for (int r = 0; r < 16; r += 2) {
+        float n0, n1;
+        unpack2<DT>(pack2<DT>(a1[c][r], a1[c][r + 1]), n0, n1);  // num in dt
+        t[r] = n0 * rden;
+        t[r + 1] = n1 * rden;
       }
       olf[2 * c] = pack8<DT>(&t[0]);
       olf[2 * c + 1] = pack8<DT>(&t[8]);
@@ -361,14 +396,15 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
           const float bias[4] = {bb.x, bb.y, bb.z, bb.w};
           const uint2 ov = *reinterpret_cast<const uint2*>(op + d3);
           const uint32_t ob[4] = {ov.x & 0xffffu, ov.x >> 16, ov.y & 0xffffu, ov.y >> 16};
-          uint32_t res[4];
+          uint32_t res[2];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float bdt = half_bits_to_f32<DT>(f32_to_half_bits<DT>(bias[e]));  // autocast bias
-            const float ol = half_bits_to_f32<DT>(f32_to_half_bits<DT>(a2[4 * g4 + e] + bdt));
-            res[e] = f32_to_half_bits<DT>(half_bits_to_f32<DT>(ob[e]) + ol);
+          for (int e = 0; e < 4; e += 2) {
+            float b0, b1, l0, l1;
+            unpack2<DT>(pack2<DT>(bias[e], bias[e + 1]), b0, b1);                                  // autocast bias
+            unpack2<DT>(pack2<DT>(a2[4 * g4 + e] + b0, a2[4 * g4 + e + 1] + b1), l0, l1);          // o_l in dt
+            res[e >> 1] = pack2<DT>(half_bits_to_f32<DT>(ob[e]) + l0, half_bits_to_f32<DT>(ob[e + 1]) + l1);
           }
-          *reinterpret_cast<uint2*>(op + d3) = make_uint2(res[0] | (res[1] << 16), res[2] | (res[3] << 16));
+          *reinterpret_cast<uint2*>(op + d3) = make_uint2(res[0], res[1]);
         }
       }
     }

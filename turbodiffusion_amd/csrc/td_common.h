@@ -121,6 +121,12 @@ template <int DT> __device__ __forceinline__ void unpack2(uint32_t w, float& lo,
   if constexpr (DT == TD_BF16) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
   else { lo = f16_bits_to_f32(w & 0xffffu); hi = f16_bits_to_f32(w >> 16); }
 }
+// round an fp32 value to the 16-bit dtype and back (hardware RNE)
+template <int DT> __device__ __forceinline__ float round_half(float x) {
+  float lo, hi;
+  unpack2<DT>(pack2<DT>(x, 0.f), lo, hi);
+  return lo;
+}
 // GEMM epilogue for two adjacent outputs (Int8Linear.forward, ops/core.py:408-412 and the FFN GELU):
 // cast(acc) -> [+ bias, cast] -> [gelu_tanh, cast]; every cast is the hardware RNE pack (v_cvt_pk_*).
 // b0,b1: the bias values already widened to fp32.  Returns the packed 16-bit pair.

@@ -245,11 +245,14 @@ def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
 
 
 # ----------------------------------------------------------------------------- a14
+SLA_NCH = 32  # TD_SLA_NCH in include/turbodiffusion_amd.h
+
+
 def sla_linear_kv(k, vt):
     require_gpu(k, vt)
     H, L_, D = k.shape
-    ws_kv = torch.empty((H, 16, D, D), dtype=torch.float32, device=k.device)
-    ws_ks = torch.empty((H, 16, D), dtype=torch.float32, device=k.device)
+    ws_kv = torch.empty((H, SLA_NCH, D, D), dtype=torch.float32, device=k.device)
+    ws_ks = torch.empty((H, SLA_NCH, D), dtype=torch.float32, device=k.device)
     kv_t = torch.empty((H, D, D), dtype=k.dtype, device=k.device)
     ksum = torch.empty((H, D), dtype=k.dtype, device=k.device)
     call("td_sla_linear_kv", ptr(k), dt_code(k.dtype), ptr(vt), dt_code(vt.dtype), ptr(ws_kv), ptr(ws_ks),
@@ -276,13 +279,13 @@ def sla_linear_kv_partial_f32(k, vt, kv_out=None, ks_out=None):
     """This rank's un-rounded contribution: (kv f32 [H, D, D] (d1,d2), ks f32 [H, D])."""
     require_gpu(k, vt)
     H, L_, D = k.shape
-    ws_kv = torch.empty((H, 16, D, D), dtype=torch.float32, device=k.device)
-    ws_ks = torch.empty((H, 16, D), dtype=torch.float32, device=k.device)
+    ws_kv = torch.empty((H, SLA_NCH, D, D), dtype=torch.float32, device=k.device)
+    ws_ks = torch.empty((H, SLA_NCH, D), dtype=torch.float32, device=k.device)
     call("td_sla_linear_kv_partial", ptr(k), dt_code(k.dtype), ptr(vt), dt_code(vt.dtype), ptr(ws_kv), ptr(ws_ks),
          L_, H, D, stream_ptr())
     kv = kv_out if kv_out is not None else torch.empty((H, D, D), dtype=torch.float32, device=k.device)
     ks = ks_out if ks_out is not None else torch.empty((H, D), dtype=torch.float32, device=k.device)
-    call("td_sla_linear_kv_final", ptr(ws_kv), ptr(ws_ks), 16, 16 * D * D, D * D, 16 * D, D, ptr(kv), ptr(ks),
+    call("td_sla_linear_kv_final", ptr(ws_kv), ptr(ws_ks), SLA_NCH, SLA_NCH * D * D, D * D, SLA_NCH * D, D, ptr(kv), ptr(ks),
          L.TD_F32, H, D, stream_ptr())
     return kv, ks
 
