@@ -57,7 +57,7 @@ const char* td_last_error(void);
 
 /* Kernel-selection knobs for benchmarking (results never depend on them: every variant of an
  * operator is bit-identical).  value 0 = automatic. */
-#define TD_TUNE_GEMM_VARIANT 0 /* 1 = 128x128-tile kernel, 2 = 256x256-tile LDS-DMA kernel, 3 = 256x256 ping-pong */
+#define TD_TUNE_GEMM_VARIANT 0 /* 1 = 128x128-tile kernel, 2 = 256x256-tile LDS-DMA kernel, 3 = 256x256 ping-pong, 4 = 256x256 fine-interleaved */
 #define TD_TUNE_GEMM_ABLATE 1  /* profiling only, WRONG results: 1 no dequant, 2 no MFMA, 3 no LDS-DMA */
 #define TD_TUNE_COUNT 8
 int td_set_tuning(int key, int value);

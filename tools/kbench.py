@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from turbodiffusion_amd import kernels as K  # noqa: E402
 
 HBM, I8, F16 = 8.0e12, 5.0e15, 2.5e15
+GEMM_VARIANTS = (1, 2, 3, 4)
 
 
 def timeit(fn, iters, warm=3):
@@ -84,7 +85,7 @@ def main():
             wq, ws = K.quant_i8_block128((torch.randn(n, k, device=dev) / math.sqrt(k)).bfloat16())
             b = torch.zeros(n, device=dev).bfloat16()
             outs = {}
-            for var in (1, 2, 3):
+            for var in GEMM_VARIANTS:
                 K.set_tuning(K.TUNE_GEMM_VARIANT, var)
                 outs[var] = K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=(nm == "ffn1"))
                 t = timeit(lambda: K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=(nm == "ffn1")), args.iters)
@@ -97,7 +98,7 @@ def main():
                     rep(f"gemm_w8a8[v2 ABLATE {abl}] {nm}", t, flops=2.0 * L * n * k, peak_f=I8)
                 K.set_tuning(1, 0)
             K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
-            print(json.dumps({"gemm_variants_bit_identical": bool(torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3]))}), flush=True)
+            print(json.dumps({"gemm_variants_bit_identical": bool(all(torch.equal(outs[GEMM_VARIANTS[0]], o) for o in outs.values()))}), flush=True)
             del outs
             del a, aq, wq
     if not only or "prep" in only:

@@ -205,6 +205,10 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
   hipStream_t st = (hipStream_t)stream;
   // large problems: 256x256 LDS-DMA kernel (gemm_w8a8_256.hip), bit-identical results
   const int variant = td_tuning(TD_TUNE_GEMM_VARIANT);
+  if (variant == 4) {
+    TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 4 needs ldd %% 8 == 0");
+    return td_gemm_w8a8_fi(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
+  }
   if (variant == 3 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0)) {
     TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 3 needs ldd %% 8 == 0");
     return td_gemm_w8a8_pp(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);

@@ -1,0 +1,314 @@
+// a17 (large-M path, v4) — block-scaled W8A8 INT8 GEMM, 256x256 tile, LDS-DMA staging, FINE-INTERLEAVED
+// software pipeline: ONE s_barrier per K block and a homogeneous per-wave instruction stream.
+//
+// Same semantics (bit-identical) as gemm_w8a8.hip / gemm_w8a8_256.hip / gemm_w8a8_pp.hip
+// (reference: ops/gemm/kernel.hpp:390-427, utils.hpp:116-121):
+//   acc_f32[m,n] = sum over 128-deep K blocks (ascending) of
+//                  fma(float(int32 sum_k a[m,k]*b[n,k]), a_s[m/128,kb]*b_s[n/128,kb], acc)
+//
+// Why a fourth kernel.  The W8A8 format forces 2 VALU ops (int32->fp32, FMA with the block scale) per
+// output element per 128-deep K block = 4 VALU per v_mfma_i32_16x16x64_i8.  On gfx950 a SIMD issues one
+// VALU-class instruction (MFMA included) per ~4.3 cycles whatever the number of waves (tools/ubench), so
+// a K block of a SIMD's two 128x64 wave tiles costs (64 + 256) x 2 issues ~ 2750 cycles against 2048-2200
+// cycles of matrix-pipe work: the kernel is VALU-issue bound and the only thing a schedule can do is keep
+// BOTH pipes busy all the time.  The ping-pong kernel (v3) separates MFMA segments and VALU segments with
+// 8 barriers per K block; measured, the VALU segments run at ~9 cycles/op beside the partner's MFMAs and
+// every barrier costs a start-of-segment penalty: ~6000 cycles per K block.
+//
+// Here every wave runs the same homogeneous stream, one "slot" = 1 MFMA + 4 dequant VALU:
+//   group g = (K block kb, 16-row m sub-tile i) = 8 slots:
+//     slots 0-3: MFMA(k 0..63)   of sub-tiles (i, j=0..3)  ||  16 x v_add  (int32 bits -> fp32) of group g-1
+//     slots 4-7: MFMA(k 64..127) of sub-tiles (i, j=0..3)  ||  16 x v_fmac (x block scale)     of group g-1
+//   so the dequant of a group's results is issued one group (>= 8 MFMAs) after the MFMAs that produce
+//   them: no MFMA->VALU dependency stall, no hazard, and the stream is the same mix at every point, so
+//   the two waves of a SIMD interleave into a steady MFMA/VALU mix without any choreography.
+//   * fragments: weights of the K block stay in 32 VGPRs; the activation fragment of group g+1 is read
+//     (2 ds_read_b128) at the start of group g into the other half of a 2-deep ring.
+//   * ONE barrier per K block, between groups 6 and 7: by then every LDS read of stage kb has returned
+//     (the fragment of group 7 was read during group 6) and each wave's pieces of stage kb+1 have landed
+//     (s_waitcnt vmcnt(0) lgkmcnt(0) just before).  Group 7 then reloads the weight fragments from stage
+//     kb+1 half by half right behind the MFMAs that last used them, so the next K block starts without a
+//     bubble, and the LDS-DMA of stage kb+2 into the freed buffer starts in group 7 and is spread over the
+//     next K block's groups 0-4.
+//   * int32 -> fp32 without v_cvt: each sub-tile's two-MFMA chain starts from C = 0x4B400000 (1.5*2^23);
+//     |sum over a 128-deep block| < 2^22, so the int32 result reinterpreted as fp32 is exactly
+//     12582912 + sum and one exact v_add_f32 recovers float(sum).
+//   * MFMAs and VALU are asm volatile in program order (the order IS the design); the compiler only
+//     allocates registers and inserts s_waitcnt for the LDS reads.
+//   * epilogue identical to v3 (permlane32 swap -> 16-byte row-contiguous stores).
+#include "td_common.h"
+
+#define F_BM 256
+#define F_BN 256
+#define F_TILE (256 * 128)        // one operand tile per K block, bytes
+#define F_STAGE (2 * F_TILE)      // activations + weights
+#define F_LDS (2 * F_STAGE)       // two stages = 128 KB
+#define F_MAGIC_I 0x4B400000
+#define F_MAGIC_F 12582912.0f
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ uint32_t f_swz(uint32_t row, uint32_t chunk) {
+  return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4);
+}
+
+#define F_FENCE()                             \
+  {                                           \
+    __builtin_amdgcn_sched_barrier(0);        \
+    asm volatile("" ::: "memory");            \
+  }
+#define F_BARRIER()                           \
+  {                                           \
+    F_FENCE()                                 \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);        \
+  }
+
+template <int ODT, int EPI, bool HAS_BIAS>
+__global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
+    const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
+    const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
+    int64_t M, int64_t N, int64_t K, int64_t ldd, int tiles_m, int tiles_n, int group_m) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- tile assignment: XCD remap, then m-grouped raster ----
+  const uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_group = group_m * tiles_n;
+  const int gid = vid / per_group;
+  const int first_m = gid * group_m;
+  const int gsz = min(group_m, tiles_m - first_m);
+  const int in_g = vid % per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int64_t m0 = (int64_t)tm * F_BM, n0 = (int64_t)tn * F_BN;
+  const int nk = (int)(K / 128);
+
+  // ---- LDS-DMA pieces: wave w moves chunks c = w + 8t (8 rows x 128 B) of both operand tiles ----
+  uint32_t ga[4], gb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = wave + 8 * t;
+    const int row = 8 * c + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (LDS image is lane-linear)
+    int64_t am = m0 + row; if (am > M - 1) am = M - 1;   // tail rows: clamp (never stored)
+    int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
+    ga[t] = (uint32_t)(am * K + chunk * 16);
+    gb[t] = (uint32_t)(bn * K + chunk * 16);
+  }
+  const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(uint32_t)(M * K), 0x00020000);
+  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(uint32_t)(N * K), 0x00020000);
+  // piece p of stage kb_ into buffer (kb_ & 1): p = 0..3 activation chunks, 4..7 weight chunks
+#define F_PIECE(kb_, p_)                                                                          \
+  {                                                                                               \
+    char* sb_ = smem + ((kb_) & 1) * F_STAGE + wave * 1024;                                       \
+    if ((p_) < 4)                                                                                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(sb_ + ((p_) & 3) * 8192), 16,     \
+                                               ga[(p_) & 3], (kb_) * 128, 0, 0);                  \
+    else                                                                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lptr_t)(sb_ + F_TILE + ((p_) & 3) * 8192), \
+                                               16, gb[(p_) & 3], (kb_) * 128, 0, 0);              \
+  }
+
+  // ---- fragment read offsets (within a stage); weight rows use the bit-2/3-swapped order ----
+  const int pr = (l16 & 3) | ((l16 & 4) << 1) | ((l16 & 8) >> 1);
+  uint32_t xoff[2], woff[2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    xoff[kc] = f_swz(wm * 128 + l16, 4 * kc + lq);
+    woff[kc] = F_TILE + f_swz(wn * 64 + pr, 4 * kc + lq);
+  }
+
+  v4f accf[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) accf[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+  // scale rows of this wave's 128x64 sub-tile (clamped for tail tiles)
+  int64_t mb = (m0 + wm * 128) >> 7, nb = (n0 + wn * 64) >> 7;
+  const int64_t mb_max = td_cdiv(M, 128) - 1, nb_max = td_cdiv(N, 128) - 1;
+  if (mb > mb_max) mb = mb_max;
+  if (nb > nb_max) nb = nb_max;
+  const float* as_row = AS + mb * nk;
+  const float* bs_row = BS + nb * nk;
+
+  v4i magic = {F_MAGIC_I, F_MAGIC_I, F_MAGIC_I, F_MAGIC_I};
+  asm volatile("" : "+v"(magic));  // opaque: keep it in 4 VGPRs, never re-materialised inside the loop
+  v4i wf[4][2], xf[2][2], t[2][4];
+  // ring slot 1 plays "group -1": 1.5*2^23 + 0 -> its dequant adds 0 * 0 to the (zero) accumulators
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[1][j] = magic;
+
+#define F_LOAD_X(st_, i_, slot_)                                                                  \
+  _Pragma("unroll") for (int kc = 0; kc < 2; ++kc)                                                \
+    xf[slot_][kc] = *reinterpret_cast<const v4i*>((st_) + xoff[kc] + (i_) * 2048);
+#define F_LOAD_W(st_, kc_)                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+    wf[j][kc_] = *reinterpret_cast<const v4i*>((st_) + woff[kc_] + j * 2048);
+  // first MFMA of a sub-tile's chain: C = magic (dst may not overlap the sources)
+#define F_MFMA0(d_, a_, b_)                                                                       \
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %3" : "=&v"(d_) : "v"(a_), "v"(b_), "v"(magic));
+#define F_MFMA1(d_, a_, b_)                                                                       \
+  asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(d_) : "v"(a_), "v"(b_));
+#define F_ADD4(v_)                                                                                \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
+    asm volatile("v_add_f32 %0, %1, %0" : "+v"((v_)[r]) : "s"(-F_MAGIC_F));
+#define F_FMAC4(acc_, v_, sc_)                                                                    \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
+    asm volatile("v_fmac_f32 %0, %1, %2" : "+v"((acc_)[r]) : "s"(sc_), "v"((v_)[r]));
+
+  // ---- prologue: stage 0 and stage 1 in flight; wait for stage 0; fragments of group (0,0) ----
+#pragma unroll
+  for (int p = 0; p < 8; ++p) F_PIECE(0, p)
+  if (nk > 1) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) F_PIECE(1, p)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  F_BARRIER()
+  F_LOAD_W(smem, 0)
+  F_LOAD_W(smem, 1)
+  F_LOAD_X(smem, 0, 0)
+
+  // block scales live in SGPRs: sc_old = K block of the group being dequantised at i == 0 (the previous
+  // block's last group), sc_new = this block's.  (sa*sb) formed first, kernel.hpp:418.
+  float sc_old = 0.f;
+  float sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, as_row[0] * bs_row[0])));
+
+  for (int kb = 0; kb < nk; ++kb) {
+    const char* st = smem + (kb & 1) * F_STAGE;
+    const char* stn = smem + ((kb + 1) & 1) * F_STAGE;
+    const bool more = kb + 1 < nk;
+    const bool dma_tail = (kb >= 1) && more;   // rest of stage kb+1 (stage 1 was issued by the prologue)
+    const bool dma_head = kb + 2 < nk;         // first pieces of stage kb+2, after this block's barrier
+    float sa_n = 0.f, sb_n = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int cur = i & 1, prv = cur ^ 1;
+      const int pi = (i + 7) & 7;  // m sub-tile of the group being dequantised
+      const float scl = (i == 0) ? sc_old : sc_new;
+      // -- fragment prefetch for the next group into the other ring slot (its last readers, the MFMAs of
+      //    the previous group, have all been issued)
+      if (i < 7) { F_LOAD_X(st, i + 1, prv) }
+      else if (more) { F_LOAD_X(stn, 0, prv) }
+      F_FENCE()
+      // -- slots 0-3
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        F_MFMA0(t[cur][j], wf[j][0], xf[cur][0])
+        F_ADD4(t[prv][j])
+      }
+      F_FENCE()
+      if (i == 7 && more) { F_LOAD_W(stn, 0) }
+      // -- LDS-DMA issue (VMEM issue slots of this wave only)
+      if (i == 7) { if (dma_head) { F_PIECE(kb + 2, 0) F_PIECE(kb + 2, 4) } }
+      else if (i == 0) { if (dma_tail) { F_PIECE(kb + 1, 1) F_PIECE(kb + 1, 5) } }
+      else if (i == 1) { if (dma_tail) { F_PIECE(kb + 1, 2) } }
+      else if (i == 2) { if (dma_tail) { F_PIECE(kb + 1, 6) } }
+      else if (i == 3) { if (dma_tail) { F_PIECE(kb + 1, 3) } }
+      else if (i == 4) { if (dma_tail) { F_PIECE(kb + 1, 7) } }
+      else if (i == 5) { if (more) { sa_n = as_row[kb + 1]; sb_n = bs_row[kb + 1]; } }  // scalar loads
+      F_FENCE()
+      // -- slots 4-7
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        F_MFMA1(t[cur][j], wf[j][1], xf[cur][1])
+        F_FMAC4(accf[pi][j], t[prv][j], scl)
+      }
+      F_FENCE()
+      if (i == 7 && more) { F_LOAD_W(stn, 1) }
+      if (i == 6) {
+        // every LDS read of stage kb has returned (group 7's fragment was read at the top of this group),
+        // this wave's pieces of stage kb+1 have landed; after the barrier: everyone's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        F_BARRIER()
+      }
+    }
+    sc_old = sc_new;
+    sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sa_n * sb_n)));
+  }
+  // ---- drain: dequant of the last group (nk-1, 7); its MFMAs were issued >= 4 slots ago, the last one
+  //      just now: give the matrix pipe its 4 passes before the VALU reads ----
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { F_ADD4(t[1][j]) }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { F_FMAC4(accf[7][j], t[1][j], sc_old) }
+
+  // ---- epilogue ----
+  // lane owns m = ..+l16; accumulator (i,j) holds n_local = 16j + r + 8(lq&1) + 4(lq>>1).
+  // After the swap lanes with lq<2 store 8 consecutive n of sub-tile ja, lanes with lq>=2 of jb.
+  const int hi = lq >> 1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t m = m0 + wm * 128 + i * 16 + l16;
+    uint32_t pk[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int64_t n = n0 + wn * 64 + j * 16 + 8 * (lq & 1) + 4 * hi;
+      float bf[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (HAS_BIAS) {
+        if (n > N - 4) n = N - 4;  // tail: clamp the read, the value is never stored
+        const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
+        unpack2<ODT>(bb.x, bf[0], bf[1]);
+        unpack2<ODT>(bb.y, bf[2], bf[3]);
+      }
+      pk[j][0] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][0], accf[i][j][1], bf[0], bf[1]);
+      pk[j][1] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][2], accf[i][j][3], bf[2], bf[3]);
+    }
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const int ja = 2 * jp, jb = 2 * jp + 1;
+      auto s0 = __builtin_amdgcn_permlane32_swap(pk[ja][0], pk[jb][0], false, false);
+      auto s1 = __builtin_amdgcn_permlane32_swap(pk[ja][1], pk[jb][1], false, false);
+      const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      const int jt = hi ? jb : ja;
+      const int64_t n = n0 + wn * 64 + jt * 16 + 8 * (lq & 1);
+      if (m < M && n < N) *reinterpret_cast<uint4*>(D + m * ldd + n) = v;
+    }
+  }
+}
+
+template <int ODT, int EPI, bool HAS_BIAS>
+static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                          const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
+                          hipStream_t st) {
+  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+    attr_set = true;
+  }
+  const int tiles_m = (int)td_cdiv(m, F_BM), tiles_n = (int)td_cdiv(n, F_BN);
+  const int group_m = 4;
+  const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;
+  kern<<<nwg, 512, F_LDS, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldd,
+                                tiles_m, tiles_n, group_m);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// called by td_gemm_w8a8 (gemm_w8a8.hip) after argument validation; needs ldd % 8 == 0
+int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                    const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
+                    int64_t k, int64_t ldd, hipStream_t st) {
+#define TD_GEMM_CASE(ODT)                                                                              \
+  if (epilogue == TD_EPI_GELU_TANH) {                                                                  \
+    return bias ? launch_gemm_fi<ODT, TD_EPI_GELU_TANH, true>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st)  \
+                : launch_gemm_fi<ODT, TD_EPI_GELU_TANH, false>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st); \
+  } else {                                                                                             \
+    return bias ? launch_gemm_fi<ODT, TD_EPI_NONE, true>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st)    \
+                : launch_gemm_fi<ODT, TD_EPI_NONE, false>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);  \
+  }
+  if (out_dtype == TD_BF16) { TD_GEMM_CASE(TD_BF16) } else { TD_GEMM_CASE(TD_F16) }
+#undef TD_GEMM_CASE
+}

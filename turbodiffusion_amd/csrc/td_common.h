@@ -41,6 +41,9 @@ int td_tuning(int key);
 int td_gemm_w8a8_pp(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                     const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
                     int64_t k, int64_t ldd, hipStream_t st);
+int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                    const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
+                    int64_t k, int64_t ldd, hipStream_t st);
 int td_gemm_w8a8_256(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                      const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
                      int64_t k, int64_t ldd, hipStream_t st);

@@ -1,0 +1,62 @@
+"""hipGraph capture of one DiT forward ("a hipGraph-captured step").
+
+A Wan-DiT step on the MI355X is ~1250 kernel launches of 5-1000 us each; enqueued one by one through
+ctypes the host falls behind the GPU on the short ones.  ``GraphedModel`` wraps a ``WanModel`` (same call
+surface), captures the whole forward into a HIP graph the first time a given input signature is seen
+(after one eager warm-up call, which also runs every one-time ``hipFuncSetAttribute`` and builds the
+RoPE / fused-weight caches) and afterwards replays it: inputs are copied into the graph's static
+buffers, the output is the graph's static output tensor (cloned, so the caller owns it).
+
+The captured work is exactly the eager work: every C-ABI entry point launches on torch's *current*
+stream, which during capture is the capturing stream; outputs are allocated from the graph's private pool.
+Not used with sequence parallelism (the RCCL all-gathers stay eager).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+class GraphedModel(torch.nn.Module):
+    def __init__(self, net: torch.nn.Module):
+        super().__init__()
+        self.net = net
+        self._graphs = {}
+
+    def _key(self, x, t, ctx, y):
+        return (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype,
+                None if y is None else (tuple(y.shape), y.dtype))
+
+    @torch.no_grad()
+    def forward(self, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, frame_cond_crossattn_emb_B_L_D=None,
+                y_B_C_T_H_W: Optional[torch.Tensor] = None, **kwargs):
+        if frame_cond_crossattn_emb_B_L_D is not None or getattr(self.net, "seq_parallel", None) is not None:
+            return self.net(x_B_C_T_H_W, timesteps_B_T, crossattn_emb,
+                            frame_cond_crossattn_emb_B_L_D=frame_cond_crossattn_emb_B_L_D,
+                            y_B_C_T_H_W=y_B_C_T_H_W, **kwargs)
+        key = self._key(x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W)
+        ent = self._graphs.get(key)
+        if ent is None:
+            sx, st, sc = x_B_C_T_H_W.clone(), timesteps_B_T.clone(), crossattn_emb.clone()
+            sy = None if y_B_C_T_H_W is None else y_B_C_T_H_W.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # eager warm-up on the side stream (lazy one-time work happens here)
+                self.net(sx, st, sc, y_B_C_T_H_W=sy)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                so = self.net(sx, st, sc, y_B_C_T_H_W=sy)
+            ent = (g, sx, st, sc, sy, so)
+            self._graphs[key] = ent
+        g, sx, st, sc, sy, so = ent
+        sx.copy_(x_B_C_T_H_W)
+        st.copy_(timesteps_B_T)
+        if sc.data_ptr() != crossattn_emb.data_ptr():
+            sc.copy_(crossattn_emb)
+        if sy is not None:
+            sy.copy_(y_B_C_T_H_W)
+        g.replay()
+        return so.clone()

@@ -95,7 +95,7 @@ def sinusoidal_embedding_1d(dim, position):
     """wan2pt1.py:144-153 (fp64)."""
     half = dim // 2
     position = position.type(torch.float64)
-    sinusoid = torch.outer(position, torch.pow(10000, -torch.arange(half).to(position).div(half)))
+    sinusoid = torch.outer(position, torch.pow(10000, -torch.arange(half, device=position.device).to(position).div(half)))
     return torch.cat([torch.cos(sinusoid), torch.sin(sinusoid)], dim=1)
 
 
