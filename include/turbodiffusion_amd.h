@@ -59,6 +59,9 @@ const char* td_last_error(void);
  * operator is bit-identical).  value 0 = automatic. */
 #define TD_TUNE_GEMM_VARIANT 0 /* 1 = 128x128-tile kernel, 2 = 256x256-tile LDS-DMA kernel, 3 = 256x256 ping-pong, 4 = 256x256 fine-interleaved */
 #define TD_TUNE_GEMM_ABLATE 1  /* profiling only, WRONG results: 1 no dequant, 2 no MFMA, 3 no LDS-DMA */
+#define TD_TUNE_GEMM_LDPAD 2   /* profiling only: int8 operand row stride = k + value (buffers must be that large) */
+#define TD_TUNE_GEMM_GROUP_M 3 /* m-tiles per raster group of the 256x256 kernels (0 = default 4) */
+#define TD_TUNE_GEMM_SCHED 4   /* v4 only: 1 = issue the LDS-DMA of the next stage right after the barrier */
 #define TD_TUNE_COUNT 8
 int td_set_tuning(int key, int value);
 /* profiling: copy the n (<= 256) 64-bit s_memtime stamps of the last TD_TUNE_GEMM_ABLATE == 9 launch to host */
@@ -82,6 +85,14 @@ int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, const float
                  const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
                  int64_t k, int64_t ldd, td_stream_t stream);
 
+/* ---- a15 -> a16 fused: the same GEMM whose epilogue block-quantises its own (16-bit rounded) result for the next
+ * Int8Linear: d_q int8 [m,n], d_s f32 [ceil(m/128), ceil(n/128)] == td_quant_i8_block128(td_gemm_w8a8(...)) bit for
+ * bit (Int8Linear.forward -> int8_quant of the next Int8Linear, ops/core.py:408-412,12-25; the FFN pair
+ * wan2pt1.py:375).  act_dtype = the 16-bit dtype the intermediate is rounded to.  Requires k % 128 == 0, n % 16 == 0. */
+int td_gemm_w8a8_quant(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                       const void* bias, int8_t* d_q, float* d_s, int act_dtype, int epilogue,
+                       int64_t m, int64_t n, int64_t k, td_stream_t stream);
+
 /* ---- a5: RMSNorm over the last dim (ops/core.py:139-191; rms_norm_cuda) ----
  * y = cast((x*rsqrt(mean(x^2)+eps))*w), fp32 math. x [m,n] in_dtype (f32|bf16|f16),
  * w [n] f32, y [m,n] out_dtype. Requires n % 8 == 0, n <= 8192. */
@@ -96,6 +107,13 @@ int td_rmsnorm(const void* x, int in_dtype, const float* w, void* y, int out_dty
 int td_layernorm(const void* x, int in_dtype, const float* w, const float* b, const float* scale,
                  const float* shift, int64_t rows_per_batch, void* y, int out_dtype, float eps,
                  int64_t m, int64_t n, td_stream_t stream);
+
+/* ---- a6 + a7 -> a16 fused: LayerNorm (+ affine, + AdaLN modulate) whose 16-bit result is block-quantised for the
+ * Int8Linear that consumes it: q int8 [m,n], qs f32 [ceil(m/128), ceil(n/128)] == td_quant_i8_block128(td_layernorm(...))
+ * bit for bit (x, and the intermediate, in `dtype` = f16|bf16).  Requires n % 8 == 0 and n <= 1536. */
+int td_layernorm_quant(const void* x, int dtype, const float* w, const float* b, const float* scale,
+                       const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float eps,
+                       int64_t m, int64_t n, td_stream_t stream);
 
 /* ---- a7: gated residual  x = x + y*gate.type_as(x)  (wan2pt1.py:405-406,412-413) ----
  * x,y [m,n] f16|bf16 (in place on x), gate f32 [batch,n] or NULL (plain x += y, :410).

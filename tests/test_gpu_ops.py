@@ -89,6 +89,24 @@ def test_gemm_variants_bit_identical(K, m, n, k, bias, gelu):
         assert ulp_diff_bf16(outs[1], ref).max().item() <= 1
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 1536, 384), (3000, 8960, 256), (300, 272, 256), (1111, 1552, 1280),
+                                   (77, 128, 128)])
+@pytest.mark.parametrize("bias,gelu", [(True, True), (False, False), (True, False)])
+def test_gemm_fused_output_quant_bit_exact(K, m, n, k, bias, gelu):
+    """td_gemm_w8a8_quant == td_quant_i8_block128(td_gemm_w8a8(...)): codes and scales bit for bit, incl. ragged
+    M / N tails (zero-filled like the stand-alone quantiser) and realistic value ranges."""
+    x = act_like(m, k, torch.bfloat16, seed=m + n + k)
+    w = (torch.randn(n, k, generator=torch.Generator().manual_seed(k)) / k ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(n, generator=torch.Generator().manual_seed(3)) * 0.1).to(torch.bfloat16).to(DEV) if bias else None
+    xq, xs = K.quant_i8_block128(x.to(DEV))
+    wq, ws = K.quant_i8_block128(w.to(DEV))
+    y = K.gemm_w8a8(xq, xs, wq, ws, torch.bfloat16, bias=b, gelu_tanh=gelu)
+    q_ref, s_ref = K.quant_i8_block128(y)
+    q, s = K.gemm_w8a8_quant(xq, xs, wq, ws, torch.bfloat16, bias=b, gelu_tanh=gelu)
+    assert torch.equal(s, s_ref), "scales"
+    assert torch.equal(q, q_ref), f"codes differ at {(q != q_ref).sum().item()} positions"
+
+
 def test_gemm_rejects_bad_k(K):
     from turbodiffusion_amd._lib import TurboDiffusionAMDError
     a = torch.zeros(128, 192, dtype=torch.int8, device=DEV)
@@ -130,6 +148,26 @@ def test_layernorm_modulate(K, m, n, affine, mod):
     # modulate amplifies a 1-ulp difference of the rounded norm output by (1+scale): allow 2 there
     assert ulp.max().item() <= (2 if mod else 1), f"max ulp {ulp.max().item()}"
     assert (ulp > 0).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("m,n", [(7, 1536), (300, 256), (1000, 1536), (129, 1024), (256, 520), (4096, 1536)])
+@pytest.mark.parametrize("affine,mod", [(False, True), (True, False), (False, False), (True, True)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_layernorm_quant_bit_exact(K, m, n, affine, mod, dtype):
+    """td_layernorm_quant == td_quant_i8_block128(td_layernorm(...)): INT8 codes and fp32 scales bit for bit
+    (ragged row tails, two batch entries with different AdaLN vectors, outlier channels)."""
+    x = act_like(m, n, dtype, seed=m + n).to(DEV)
+    g = torch.Generator().manual_seed(n)
+    w = (1 + 0.1 * torch.randn(n, generator=g)).to(DEV) if affine else None
+    b = (0.05 * torch.randn(n, generator=g)).to(DEV) if affine else None
+    nb = 2 if (mod and m % 2 == 0) else 1
+    sc = (0.2 * torch.randn(nb, n, generator=g)).to(DEV) if mod else None
+    sh = (0.2 * torch.randn(nb, n, generator=g)).to(DEV) if mod else None
+    y = K.layernorm(x, w, b, 1e-6, sc, sh, rows_per_batch=m // nb if mod else 0)
+    q_ref, s_ref = K.quant_i8_block128(y)
+    q, s = K.layernorm_quant(x, w, b, 1e-6, sc, sh, rows_per_batch=m // nb if mod else 0)
+    assert torch.equal(s, s_ref), "scales"
+    assert torch.equal(q, q_ref), f"codes differ at {(q != q_ref).sum().item()} positions"
 
 
 def test_gated_residual_bit_exact(K):

@@ -22,3 +22,19 @@ extern "C" int td_set_tuning(int key, int value) {
   g_tuning[key] = value;
   return TD_OK;
 }
+
+// profiling aid shared by the GEMM kernels' DBG instantiations: 256 x 64-bit s_memtime stamps in device memory
+static unsigned long long* g_dbg_buf = nullptr;
+unsigned long long* td_dbg_buffer(void) {
+  if (!g_dbg_buf) {
+    if (hipMalloc(&g_dbg_buf, 256 * 8) != hipSuccess) return nullptr;
+    (void)hipMemset(g_dbg_buf, 0, 256 * 8);
+  }
+  return g_dbg_buf;
+}
+extern "C" int td_debug_read(unsigned long long* host_dst, int n) {
+  if (n > 256) n = 256;
+  unsigned long long* b = td_dbg_buffer();
+  if (!b || n < 0) return TD_ERR_LAUNCH;
+  return hipMemcpy(host_dst, b, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
+}

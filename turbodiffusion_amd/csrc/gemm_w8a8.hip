@@ -205,11 +205,12 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
   hipStream_t st = (hipStream_t)stream;
   // large problems: 256x256 LDS-DMA kernel (gemm_w8a8_256.hip), bit-identical results
   const int variant = td_tuning(TD_TUNE_GEMM_VARIANT);
-  if (variant == 4) {
+  // large problems: the fine-interleaved 256x256 LDS-DMA kernel (gemm_w8a8_fi.hip); every variant is bit-identical
+  if (variant == 4 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0)) {
     TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 4 needs ldd %% 8 == 0");
     return td_gemm_w8a8_fi(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
   }
-  if (variant == 3 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0)) {
+  if (variant == 3) {
     TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 3 needs ldd %% 8 == 0");
     return td_gemm_w8a8_pp(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
   }
@@ -225,4 +226,20 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
   }
   if (out_dtype == TD_BF16) { TD_GEMM_CASE(TD_BF16) } else { TD_GEMM_CASE(TD_F16) }
 #undef TD_GEMM_CASE
+}
+
+extern "C" int td_gemm_w8a8_quant(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                                  const void* bias, int8_t* d_q, float* d_s, int act_dtype, int epilogue,
+                                  int64_t m, int64_t n, int64_t k, td_stream_t stream) {
+  TD_REQUIRE(a && a_s && b && b_s && d_q && d_s, TD_ERR_INVALID, "td_gemm_w8a8_quant: null pointer");
+  TD_REQUIRE(m >= 0 && n >= 0 && k >= 0, TD_ERR_INVALID, "td_gemm_w8a8_quant: negative size");
+  TD_REQUIRE(act_dtype == TD_F16 || act_dtype == TD_BF16, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8_quant: intermediate dtype %d (need f16|bf16)", act_dtype);
+  TD_REQUIRE(k % 128 == 0 && k > 0, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8_quant: k=%lld must be a positive multiple of 128", (long long)k);
+  TD_REQUIRE(n % 16 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_quant: n=%lld must be a multiple of 16", (long long)n);
+  TD_REQUIRE(epilogue == TD_EPI_NONE || epilogue == TD_EPI_GELU_TANH, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8_quant: epilogue %d", epilogue);
+  if (m == 0 || n == 0) return TD_OK;
+  return td_gemm_w8a8_fi_q(a, a_s, b, b_s, bias, d_q, d_s, act_dtype, epilogue, m, n, k, (hipStream_t)stream);
 }

@@ -43,6 +43,7 @@
 #define F_TILE (256 * 128)        // one operand tile per K block, bytes
 #define F_STAGE (2 * F_TILE)      // activations + weights
 #define F_LDS (2 * F_STAGE)       // two stages = 128 KB
+#define F_DUMP 2048               // landing area of the L2-prefetch dwords
 #define F_MAGIC_I 0x4B400000
 #define F_MAGIC_F 12582912.0f
 
@@ -65,17 +66,31 @@ __device__ __forceinline__ uint32_t f_swz(uint32_t row, uint32_t chunk) {
     __builtin_amdgcn_sched_barrier(0);        \
   }
 
-template <int ODT, int EPI, bool HAS_BIAS>
+// DBG = 1: profiling instantiation, records s_memtime at every group boundary of K blocks 8 and 9 for waves 0
+// and 4 of workgroup 0 (read back with td_debug_read; tools/gemm_trace.py)
+// SCHED bit 0: issue all 8 LDS-DMA pieces of stage kb+2 in groups 7 and 0 (right after the barrier) instead of
+// spreading them over groups 7,0..4
+// QOUT: the epilogue block-quantises the (bias/GELU'd, 16-bit-rounded) result for the NEXT W8A8 GEMM instead of
+// storing it: D is int8 [M, ldd], QS the fp32 scales [ceil(M/128), ldqs] — bit-identical to td_gemm_w8a8 followed by
+// td_quant_i8_block128 (quant.hip), minus one 2-byte write, one 2-byte read and a launch.
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
-    int64_t M, int64_t N, int64_t K, int64_t ldd, int tiles_m, int tiles_n, int group_m) {
+    int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int tiles_m, int tiles_n, int group_m,
+    unsigned long long* __restrict__ dbg, float* __restrict__ QS, int64_t ldqs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
   const int wm = wave >> 2, wn = wave & 3;
+  unsigned long long dbg_t[40];
+  int dbg_n = 0;
+#define F_STAMP()                                                                             \
+  if constexpr (DBG) {                                                                        \
+    if ((kb == 8 || kb == 9) && dbg_n < 40) dbg_t[dbg_n++] = __builtin_amdgcn_s_memtime();    \
+  }
 
   // ---- tile assignment: XCD remap, then m-grouped raster ----
   const uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
@@ -98,11 +113,30 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (LDS image is lane-linear)
     int64_t am = m0 + row; if (am > M - 1) am = M - 1;   // tail rows: clamp (never stored)
     int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
-    ga[t] = (uint32_t)(am * K + chunk * 16);
-    gb[t] = (uint32_t)(bn * K + chunk * 16);
+    ga[t] = (uint32_t)(am * lda + chunk * 16);
+    gb[t] = (uint32_t)(bn * ldb + chunk * 16);
   }
-  const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(uint32_t)(M * K), 0x00020000);
-  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(uint32_t)(N * K), 0x00020000);
+  const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(uint32_t)(M * lda), 0x00020000);
+  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(uint32_t)(N * ldb), 0x00020000);
+  // L2 prefetch (SCHED bit 1): one buffer_load_dword per wave touches 64 cache lines (one 128-B line per lane) of a
+  // stage several K blocks ahead, so that the LDS-DMA of that stage later hits in L2 instead of waiting on HBM.
+  // waves 0-3: activation rows 64*(wave&3)+lane, waves 4-7: weight rows.  The loaded dword is never used.
+  uint32_t pf_off;
+  {
+    const int row = 64 * (wave & 3) + lane;
+    int64_t am = m0 + row; if (am > M - 1) am = M - 1;
+    int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
+    pf_off = wave < 4 ? (uint32_t)(am * lda) : (uint32_t)(bn * ldb);
+  }
+  // (LDS-DMA form with a 4-byte element: no destination VGPR; the dwords land in a 2 KB dump area behind the stages)
+#define F_PREFETCH(kb_)                                                                           \
+  if constexpr ((SCHED & 2) != 0) {                                                               \
+    char* dump_ = smem + F_LDS + wave * 256;                                                      \
+    if (wave < 4)                                                                                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)dump_, 4, pf_off, (kb_) * 128, 0, 0); \
+    else                                                                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lptr_t)dump_, 4, pf_off, (kb_) * 128, 0, 0); \
+  }
   // piece p of stage kb_ into buffer (kb_ & 1): p = 0..3 activation chunks, 4..7 weight chunks
 #define F_PIECE(kb_, p_)                                                                          \
   {                                                                                               \
@@ -173,6 +207,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  F_PREFETCH(2)
+  F_PREFETCH(3)
   F_BARRIER()
   F_LOAD_W(smem, 0)
   F_LOAD_W(smem, 1)
@@ -195,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       const int cur = i & 1, prv = cur ^ 1;
       const int pi = (i + 7) & 7;  // m sub-tile of the group being dequantised
       const float scl = (i == 0) ? sc_old : sc_new;
+      F_STAMP()
       // -- fragment prefetch for the next group into the other ring slot (its last readers, the MFMAs of
       //    the previous group, have all been issued)
       if (i < 7) { F_LOAD_X(st, i + 1, prv) }
@@ -209,14 +246,21 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       F_FENCE()
       if (i == 7 && more) { F_LOAD_W(stn, 0) }
       // -- LDS-DMA issue (VMEM issue slots of this wave only)
-      if (i == 7) { if (dma_head) { F_PIECE(kb + 2, 0) F_PIECE(kb + 2, 4) } }
-      else if (i == 0) { if (dma_tail) { F_PIECE(kb + 1, 1) F_PIECE(kb + 1, 5) } }
-      else if (i == 1) { if (dma_tail) { F_PIECE(kb + 1, 2) } }
-      else if (i == 2) { if (dma_tail) { F_PIECE(kb + 1, 6) } }
-      else if (i == 3) { if (dma_tail) { F_PIECE(kb + 1, 3) } }
-      else if (i == 4) { if (dma_tail) { F_PIECE(kb + 1, 7) } }
-      else if (i == 5) { if (more) { sa_n = as_row[kb + 1]; sb_n = bs_row[kb + 1]; } }  // scalar loads
+      if (i == 7) { F_PREFETCH(kb + 4) }
+      if constexpr (SCHED & 1) {
+        if (i == 7) { if (dma_head) { F_PIECE(kb + 2, 0) F_PIECE(kb + 2, 4) F_PIECE(kb + 2, 1) F_PIECE(kb + 2, 5) } }
+        else if (i == 0) { if (dma_tail) { F_PIECE(kb + 1, 2) F_PIECE(kb + 1, 6) F_PIECE(kb + 1, 3) F_PIECE(kb + 1, 7) } }
+      } else {
+        if (i == 7) { if (dma_head) { F_PIECE(kb + 2, 0) F_PIECE(kb + 2, 4) } }
+        else if (i == 0) { if (dma_tail) { F_PIECE(kb + 1, 1) F_PIECE(kb + 1, 5) } }
+        else if (i == 1) { if (dma_tail) { F_PIECE(kb + 1, 2) } }
+        else if (i == 2) { if (dma_tail) { F_PIECE(kb + 1, 6) } }
+        else if (i == 3) { if (dma_tail) { F_PIECE(kb + 1, 3) } }
+        else if (i == 4) { if (dma_tail) { F_PIECE(kb + 1, 7) } }
+      }
+      if (i == 5) { if (more) { sa_n = as_row[kb + 1]; sb_n = bs_row[kb + 1]; } }  // scalar loads
       F_FENCE()
+      F_STAMP()
       // -- slots 4-7
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -235,6 +279,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     sc_old = sc_new;
     sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sa_n * sb_n)));
   }
+  if constexpr (DBG) {
+    if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
+      for (int q = 0; q < 40; ++q) dbg[(wave >> 2) * 64 + q] = q < dbg_n ? dbg_t[q] : 0ull;
+  }
   // ---- drain: dequant of the last group (nk-1, 7); its MFMAs were issued >= 4 slots ago, the last one
   //      just now: give the matrix pipe its 4 passes before the VALU reads ----
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
@@ -247,6 +295,96 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // lane owns m = ..+l16; accumulator (i,j) holds n_local = 16j + r + 8(lq&1) + 4(lq>>1).
   // After the swap lanes with lq<2 store 8 consecutive n of sub-tile ja, lanes with lq>=2 of jb.
   const int hi = lq >> 1;
+  if constexpr (QOUT) {
+    // (1) the 16-bit results exactly as the plain epilogue would store them, kept in 64 VGPRs
+    uint32_t pk[8][4][2];
+    const bool tail = (m0 + F_BM > M) || (n0 + F_BN > N);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool m_ok = (m0 + wm * 128 + i * 16 + l16) < M;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t n = n0 + wn * 64 + j * 16 + 8 * (lq & 1) + 4 * hi;
+        const bool ok = m_ok && n < N;
+        float bf[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (HAS_BIAS) {
+          if (n > N - 4) n = N - 4;
+          const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
+          unpack2<ODT>(bb.x, bf[0], bf[1]);
+          unpack2<ODT>(bb.y, bf[2], bf[3]);
+        }
+        pk[i][j][0] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][0], accf[i][j][1], bf[0], bf[1]);
+        pk[i][j][1] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][2], accf[i][j][3], bf[2], bf[3]);
+        if (tail && !ok) { pk[i][j][0] = 0u; pk[i][j][1] = 0u; }  // rows/cols outside the matrix: zero-filled (load.hpp:24-47)
+      }
+    }
+    // (2) amax of this wave's 128x64 half of the 128x128 quant block: max over |x| as 15-bit magnitudes (both 16-bit
+    //     formats are monotone in their magnitude bits), two per v_pk_max_u16
+    uint32_t mx = 0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t a = pk[i][j][e] & 0x7fff7fffu;
+          asm("v_pk_max_u16 %0, %0, %1" : "+v"(mx) : "v"(a));
+        }
+    uint32_t m16 = max(mx & 0xffffu, mx >> 16);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m16 = max(m16, (uint32_t)__shfl_xor((int)m16, o, 64));
+    // (3) the other half belongs to wave ^ 1: exchange through LDS (free: every wave is past the last barrier
+    //     of the main loop, nothing reads or lands in the stages any more)
+    uint32_t* red = reinterpret_cast<uint32_t*>(smem);
+    if (lane == 0) red[wave] = m16;
+    __syncthreads();
+    m16 = max(red[wave], red[wave ^ 1]);
+    float amax = half_bits_to_f32<ODT>(m16);
+    amax = fmaxf(amax, 1e-8f);
+    const float mult = 128.0f / amax;  // IEEE division, as quant.hip
+    {
+      const int64_t mb_q = (m0 + wm * 128) >> 7, nb_q = (n0 + wn * 64) >> 7;
+      if (lane == 0 && (wn & 1) == 0 && (m0 + wm * 128) < M && (n0 + wn * 64) < N) QS[mb_q * ldqs + nb_q] = amax / 128.0f;
+    }
+    // (4) quantise: q = sat_s8(rne(x * mult)).  rne via the 1.5*2^23 add (exact for |v| < 2^22, same result as
+    //     rintf of the rounded product); its low byte IS the two's-complement code.  |x*mult| <= 128(1+eps), so only
+    //     +128 needs the clamp.  (5) two lane swaps gather 16 consecutive n per lane -> one 16-byte store per row.
+    int8_t* Dq = reinterpret_cast<int8_t*>(D);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t m = m0 + wm * 128 + i * 16 + l16;
+      uint32_t qd[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x[4];
+        unpack2<ODT>(pk[i][j][0], x[0], x[1]);
+        unpack2<ODT>(pk[i][j][1], x[2], x[3]);
+        uint32_t w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = x[r] * mult;
+          v = v + F_MAGIC_F;
+          v = fminf(v, F_MAGIC_F + 127.0f);
+          w[r] = __float_as_uint(v);
+        }
+        const uint32_t lo = __builtin_amdgcn_perm(w[1], w[0], 0x0c0c0400u);  // bytes: w0.b0, w1.b0, 0, 0
+        const uint32_t hh = __builtin_amdgcn_perm(w[3], w[2], 0x04000c0cu);  // bytes: 0, 0, w2.b0, w3.b0
+        qd[j] = lo | hh;
+      }
+      // permlane32: lower lanes get {own, partner} quads of tile ja, upper lanes of tile jb (8 consecutive n)
+      auto p0 = __builtin_amdgcn_permlane32_swap(qd[0], qd[1], false, false);
+      auto p1 = __builtin_amdgcn_permlane32_swap(qd[2], qd[3], false, false);
+      // permlane16: rows (16 lanes) 1,3 of the first operand <-> rows 0,2 of the second: 16 consecutive n per lane,
+      // of tile jt = ((lq & 1) << 1) | (lq >> 1)
+      auto e0 = __builtin_amdgcn_permlane16_swap(p0[0], p1[0], false, false);
+      auto e1 = __builtin_amdgcn_permlane16_swap(p0[1], p1[1], false, false);
+      const uint4 v = make_uint4(e0[0], e1[0], e0[1], e1[1]);
+      const int jt = ((lq & 1) << 1) | hi;
+      const int64_t n = n0 + wn * 64 + jt * 16;
+      if (m < M && n < N) *reinterpret_cast<uint4*>(Dq + m * ldd + n) = v;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t m = m0 + wm * 128 + i * 16 + l16;
@@ -277,22 +415,24 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS>
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false>
 static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
-                          hipStream_t st) {
-  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS>;
+                          hipStream_t st, float* qs = nullptr, int64_t ldqs = 0) {
+  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS + F_DUMP);
     attr_set = true;
   }
   const int tiles_m = (int)td_cdiv(m, F_BM), tiles_n = (int)td_cdiv(n, F_BN);
-  const int group_m = 4;
+  const int group_m = td_tuning(TD_TUNE_GEMM_GROUP_M) > 0 ? td_tuning(TD_TUNE_GEMM_GROUP_M) : 4;
   const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;
-  kern<<<nwg, 512, F_LDS, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldd,
-                                tiles_m, tiles_n, group_m);
+  // profiling only: row stride of both int8 operands = k + pad (the caller's buffers must be that large)
+  const int64_t ldab = k + td_tuning(TD_TUNE_GEMM_LDPAD);
+  kern<<<nwg, 512, F_LDS + F_DUMP, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldab, ldab, ldd,
+                                tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr, qs, ldqs);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
@@ -301,6 +441,20 @@ static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, co
 int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                     const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
                     int64_t k, int64_t ldd, hipStream_t st) {
+  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 9)  // s_memtime trace instantiation
+    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 8)  // s_memtime trace, early-DMA schedule
+    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 1, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+  if (epilogue == TD_EPI_NONE && bias && out_dtype == TD_BF16) {
+    switch (td_tuning(TD_TUNE_GEMM_SCHED)) {
+      case 1: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      case 2: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      case 3: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 3>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      default: break;
+    }
+  }
+  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 7)  // s_memtime trace, L2 prefetch
+    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 1, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
 #define TD_GEMM_CASE(ODT)                                                                              \
   if (epilogue == TD_EPI_GELU_TANH) {                                                                  \
     return bias ? launch_gemm_fi<ODT, TD_EPI_GELU_TANH, true>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st)  \
@@ -310,5 +464,22 @@ int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const fl
                 : launch_gemm_fi<ODT, TD_EPI_NONE, false>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);  \
   }
   if (out_dtype == TD_BF16) { TD_GEMM_CASE(TD_BF16) } else { TD_GEMM_CASE(TD_F16) }
+#undef TD_GEMM_CASE
+}
+
+// a15+a16 fused: d_q int8 [m, n] + d_s f32 [ceil(m/128), ceil(n/128)] = quant_block128(cast(gemm(...)+bias [gelu]))
+int td_gemm_w8a8_fi_q(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
+                      int8_t* d_q, float* d_s, int act_dtype, int epilogue, int64_t m, int64_t n, int64_t k,
+                      hipStream_t st) {
+  const int64_t ldqs = td_cdiv(n, 128);
+#define TD_GEMM_CASE(ODT)                                                                                   \
+  if (epilogue == TD_EPI_GELU_TANH) {                                                                       \
+    return bias ? launch_gemm_fi<ODT, TD_EPI_GELU_TANH, true, 0, 0, true>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs)  \
+                : launch_gemm_fi<ODT, TD_EPI_GELU_TANH, false, 0, 0, true>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs); \
+  } else {                                                                                                  \
+    return bias ? launch_gemm_fi<ODT, TD_EPI_NONE, true, 0, 0, true>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs)       \
+                : launch_gemm_fi<ODT, TD_EPI_NONE, false, 0, 0, true>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);     \
+  }
+  if (act_dtype == TD_BF16) { TD_GEMM_CASE(TD_BF16) } else { TD_GEMM_CASE(TD_F16) }
 #undef TD_GEMM_CASE
 }

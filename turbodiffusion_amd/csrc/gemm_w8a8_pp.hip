@@ -67,12 +67,12 @@ __device__ __forceinline__ uint32_t p_swz(uint32_t row, uint32_t chunk) {
 
 // DBG: profiling instantiation that records s_memtime at every segment boundary of K block 5 for waves
 // 0 and 4 of workgroup 0 into g_td_dbg (read back with td_debug_read)
-__device__ unsigned long long g_td_dbg[256];
 template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_pp_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
-    int64_t M, int64_t N, int64_t K, int64_t ldd, int tiles_m, int tiles_n, int group_m) {
+    int64_t M, int64_t N, int64_t K, int64_t ldd, int tiles_m, int tiles_n, int group_m,
+    unsigned long long* __restrict__ g_td_dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -307,7 +307,7 @@ static int launch_gemm_pp(const int8_t* a, const float* a_s, const int8_t* b, co
   const int group_m = 4;
   const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;
   kern<<<nwg, 512, P_LDS, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldd,
-                                tiles_m, tiles_n, group_m);
+                                tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
@@ -333,9 +333,4 @@ int td_gemm_w8a8_pp(const int8_t* a, const float* a_s, const int8_t* b, const fl
   }
   if (out_dtype == TD_BF16) { TD_GEMM_CASE(TD_BF16) } else { TD_GEMM_CASE(TD_F16) }
 #undef TD_GEMM_CASE
-}
-
-extern "C" int td_debug_read(unsigned long long* host_dst, int n) {
-  if (n > 256) n = 256;
-  return hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_td_dbg), (size_t)n * 8) == hipSuccess ? TD_OK : TD_ERR_LAUNCH;
 }

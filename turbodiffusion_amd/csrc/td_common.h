@@ -37,6 +37,7 @@ void td_set_error(const char* fmt, ...);
 
 // tuning knobs (td_set_tuning); 0 = automatic choice
 int td_tuning(int key);
+unsigned long long* td_dbg_buffer(void);  // 256 x u64 device scratch for the DBG kernel instantiations
 // internal kernel entry points shared between translation units
 int td_gemm_w8a8_pp(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                     const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
@@ -44,6 +45,9 @@ int td_gemm_w8a8_pp(const int8_t* a, const float* a_s, const int8_t* b, const fl
 int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                     const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
                     int64_t k, int64_t ldd, hipStream_t st);
+int td_gemm_w8a8_fi_q(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
+                      int8_t* d_q, float* d_s, int act_dtype, int epilogue, int64_t m, int64_t n, int64_t k,
+                      hipStream_t st);
 int td_gemm_w8a8_256(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                      const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
                      int64_t k, int64_t ldd, hipStream_t st);

@@ -98,6 +98,26 @@ def gemm_w8a8(a_q, a_s, b_q, b_s, out_dtype=torch.bfloat16, bias=None, gelu_tanh
     return out
 
 
+def gemm_w8a8_quant(a_q, a_s, b_q, b_s, act_dtype=torch.bfloat16, bias=None, gelu_tanh=False):
+    """W8A8 GEMM whose epilogue block-quantises its own result for the next Int8Linear:
+    == quant_i8_block128(gemm_w8a8(...)) bit for bit, without the 16-bit round trip through HBM."""
+    require_gpu(a_q, a_s, b_q, b_s, bias)
+    assert a_q.dtype == torch.int8 and b_q.dtype == torch.int8
+    assert a_q.is_contiguous() and b_q.is_contiguous() and a_s.is_contiguous() and b_s.is_contiguous()
+    m, k = a_q.shape
+    n, k2 = b_q.shape
+    assert k == k2, "gemm_w8a8_quant: K mismatch"
+    assert a_s.shape == (cdiv(m, 128), k // 128) and b_s.shape == (cdiv(n, 128), k // 128), "scale shapes"
+    if bias is not None:
+        assert bias.dtype == act_dtype and bias.shape == (n,) and bias.is_contiguous()
+    q = torch.empty((m, n), dtype=torch.int8, device=a_q.device)
+    s = torch.empty((cdiv(m, 128), cdiv(n, 128)), dtype=torch.float32, device=a_q.device)
+    _timed("td_gemm_w8a8", (m, n, k), lambda: call(
+        "td_gemm_w8a8_quant", ptr(a_q), ptr(a_s), ptr(b_q), ptr(b_s), ptr(bias), ptr(q), ptr(s), dt_code(act_dtype),
+        L.TD_EPI_GELU_TANH if gelu_tanh else L.TD_EPI_NONE, m, n, k, stream_ptr()))
+    return q, s
+
+
 # ----------------------------------------------------------------------------- a5 / a6 / a7
 def rmsnorm(x, w, eps, out_dtype=None):
     require_gpu(x, w)
@@ -132,6 +152,33 @@ def layernorm(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, out_dtype=
     call("td_layernorm", ptr(x2), dt_code(x.dtype), ptr(w), ptr(b), ptr(scale), ptr(shift), rows_per_batch,
          ptr(y), dt_code(out_dtype), float(eps), x2.shape[0], n, stream_ptr())
     return y.reshape(x.shape)
+
+
+LNQ_MAX_N = 1536  # td_layernorm_quant keeps a 128-row block on chip; wider rows use layernorm + quant_i8_block128
+
+
+def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0):
+    """LayerNorm (+ affine, + AdaLN modulate) fused with the per-128x128-block INT8 quantiser of the consuming
+    Int8Linear: returns (q int8 [m,n], s f32 [ceil(m/128), ceil(n/128)]) == quant_i8_block128(layernorm(...))."""
+    require_gpu(x, w, b, scale, shift)
+    assert x.is_contiguous() and x.dim() == 2, "Input must be a contiguous 2-D tensor"
+    m, n = x.shape
+    if n > LNQ_MAX_N or n % 8:
+        return quant_i8_block128(layernorm(x, w, b, eps, scale, shift, rows_per_batch))
+    if w is not None:
+        w = w.float().contiguous()
+        b = b.float().contiguous() if b is not None else torch.zeros_like(w)
+    if scale is not None:
+        scale = scale.float().contiguous().reshape(-1, n)
+        shift = shift.float().contiguous().reshape(-1, n)
+        if rows_per_batch == 0:
+            assert m % scale.shape[0] == 0
+            rows_per_batch = m // scale.shape[0]
+    q = torch.empty((m, n), dtype=torch.int8, device=x.device)
+    s = torch.empty((cdiv(m, 128), cdiv(n, 128)), dtype=torch.float32, device=x.device)
+    call("td_layernorm_quant", ptr(x), dt_code(x.dtype), ptr(w), ptr(b), ptr(scale), ptr(shift), rows_per_batch,
+         ptr(q), ptr(s), float(eps), m, n, stream_ptr())
+    return q, s
 
 
 def gated_residual_(x, y, gate=None):

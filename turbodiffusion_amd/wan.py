@@ -180,6 +180,22 @@ class WanModel(nn.Module):
         y = F.linear(x, mod.weight, mod.bias)
         return F.gelu(y, approximate="tanh") if gelu else y
 
+    def _lin_q(self, mod, xq, xs, dtype, gelu=False):
+        """Int8Linear on an already block-quantised activation."""
+        return K.gemm_w8a8(xq, xs, mod.int8_weight, mod.scale, dtype, bias=mod.bias, gelu_tanh=gelu)
+
+    def _ffn_q(self, lin1, lin2, xq, xs, dtype):
+        hq, hs = K.gemm_w8a8_quant(xq, xs, lin1.int8_weight, lin1.scale, dtype, bias=lin1.bias, gelu_tanh=True)
+        return K.gemm_w8a8(hq, hs, lin2.int8_weight, lin2.scale, dtype, bias=lin2.bias)
+
+    def _ffn(self, lin1, lin2, x):
+        """Linear -> GELU(tanh) -> Linear (wan2pt1.py:375).  W8A8: the first GEMM's epilogue also block-quantises its
+        output for the second (same bits as Int8Linear -> GELU -> int8_quant, without the [L, ffn] 16-bit round trip)."""
+        if isinstance(lin1, Int8Linear) and isinstance(lin2, Int8Linear):
+            xq, xs = K.quant_i8_block128(x)
+            return self._ffn_q(lin1, lin2, xq, xs, x.dtype)
+        return self._lin(lin2, self._lin(lin1, x, gelu=True))
+
     def _fused_weights(self, i, blk):
         """q|k|v of self-attention and k|v of cross-attention share their input: concatenate the
         weights (and block scales — 128-row aligned, so the concatenation keeps the block structure)
@@ -216,15 +232,19 @@ class WanModel(nn.Module):
         return F.linear(x, w, b)
 
     # ------------------------------------------------------------------ one transformer block
-    def _self_attention(self, i, blk, h, cos, sin, L_loc):
-        """h: [L_loc, dim] modulated input of this rank's tokens -> [L_loc, dim] attention output."""
+    def _self_attention(self, i, blk, h, cos, sin, L_loc, dtype):
+        """h: [L_loc, dim] modulated input of this rank's tokens (or its (int8, scales) pair when the norm
+        already quantised it) -> [L_loc, dim] attention output."""
         f = self._fused_weights(i, blk)
         sa = blk.self_attn
         H, D, dim = self.num_heads, 128, self.dim
-        qkv = self._fused_lin(h, f["qkv_w"], f.get("qkv_s"), f["qkv_b"])  # [L, 3*dim]
+        if isinstance(h, tuple):
+            qkv = K.gemm_w8a8(h[0], h[1], f["qkv_w"], f["qkv_s"], dtype, bias=f["qkv_b"])
+        else:
+            qkv = self._fused_lin(h, f["qkv_w"], f.get("qkv_s"), f["qkv_b"])  # [L, 3*dim]
         q = K.qk_norm_rope(qkv, 0, H, D, sa.norm_q.weight, cos, sin, self.eps)
         k = K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
-        out = torch.empty((L_loc, dim), dtype=h.dtype, device=h.device)
+        out = torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
         if self.seq_parallel is not None:
             return self.seq_parallel.self_attention(self, f, q, k, qkv, out)
         at = self.attention_type
@@ -240,14 +260,14 @@ class WanModel(nn.Module):
         f = self._fused_weights(i, blk)
         ca = blk.cross_attn
         H, D, dim = self.num_heads, 128, self.dim
-        L_ = xn.shape[0]
+        L_ = xn[0].shape[0] if isinstance(xn, tuple) else xn.shape[0]
         Lc = context.shape[0]
-        qc = self._lin(ca.q, xn)
+        qc = self._lin_q(ca.q, xn[0], xn[1], context.dtype) if isinstance(xn, tuple) else self._lin(ca.q, xn)
         q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
         kv = self._fused_lin(context, f["ckv_w"], f.get("ckv_s"), f["ckv_b"])  # [Lc, 2*dim]
         k = K.qk_norm_rope(kv, 0, H, D, ca.norm_k.weight, None, None, self.eps)
-        vt = K.v_transpose(kv[:, dim:], D, 2 * dim, Lc, H, D, xn.dtype)
-        out = torch.empty((L_, dim), dtype=xn.dtype, device=xn.device)
+        vt = K.v_transpose(kv[:, dim:], D, 2 * dim, Lc, H, D, context.dtype)
+        out = torch.empty((L_, dim), dtype=context.dtype, device=context.device)
         K.attn_16(q, k, vt, None, out, D, dim)
         return out
 
@@ -257,24 +277,41 @@ class WanModel(nn.Module):
         e = (blk.modulation.float() + e0_B_6_D)  # fp32 [B, 6, dim]  (wan2pt1.py:400)
         ec = [e[:, j].contiguous() for j in range(6)]
         x2 = x.view(B * L_loc, dim)
+        dt = x.dtype
+        # with W8A8 linears the norms emit the INT8 activation of their consumer directly (td_layernorm_quant ==
+        # td_layernorm + td_quant_i8_block128 bit for bit); wider models (dim > 1536) keep the two-kernel form
+        fuse = self.quant_linear and dim <= K.LNQ_MAX_N
+        rows = [slice(b * L_loc, (b + 1) * L_loc) for b in range(B)]
         # ---- self attention ----
-        h = K.layernorm(x2, None, None, self.eps, scale=ec[1], shift=ec[0], rows_per_batch=L_loc)
-        ys = [self._self_attention(i, blk, h[b * L_loc:(b + 1) * L_loc], cos, sin, L_loc) for b in range(B)]
+        if fuse:
+            hs_ = [K.layernorm_quant(x2[r], None, None, self.eps, scale=ec[1][b:b + 1], shift=ec[0][b:b + 1],
+                                     rows_per_batch=L_loc) for b, r in enumerate(rows)]
+        else:
+            h = K.layernorm(x2, None, None, self.eps, scale=ec[1], shift=ec[0], rows_per_batch=L_loc)
+            hs_ = [h[r] for r in rows]
+        ys = [self._self_attention(i, blk, hb, cos, sin, L_loc, dt) for hb in hs_]
         y = ys[0] if B == 1 else torch.cat(ys, 0)
         o = self._lin(blk.self_attn.o, y)
         K.gated_residual_(x2, o, ec[2])
         # ---- cross attention ----
         if isinstance(blk.norm3, FastLayerNorm):
-            xn = K.layernorm(x2, blk.norm3.weight, blk.norm3.bias, self.eps)
+            if fuse:
+                xns = [K.layernorm_quant(x2[r], blk.norm3.weight, blk.norm3.bias, self.eps) for r in rows]
+            else:
+                xn = K.layernorm(x2, blk.norm3.weight, blk.norm3.bias, self.eps)
+                xns = [xn[r] for r in rows]
         else:
-            xn = x2
-        cs = [self._cross_attention(i, blk, xn[b * L_loc:(b + 1) * L_loc], context[b]) for b in range(B)]
+            xns = [x2[r] for r in rows]
+        cs = [self._cross_attention(i, blk, xns[b], context[b]) for b in range(B)]
         c = cs[0] if B == 1 else torch.cat(cs, 0)
         K.gated_residual_(x2, self._lin(blk.cross_attn.o, c), None)
         # ---- FFN ----
-        h2 = K.layernorm(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
-        f1 = self._lin(blk.ffn[0], h2, gelu=True)
-        f2 = self._lin(blk.ffn[2], f1)
+        if fuse:
+            hq, hs = K.layernorm_quant(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
+            f2 = self._ffn_q(blk.ffn[0], blk.ffn[2], hq, hs, dt)
+        else:
+            h2 = K.layernorm(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
+            f2 = self._ffn(blk.ffn[0], blk.ffn[2], h2)
         K.gated_residual_(x2, f2, ec[5])
         return x
 
