@@ -79,6 +79,23 @@ def build_model(name, wl, dev, topk, num_layers=None):
     return net.eval(), cfg
 
 
+def pmc_traffic(prefixes):
+    """HBM-side bytes per launch (fetch + write) of the kernels whose names start with one of ``prefixes``, from the
+    committed rocprofv3 PMC summary of this same command (profiles/r01_pmc_hbm_traffic.json, produced by
+    tools/_g10.sh + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 fetch correction).
+    bench.py itself cannot collect counters while it times; None if the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    n = b = 0.0
+    for name, v in ks.items():
+        if any(name.startswith(p) for p in prefixes):
+            n += v["launches"]
+            b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+    return (b / n) if n else None
+
+
 def cpu_baseline(cfg, lat_shape, topk):
     """Oracle port of the reference's ORIGINAL eager path (config C1: SDPA, plain Linear, eager norms)
     timed on the host cores on a bounded sample: ONE of the 30 blocks (+ embeddings) of ONE DiT step at
@@ -210,7 +227,9 @@ def main():
             ach = flops / (gs["avg_ms"] * 1e-3)
             roof = {"kernel": "gemm_w8a8_kernel (W8A8 block-scaled INT8 GEMM)", "bound": "mfma",
                     "achieved": ach / 1e12, "peak": I8_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / I8_PEAK,
-                    "traffic": None, "avg_launch_ms": gs["avg_ms"], "launches": gs["launches"],
+                    "traffic": pmc_traffic(("gemm_w8a8_",)), "traffic_unit": "B/launch (HBM-side fetch+write, PMC)",
+                    "algorithmic_bytes": sum(m * k + n * k + 2.0 * m * n for (m, n, k) in gs["metas"]) / gs["launches"],
+                    "avg_launch_ms": gs["avg_ms"], "launches": gs["launches"],
                     "share_of_step": gs["total_ms"] * 1e-3 / (eager_elapsed or elapsed)}
         roof_attn = None
         if "td_attn_i8" in summ:
@@ -223,7 +242,9 @@ def main():
             by /= a["launches"]
             ach = by / (a["avg_ms"] * 1e-3)
             roof_attn = {"kernel": "attn_kernel<int8 QK, fp16 PV>", "bound": "hbm", "achieved": ach / 1e9,
-                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK, "traffic": None,
+                         "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": ach / HBM_PEAK,
+                         "traffic": pmc_traffic(("attn_kernel<true",)), "traffic_unit": "B/launch (HBM-side fetch+write, PMC)",
+                         "algorithmic_bytes": by,
                          "avg_launch_ms": a["avg_ms"], "launches": a["launches"],
                          "share_of_step": a["total_ms"] * 1e-3 / (eager_elapsed or elapsed)}
         if roof is None:

@@ -65,7 +65,8 @@ def test_gemm_w8a8(K, m, n, k, bias, gelu):
 
 
 @pytest.mark.parametrize("m,n,k", [(1000, 1536, 1536), (2050, 264, 384), (256, 256, 128), (3000, 8960, 256),
-                                   (1111, 1544, 1280), (700, 512, 128), (513, 520, 2304)])
+                                   (1111, 1544, 1280), (700, 512, 128), (513, 520, 2304),
+                                   (9000, 2304, 256)])
 @pytest.mark.parametrize("bias,gelu", [(False, False), (True, True)])
 def test_gemm_variants_bit_identical(K, m, n, k, bias, gelu):
     """128x128-tile kernel, the three 256x256-tile LDS-DMA kernels and the oracle: same bits (ragged M and N tails)."""

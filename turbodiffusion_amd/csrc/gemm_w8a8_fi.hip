@@ -87,8 +87,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   const int wm = wave >> 2, wn = wave & 3;
   unsigned long long dbg_t[40];
   int dbg_n = 0;
+  unsigned long long c_t0 = 0, c_t1 = 0, c_t2 = 0;
+  if constexpr (DBG >= 2) c_t0 = __builtin_amdgcn_s_memtime();
 #define F_STAMP()                                                                             \
-  if constexpr (DBG) {                                                                        \
+  if constexpr (DBG == 1) {                                                                   \
     if ((kb == 8 || kb == 9) && dbg_n < 40) dbg_t[dbg_n++] = __builtin_amdgcn_s_memtime();    \
   }
 
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   F_PREFETCH(2)
   F_PREFETCH(3)
   F_BARRIER()
+  if constexpr (DBG >= 2) c_t1 = __builtin_amdgcn_s_memtime();
   F_LOAD_W(smem, 0)
   F_LOAD_W(smem, 1)
   F_LOAD_X(smem, 0, 0)
@@ -279,10 +282,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     sc_old = sc_new;
     sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sa_n * sb_n)));
   }
-  if constexpr (DBG) {
+  if constexpr (DBG == 1) {
     if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
       for (int q = 0; q < 40; ++q) dbg[(wave >> 2) * 64 + q] = q < dbg_n ? dbg_t[q] : 0ull;
   }
+  if constexpr (DBG >= 2) c_t2 = __builtin_amdgcn_s_memtime();
   // ---- drain: dequant of the last group (nk-1, 7); its MFMAs were issued >= 4 slots ago, the last one
   //      just now: give the matrix pipe its 4 passes before the VALU reads ----
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
@@ -410,7 +414,25 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
       const int jt = hi ? jb : ja;
       const int64_t n = n0 + wn * 64 + jt * 16 + 8 * (lq & 1);
-      if (m < M && n < N) *reinterpret_cast<uint4*>(D + m * ldd + n) = v;
+      if (m < (DBG == 3 ? (int64_t)(ldqs) : M) && n < N) {
+        if constexpr (DBG == 4) {  // experiment: non-temporal (streaming) stores
+          typedef unsigned v4u __attribute__((ext_vector_type(4)));
+          __builtin_nontemporal_store((v4u){v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(D + m * ldd + n));
+        } else {
+          *reinterpret_cast<uint4*>(D + m * ldd + n) = v;
+        }
+      }
+    }
+  }
+  if constexpr (DBG >= 2) {
+    // phase stamps of workgroups 0, 256, 512, ... (one per round on CU-slot 0): {start, first stage landed, main loop
+    // done, stores issued, stores complete}
+    const unsigned long long c_t3 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long c_t4 = __builtin_amdgcn_s_memtime();
+    if ((blockIdx.x & 255) == 0 && wave == 0 && lane == 0 && (blockIdx.x >> 8) < 12) {
+      unsigned long long* o = dbg + (blockIdx.x >> 8) * 5;
+      o[0] = c_t0; o[1] = c_t1; o[2] = c_t2; o[3] = c_t3; o[4] = c_t4;
     }
   }
 }
@@ -443,6 +465,12 @@ int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const fl
                     int64_t k, int64_t ldd, hipStream_t st) {
   if (td_tuning(TD_TUNE_GEMM_ABLATE) == 9)  // s_memtime trace instantiation
     return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 6)  // phase stamps (prologue / main loop / epilogue)
+    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 4)  // phase stamps, non-temporal stores
+    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 5)  // phase stamps with every store predicated off (WRONG results: nothing is written)
+    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 3>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, nullptr, 0);
   if (td_tuning(TD_TUNE_GEMM_ABLATE) == 8)  // s_memtime trace, early-DMA schedule
     return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 1, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
   if (epilogue == TD_EPI_NONE && bias && out_dtype == TD_BF16) {
