@@ -56,6 +56,10 @@ def test_gemm_w8a8(K, m, n, k, bias, gelu):
     out = K.gemm_w8a8(xq.to(DEV), xs.to(DEV), wq.to(DEV), ws.to(DEV), torch.bfloat16,
                       bias=None if b is None else b.to(DEV), gelu_tanh=gelu)
     ulp = ulp_diff_bf16(out, ref)
+    if gelu:
+        # the kernel evaluates tanh-GELU as x*sigmoid(2u) (exact identity, no cancellation); torch's 0.5x(1+tanh u)
+        # loses its digits for x < -4 (|y| < 1e-4): there the two may differ by more than a bf16 ulp of a tiny number
+        ulp = torch.where((out.float().cpu() - ref.float()).abs() <= 3e-7, torch.zeros_like(ulp), ulp)
     assert ulp.max().item() <= 1, f"max ulp {ulp.max().item()}"
     assert (ulp > 0).float().mean().item() < 0.01
     # and against the fp32 matmul of the de-quantised operands (rel-L2 <= 1e-2)

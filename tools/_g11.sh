@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+T=${1:-g11}
+timeout 1200 python -m pytest tests -m gpu -q -x --timeout=600 --no-header -p no:cacheprovider 2>&1 | tail -6
+timeout 600 python tools/kbench.py --iters 10 --only attn 2>&1 | grep -v amdgpu.ids | tee gpurun_out/kbench_$T.log
+timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_$T.log 2>&1
+echo "bench exit $?" >> gpurun_out/bench_$T.log; tail -2 gpurun_out/bench_$T.log | cut -c1-330

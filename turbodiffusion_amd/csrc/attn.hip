@@ -40,6 +40,7 @@ struct AttnParams {
   int H, Qb, Kb, nsel;
   int64_t k_rows_alloc;  // K rows allocated per head (>= Lk; gathered sequence-parallel layout)
   int kb_alloc;          // K blocks allocated per head in vt / k_s
+  float tau;             // lazy running-max threshold (log2 units)
 };
 
 template <bool QK_I8> struct KTile {
@@ -52,6 +53,8 @@ template <bool QK_I8> struct KTile {
   }
 };
 #define VT_BYTES (128 * 128)
+#define A_MAGIC_I 0x4B400000
+#define A_MAGIC_F 12582912.0f
 __device__ __forceinline__ uint32_t vt_off(uint32_t row, uint32_t slot) {
   return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
 }
@@ -138,6 +141,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
   float m_run = -INFINITY, l_part = 0.f;
+  v16i magic16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) magic16[r] = A_MAGIC_I;
+  if constexpr (QK_I8) asm volatile("" : "+v"(magic16));  // loop-invariant C operand of the first MFMA of every chain
 
   int kb_next = lut ? lut[0] : 0;
   TLOAD(kb_next)
@@ -155,22 +162,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     const char* vtile = kt + KT::BYTES;
 
     // ---- S^T = K . Q^T : two 32-key groups ----
+    // INT8 path: every 4-MFMA chain starts from C = 0x4B400000 (1.5*2^23): |sum| <= 128*127*128 < 2^22, so the int32
+    // result reinterpreted as fp32 IS 12582912 + sum — "raw".  raw is monotone in the score, so the row max is taken on
+    // raw, and the softmax argument (sum*mult - m) is ONE fma per element: fma(raw, mult, -(12582912*mult + m)).
+    // The folded constant is ~2e3 with an ulp of ~1e-4 (log2 domain): a common factor per (row, K block) of relative
+    // size < 1e-4, below the fp16 rounding of P.  No v_cvt, no separate scale multiply, no subtract.
     float s[2][16];
+    float mult = p.scale_log2;
     if constexpr (QK_I8) {
+      mult = (qs * p.k_s[(int64_t)h * p.kb_alloc + kb]) * p.scale_log2;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        v16i acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0;
+        v16i acc = magic16;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
           const v4i kf = *reinterpret_cast<const v4i*>(kt + KT::off(32 * g + li, 2 * kc + hi));
           v4i qv; qv[0] = qf[kc].x; qv[1] = qf[kc].y; qv[2] = qf[kc].z; qv[3] = qf[kc].w;
           acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qv, acc, 0, 0, 0);
         }
-        const float mult = (qs * p.k_s[(int64_t)h * p.kb_alloc + kb]) * p.scale_log2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[g][r] = (float)acc[r] * mult;
+        for (int r = 0; r < 16; ++r) s[g][r] = __int_as_float(acc[r]);
       }
     } else {
 #pragma unroll
@@ -185,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
           acc = Mma16<PDT>::mma(kf, qv, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[g][r] = acc[r] * p.scale_log2;
+        for (int r = 0; r < 16; ++r) s[g][r] = acc[r];
       }
     }
     // ---- tail mask (only the last, partial K block) ----
@@ -205,15 +216,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[g][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
+    constexpr float OFFS = QK_I8 ? A_MAGIC_F : 0.0f;
+    mx = (mx - OFFS) * mult;  // the scaled row max of this block (exact subtraction)
+    // lazy running max: the reference point of the exponentials only moves when the row max grows by more than 2^8
+    // — softmax is invariant to it as long as numerator and denominator use the same one; P stays <= 256 (fp16-safe)
+    // and the 64 accumulator rescales per lane are skipped for almost every K block
+    const float m_new = (mx > m_run + p.tau) ? mx : m_run;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first block: exp2(-inf) = 0
     m_run = m_new;
+    const float cc = fmaf(-OFFS, mult, -m_new);
     float psum = 0.f;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[g][r] = __builtin_amdgcn_exp2f(s[g][r] - m_new);
+        s[g][r] = __builtin_amdgcn_exp2f(fmaf(s[g][r], mult, cc));
         psum += s[g][r];
       }
     l_part = l_part * alpha + psum;
@@ -304,6 +321,7 @@ extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_
   if (Lk_alloc == 0) Lk_alloc = Lk;
   TD_REQUIRE(Lk_alloc >= Lk && (Lk_alloc == Lk || Lk_alloc % 64 == 0), TD_ERR_INVALID, "attn: Lk_alloc=%lld", (long long)Lk_alloc);
   p.k_rows_alloc = Lk_alloc; p.kb_alloc = (int)td_cdiv(Lk_alloc, 64);
+  p.tau = td_tuning(TD_TUNE_ATTN_TAU) < 0 ? 0.0f : (td_tuning(TD_TUNE_ATTN_TAU) == 0 ? 8.0f : (float)td_tuning(TD_TUNE_ATTN_TAU));
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == TD_BF16) return launch_attn<true, TD_F16, TD_BF16>(p, st);
   return launch_attn<true, TD_F16, TD_F16>(p, st);
@@ -323,6 +341,7 @@ extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const in
   if (Lk_alloc == 0) Lk_alloc = Lk;
   TD_REQUIRE(Lk_alloc >= Lk && (Lk_alloc == Lk || Lk_alloc % 64 == 0), TD_ERR_INVALID, "attn: Lk_alloc=%lld", (long long)Lk_alloc);
   p.k_rows_alloc = Lk_alloc; p.kb_alloc = (int)td_cdiv(Lk_alloc, 64);
+  p.tau = td_tuning(TD_TUNE_ATTN_TAU) < 0 ? 0.0f : (td_tuning(TD_TUNE_ATTN_TAU) == 0 ? 8.0f : (float)td_tuning(TD_TUNE_ATTN_TAU));
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16) return launch_attn<false, TD_BF16, TD_BF16>(p, st);
   return launch_attn<false, TD_F16, TD_F16>(p, st);
