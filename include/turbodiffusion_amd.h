@@ -94,6 +94,14 @@ int td_gemm_w8a8_quant(const int8_t* a, const float* a_s, const int8_t* b, const
                        const void* bias, int8_t* d_q, float* d_s, int act_dtype, int epilogue,
                        int64_t m, int64_t n, int64_t k, td_stream_t stream);
 
+/* ---- a15 -> a7 fused: the same GEMM whose epilogue applies the block's gated residual in place:
+ * x[m,n] = x[m,n] + cast(cast(gemm+bias)[m,n] * cast(gate[n]))   (gate f32 [n], or NULL for a plain add; x f16|bf16 with
+ * row stride ldx) == td_gated_residual(x, td_gemm_w8a8(...), gate) bit for bit (Int8Linear.forward ops/core.py:408-412
+ * followed by `x + y * e.type_as(x)`, wan2pt1.py:405-406,412-413).  Requires k % 128 == 0, n % 8 == 0, ldx % 8 == 0. */
+int td_gemm_w8a8_residual(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                          const void* bias, void* x, const float* gate, int dtype, int64_t m,
+                          int64_t n, int64_t k, int64_t ldx, td_stream_t stream);
+
 /* ---- a5: RMSNorm over the last dim (ops/core.py:139-191; rms_norm_cuda) ----
  * y = cast((x*rsqrt(mean(x^2)+eps))*w), fp32 math. x [m,n] in_dtype (f32|bf16|f16),
  * w [n] f32, y [m,n] out_dtype. Requires n % 8 == 0, n <= 8192. */

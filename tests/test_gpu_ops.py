@@ -112,6 +112,23 @@ def test_gemm_fused_output_quant_bit_exact(K, m, n, k, bias, gelu):
     assert torch.equal(q, q_ref), f"codes differ at {(q != q_ref).sum().item()} positions"
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 1536, 384), (300, 264, 256), (1111, 1544, 1280), (4096, 1536, 1536)])
+@pytest.mark.parametrize("bias,gated", [(True, True), (True, False), (False, True)])
+def test_gemm_fused_residual_bit_exact(K, m, n, k, bias, gated):
+    """td_gemm_w8a8_residual == td_gated_residual(x, td_gemm_w8a8(...), gate) bit for bit (ragged M / N tails)."""
+    g = torch.Generator().manual_seed(m + n)
+    a = act_like(m, k, torch.bfloat16, seed=m + n + k)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(n, generator=g) * 0.1).to(torch.bfloat16).to(DEV) if bias else None
+    gate = (torch.randn(1, n, generator=g) * 0.5).to(DEV) if gated else None
+    x0 = torch.randn(m, n, generator=g).to(torch.bfloat16).to(DEV)
+    aq, as_ = K.quant_i8_block128(a.to(DEV))
+    wq, ws = K.quant_i8_block128(w.to(DEV))
+    ref = K.gated_residual_(x0.clone(), K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b), gate)
+    out = K.gemm_w8a8_residual_(x0.clone(), aq, as_, wq, ws, bias=b, gate=gate)
+    assert torch.equal(out, ref), f"differ at {(out != ref).sum().item()} positions"
+
+
 def test_gemm_rejects_bad_k(K):
     from turbodiffusion_amd._lib import TurboDiffusionAMDError
     a = torch.zeros(128, 192, dtype=torch.int8, device=DEV)

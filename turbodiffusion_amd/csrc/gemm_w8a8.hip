@@ -243,3 +243,17 @@ extern "C" int td_gemm_w8a8_quant(const int8_t* a, const float* a_s, const int8_
   if (m == 0 || n == 0) return TD_OK;
   return td_gemm_w8a8_fi_q(a, a_s, b, b_s, bias, d_q, d_s, act_dtype, epilogue, m, n, k, (hipStream_t)stream);
 }
+
+extern "C" int td_gemm_w8a8_residual(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                                     const void* bias, void* x, const float* gate, int dtype, int64_t m,
+                                     int64_t n, int64_t k, int64_t ldx, td_stream_t stream) {
+  TD_REQUIRE(a && a_s && b && b_s && x, TD_ERR_INVALID, "td_gemm_w8a8_residual: null pointer");
+  TD_REQUIRE(m >= 0 && n >= 0 && k >= 0, TD_ERR_INVALID, "td_gemm_w8a8_residual: negative size");
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_residual: dtype %d (need f16|bf16)", dtype);
+  TD_REQUIRE(k % 128 == 0 && k > 0, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8_residual: k=%lld must be a positive multiple of 128", (long long)k);
+  TD_REQUIRE(n % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_residual: n=%lld must be a multiple of 8", (long long)n);
+  TD_REQUIRE(ldx >= n && ldx % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_residual: bad ldx=%lld", (long long)ldx);
+  if (m == 0 || n == 0) return TD_OK;
+  return td_gemm_w8a8_fi_res(a, a_s, b, b_s, bias, x, gate, dtype, m, n, k, ldx, (hipStream_t)stream);
+}

@@ -73,12 +73,15 @@ __device__ __forceinline__ uint32_t f_swz(uint32_t row, uint32_t chunk) {
 // QOUT: the epilogue block-quantises the (bias/GELU'd, 16-bit-rounded) result for the NEXT W8A8 GEMM instead of
 // storing it: D is int8 [M, ldd], QS the fp32 scales [ceil(M/128), ldqs] — bit-identical to td_gemm_w8a8 followed by
 // td_quant_i8_block128 (quant.hip), minus one 2-byte write, one 2-byte read and a launch.
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false>
+// RES: the epilogue applies the block's gated residual in place (a7, wan2pt1.py:405-406,412-413):
+//   D[m,n] = D[m,n] + cast(cast(y[m,n]) * cast(gate[n]))  (gate == nullptr: plain add), y = this GEMM's 16-bit result —
+// bit-identical to td_gemm_w8a8 followed by td_gated_residual, minus a 2-byte write, a 2-byte read and a launch.
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int tiles_m, int tiles_n, int group_m,
-    unsigned long long* __restrict__ dbg, float* __restrict__ QS, int64_t ldqs) {
+    unsigned long long* __restrict__ dbg, float* __restrict__ QS, int64_t ldqs, const float* __restrict__ gate) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -389,6 +392,21 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     }
     return;
   }
+  // RES: the residual tile is fetched up front — 16 independent 16-byte loads per lane in flight, at the addresses
+  // this lane will store to (row i*16 + l16, the 8 consecutive n it owns after the lane swap) — so their latency
+  // overlaps the conversion of the accumulators instead of serialising load -> add -> store per row
+  uint4 xres[RES ? 8 : 1][2];
+  if constexpr (RES) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int64_t m = m0 + wm * 128 + i * 16 + l16;
+        const int64_t n = n0 + wn * 64 + (hi ? 2 * jp + 1 : 2 * jp) * 16 + 8 * (lq & 1);
+        xres[i][jp] = make_uint4(0, 0, 0, 0);
+        if (m < M && n < N) xres[i][jp] = *reinterpret_cast<const uint4*>(D + m * ldd + n);
+      }
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t m = m0 + wm * 128 + i * 16 + l16;
@@ -414,6 +432,28 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
       const int jt = hi ? jb : ja;
       const int64_t n = n0 + wn * 64 + jt * 16 + 8 * (lq & 1);
+      if constexpr (RES) {
+        if (m < M && n < N) {
+          uint16_t* xp = D + m * ldd + n;
+          float xf[8], yf[8];
+          unpack8<ODT>(xres[i][jp], xf);
+          unpack8<ODT>(v, yf);
+          if (gate != nullptr) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gate + n), g1 = *reinterpret_cast<const float4*>(gate + n + 4);
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float gd = round_half<ODT>(g[e]);           // gate.type_as(x)
+              const float t = round_half<ODT>(yf[e] * gd);      // y * gate -> x.dtype
+              xf[e] = xf[e] + t;                                // x + t    -> x.dtype (rounded at pack)
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf[e] = xf[e] + yf[e];
+          }
+          *reinterpret_cast<uint4*>(xp) = pack8<ODT>(xf);
+        }
+      } else
       if (m < (DBG == 3 ? (int64_t)(ldqs) : M) && n < N) {
         if constexpr (DBG == 4) {  // experiment: non-temporal (streaming) stores
           typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -437,11 +477,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false>
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false>
 static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
-                          hipStream_t st, float* qs = nullptr, int64_t ldqs = 0) {
-  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT>;
+                          hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
+  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -454,7 +494,7 @@ static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, co
   // profiling only: row stride of both int8 operands = k + pad (the caller's buffers must be that large)
   const int64_t ldab = k + td_tuning(TD_TUNE_GEMM_LDPAD);
   kern<<<nwg, 512, F_LDS + F_DUMP, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldab, ldab, ldd,
-                                tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr, qs, ldqs);
+                                tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr, qs, ldqs, gate);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
@@ -510,4 +550,15 @@ int td_gemm_w8a8_fi_q(const int8_t* a, const float* a_s, const int8_t* b, const 
   }
   if (act_dtype == TD_BF16) { TD_GEMM_CASE(TD_BF16) } else { TD_GEMM_CASE(TD_F16) }
 #undef TD_GEMM_CASE
+}
+
+// a15 + a7 fused: x[m, ldx] += cast(cast(gemm + bias) * cast(gate))   (gate f32 [n] or NULL for a plain add)
+int td_gemm_w8a8_fi_res(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
+                        void* x, const float* gate, int dtype, int64_t m, int64_t n, int64_t k, int64_t ldx,
+                        hipStream_t st) {
+  if (dtype == TD_BF16)
+    return bias ? launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate)
+                : launch_gemm_fi<TD_BF16, TD_EPI_NONE, false, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+  return bias ? launch_gemm_fi<TD_F16, TD_EPI_NONE, true, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate)
+              : launch_gemm_fi<TD_F16, TD_EPI_NONE, false, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
 }

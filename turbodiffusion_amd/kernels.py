@@ -154,6 +154,27 @@ def layernorm(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, out_dtype=
     return y.reshape(x.shape)
 
 
+def gemm_w8a8_residual_(x, a_q, a_s, b_q, b_s, bias=None, gate=None):
+    """In place: x = x + (W8A8 GEMM + bias) * gate.type_as(x)  (gate f32 [n] or None for a plain add) ==
+    gated_residual_(x, gemm_w8a8(...), gate) bit for bit, without the 16-bit round trip of the GEMM result."""
+    require_gpu(x, a_q, a_s, b_q, b_s, bias, gate)
+    assert a_q.dtype == torch.int8 and b_q.dtype == torch.int8 and x.dim() == 2 and x.stride(1) == 1
+    assert a_q.is_contiguous() and b_q.is_contiguous() and a_s.is_contiguous() and b_s.is_contiguous()
+    m, k = a_q.shape
+    n, k2 = b_q.shape
+    assert k == k2 and x.shape == (m, n), "gemm_w8a8_residual_: shape mismatch"
+    assert a_s.shape == (cdiv(m, 128), k // 128) and b_s.shape == (cdiv(n, 128), k // 128), "scale shapes"
+    if bias is not None:
+        assert bias.dtype == x.dtype and bias.shape == (n,) and bias.is_contiguous()
+    if gate is not None:
+        gate = gate.float().contiguous().reshape(-1)
+        assert gate.numel() == n, "gemm_w8a8_residual_: one gate row (call per batch entry)"
+    _timed("td_gemm_w8a8", (m, n, k), lambda: call(
+        "td_gemm_w8a8_residual", ptr(a_q), ptr(a_s), ptr(b_q), ptr(b_s), ptr(bias), ptr(x), ptr(gate), dt_code(x.dtype),
+        m, n, k, x.stride(0), stream_ptr()))
+    return x
+
+
 LNQ_MAX_N = 1536  # td_layernorm_quant keeps a 128-row block on chip; wider rows use layernorm + quant_i8_block128
 
 

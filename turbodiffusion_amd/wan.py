@@ -189,6 +189,23 @@ class WanModel(nn.Module):
         hq, hs = K.gemm_w8a8_quant(xq, xs, lin1.int8_weight, lin1.scale, dtype, bias=lin1.bias, gelu_tanh=True)
         return K.gemm_w8a8(hq, hs, lin2.int8_weight, lin2.scale, dtype, bias=lin2.bias)
 
+    def _residual_lin_(self, x2, mod, y, gate):
+        """x2 += Linear(y) * gate.type_as(x2)  (gate fp32 [B, dim] or None), in place (wan2pt1.py:405-406,412-413).
+        W8A8 and one batch entry: the GEMM's epilogue applies the residual (same bits, one pass less over [L, dim])."""
+        if isinstance(mod, Int8Linear) and (gate is None or gate.shape[0] == 1):
+            yq, ys = K.quant_i8_block128(y)
+            return K.gemm_w8a8_residual_(x2, yq, ys, mod.int8_weight, mod.scale, bias=mod.bias, gate=gate)
+        return K.gated_residual_(x2, self._lin(mod, y), gate)
+
+    def _ffn_residual_(self, x2, lin1, lin2, h, gate):
+        """x2 += FFN(h) * gate: Linear -> GELU(tanh) -> Linear with both fusions (epilogue quantiser, epilogue residual)."""
+        if isinstance(lin1, Int8Linear) and isinstance(lin2, Int8Linear) and gate.shape[0] == 1:
+            xq, xs = h if isinstance(h, tuple) else K.quant_i8_block128(h)
+            hq, hs = K.gemm_w8a8_quant(xq, xs, lin1.int8_weight, lin1.scale, x2.dtype, bias=lin1.bias, gelu_tanh=True)
+            return K.gemm_w8a8_residual_(x2, hq, hs, lin2.int8_weight, lin2.scale, bias=lin2.bias, gate=gate)
+        f2 = self._ffn_q(lin1, lin2, h[0], h[1], x2.dtype) if isinstance(h, tuple) else self._ffn(lin1, lin2, h)
+        return K.gated_residual_(x2, f2, gate)
+
     def _ffn(self, lin1, lin2, x):
         """Linear -> GELU(tanh) -> Linear (wan2pt1.py:375).  W8A8: the first GEMM's epilogue also block-quantises its
         output for the second (same bits as Int8Linear -> GELU -> int8_quant, without the [L, ffn] 16-bit round trip)."""
@@ -293,8 +310,7 @@ class WanModel(nn.Module):
             hs_ = [h[r] for r in rows]
         ys = [self._self_attention(i, blk, hb, cos, sin, L_loc, dt) for hb in hs_]
         y = ys[0] if B == 1 else torch.cat(ys, 0)
-        o = self._lin(blk.self_attn.o, y)
-        K.gated_residual_(x2, o, ec[2])
+        self._residual_lin_(x2, blk.self_attn.o, y, ec[2])
         # ---- cross attention ----
         if isinstance(blk.norm3, FastLayerNorm):
             if fuse:
@@ -306,15 +322,13 @@ class WanModel(nn.Module):
             xns = [x2[r] for r in rows]
         cs = [self._cross_attention(i, blk, xns[b], context[b]) for b in range(B)]
         c = cs[0] if B == 1 else torch.cat(cs, 0)
-        K.gated_residual_(x2, self._lin(blk.cross_attn.o, c), None)
+        self._residual_lin_(x2, blk.cross_attn.o, c, None)
         # ---- FFN ----
         if fuse:
-            hq, hs = K.layernorm_quant(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
-            f2 = self._ffn_q(blk.ffn[0], blk.ffn[2], hq, hs, dt)
+            h2 = K.layernorm_quant(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
         else:
             h2 = K.layernorm(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
-            f2 = self._ffn(blk.ffn[0], blk.ffn[2], h2)
-        K.gated_residual_(x2, f2, ec[5])
+        self._ffn_residual_(x2, blk.ffn[0], blk.ffn[2], h2, ec[5])
         return x
 
     # ------------------------------------------------------------------ forward
