@@ -191,12 +191,30 @@ int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const f
                int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
                int64_t Lk_alloc, int H, td_stream_t stream);
 
+/* The same kernel with its two optional epilogue fusions (both leave the attention arithmetic untouched):
+ *   add_t   : 16-bit addend in the lane-private layout written by td_sla_linear_out_t; the output becomes
+ *             o_s + o_l (the 16-bit add of SLA/core.py:253) without a separate read-modify-write pass over o;
+ *   q_out / q_scale : instead of o, write the [L, H*128] attention output block-quantised for the Int8Linear o
+ *             projection: q_out int8 [L, H*128], q_scale f32 [ceil(L/128), H] == td_quant_i8_block128 of the
+ *             16-bit output, bit for bit (a workgroup's 128-token x one-head tile is exactly one 128x128 block).
+ * Without q_out the output strides must be multiples of 8 elements. */
+int td_attn_i8_ex(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                  const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
+                  int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
+                  int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale,
+                  td_stream_t stream);
+
 /* ---- a12 / a9 / a4: 16-bit QK attention (SLA Triton arithmetic; dense cross-attention) ----
  * q [H, L, 128], k [H, Lk, 128] dtype (bf16|f16); vt [H, ceil(Lk/64), 128, 64] same dtype;
  * P is rounded to dtype before P@V (SLA/kernel.py:68). lut as above. */
 int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
                int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
                int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream);
+
+int td_attn_16_ex(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
+                  int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+                  int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale,
+                  td_stream_t stream);
 
 #define TD_SLA_NCH 32 /* partial-sum chunks per head of td_sla_linear_kv* (workspace leading extent) */
 
@@ -224,6 +242,12 @@ int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, int nch, int6
 int td_sla_linear_out(const void* q, int dtype, const void* kvsum_t, const void* ksum,
                       const float* wp, const float* bp, void* o, int64_t o_stride_h,
                       int64_t o_stride_l, int64_t L, int H, int D, td_stream_t stream);
+
+/* pass 2 without the read-modify-write: o_l = cast(proj_l(...)) is written to t_out, 16-bit, in the lane-private
+ * layout [H][ceil(L/128)][4 waves][16][64 lanes][4] that td_attn_*_ex consumes through add_t (run it BEFORE the
+ * attention kernel: it only needs q, kvsum, ksum). */
+int td_sla_linear_out_t(const void* q, int dtype, const void* kvsum_t, const void* ksum, const float* wp,
+                        const float* bp, void* t_out, int64_t L, int H, int D, td_stream_t stream);
 
 #ifdef __cplusplus
 }

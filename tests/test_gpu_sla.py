@@ -178,6 +178,41 @@ def test_attn_softmax_rescale_spike(K):
     assert rel_l2(out[0, 37], ref[0, 37]) < 1e-2
 
 
+@pytest.mark.parametrize("H,L,ratio", [(2, 300, 0.5), (3, 1000, 0.3), (12, 1664, 0.2)])
+def test_attention_epilogue_fusions_bit_exact(K, H, L, ratio):
+    """add_t (o_l added in the attention epilogue) and quant_out (epilogue block-quantiser) reproduce the separate
+    passes bit for bit: attn -> linear_out_ (read-modify-write) -> quant_i8_block128."""
+    q, k, v, q_i8, q_s, k_i8, k_s = _sage_inputs(H, L, 21)
+    _, lut, topk = S.get_block_map(q, k, ratio, 128, 64)
+    g = torch.Generator().manual_seed(5)
+    wp = (torch.randn(128, 128, generator=g) * 0.05).to(DEV)
+    bp = (torch.randn(128, generator=g) * 0.05).to(DEV)
+    qd, kd = q[0].contiguous().to(DEV), k[0].contiguous().to(DEV)
+    vt = K.v_transpose(v[0].contiguous().to(DEV), L * 128, 128, L, H, 128, torch.float16)
+    kv_t, ksum = K.sla_linear_kv(kd, vt)
+    args = (q_i8[0].to(DEV), q_s[0].to(DEV), k_i8[0].to(DEV), k_s[0].to(DEV), vt, lut[0].int().to(DEV))
+    # reference: separate passes, token-major [L, H*128] output like the DiT block uses
+    ref = torch.empty(L, H * 128, dtype=torch.bfloat16, device=DEV)
+    K.attn_i8(*args, ref, 128, H * 128)
+    K.sla_linear_out_(qd, kv_t, ksum, wp, bp, ref, 128, H * 128)
+    rq, rs = K.quant_i8_block128(ref)
+    # fused: o_l first, added + quantised in the attention epilogue
+    o_l = K.sla_linear_out_t(qd, kv_t, ksum, wp, bp)
+    out = torch.empty(L, H * 128, dtype=torch.bfloat16, device=DEV)
+    K.attn_i8(*args, out, 128, H * 128, add_t=o_l)
+    assert torch.equal(out, ref), f"add_t: {(out != ref).sum().item()} elements differ"
+    oq, os_ = K.attn_i8(*args, torch.bfloat16, 128, H * 128, add_t=o_l, quant_out=True)
+    assert torch.equal(os_, rs) and torch.equal(oq, rq)
+    # 16-bit QK kernel (the dense cross-attention shape: few keys), quantised output
+    kc, vc = kd[:, :200].contiguous(), v[0][:, :200].contiguous().to(DEV)
+    vtc = K.v_transpose(vc, 200 * 128, 128, 200, H, 128, torch.bfloat16)
+    ref2 = torch.empty(L, H * 128, dtype=torch.bfloat16, device=DEV)
+    K.attn_16(qd, kc, vtc, None, ref2, 128, H * 128)
+    rq2, rs2 = K.quant_i8_block128(ref2)
+    oq2, os2 = K.attn_16(qd, kc, vtc, None, None, 128, H * 128, quant_out=True)
+    assert torch.equal(os2, rs2) and torch.equal(oq2, rq2)
+
+
 @pytest.mark.parametrize("H,L", [(2, 300), (3, 1000)])
 def test_linear_branch(K, H, L):
     q, k, v = qkv(H, L, 10)

@@ -41,6 +41,10 @@ struct AttnParams {
   int64_t k_rows_alloc;  // K rows allocated per head (>= Lk; gathered sequence-parallel layout)
   int kb_alloc;          // K blocks allocated per head in vt / k_s
   float tau;             // lazy running-max threshold (log2 units)
+  const uint16_t* add_t;  // optional: 16-bit addend in the lane-private layout of td_sla_linear_out_t (o = o_s + o_l)
+  int8_t* q_out;          // optional: block-quantised output int8 [L, q_ld] instead of o ...
+  float* q_scale;         // ... with scales [ceil(L/128), H]  (== td_quant_i8_block128 of the [L, H*128] output)
+  int64_t q_ld;
 };
 
 template <bool QK_I8> struct KTile {
@@ -262,20 +266,92 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
   }
 
   // ---- epilogue: lane = q row; oacc[c][r] is d = 32c + (r&3) + 8(r>>2) + 4hi ----
+  // The tile [128 tokens x 128 d] is transposed through LDS (K/V buffers are free: the loop ended on a barrier) so
+  // that global memory sees 16-byte row-contiguous accesses (a lane-per-row store touches 64 cache lines per
+  // instruction), the linear branch's o_l is added from its lane-private layout (a coalesced read instead of a
+  // strided read-modify-write pass), and — optionally — the tile, which is exactly one 128x128 quantisation block of
+  // the [L, H*128] attention output, is block-quantised for the o projection right here.
   const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (q_ok) {
-    uint16_t* op = p.o + (int64_t)h * p.o_stride_h + qrow * p.o_stride_l;
+  uint2 addv[16];
+  if (p.add_t) {
+    const uint2* ap = reinterpret_cast<const uint2*>(p.add_t) + (((int64_t)h * p.Qb + qb) * 4 + wave) * 16 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) addv[i] = ap[i * 64];
+  }
+  constexpr int SROW = 272;  // bytes per staged token row (256 + 16: conflict-free 8-byte writes and 16-byte reads)
+  {
+    char* srow = smem + (wave * 32 + li) * SROW;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        uint32_t b[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b[e] = f32_to_half_bits<ODT>(oacc[c][4 * g4 + e] * inv);
-        *reinterpret_cast<uint2*>(op + 32 * c + 8 * g4 + 4 * hi) =
-            make_uint2(b[0] | (b[1] << 16), b[2] | (b[3] << 16));
+        uint32_t w0 = pack2<ODT>(oacc[c][4 * g4] * inv, oacc[c][4 * g4 + 1] * inv);      // o_s in the output dtype
+        uint32_t w1 = pack2<ODT>(oacc[c][4 * g4 + 2] * inv, oacc[c][4 * g4 + 3] * inv);
+        if (p.add_t) {                                                                    // o = o_s + o_l (16-bit add)
+          float a0, a1, a2, a3, b0, b1, b2, b3;
+          unpack2<ODT>(w0, a0, a1); unpack2<ODT>(w1, a2, a3);
+          unpack2<ODT>(addv[c * 4 + g4].x, b0, b1); unpack2<ODT>(addv[c * 4 + g4].y, b2, b3);
+          w0 = pack2<ODT>(a0 + b0, a1 + b1);
+          w1 = pack2<ODT>(a2 + b2, a3 + b3);
+        }
+        if (!q_ok) { w0 = 0u; w1 = 0u; }  // rows past L: zero (they only matter to the block amax)
+        *reinterpret_cast<uint2*>(srow + (32 * c + 8 * g4 + 4 * hi) * 2) = make_uint2(w0, w1);
       }
+  }
+  __syncthreads();
+  uint4 tv[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
+    tv[it] = *reinterpret_cast<const uint4*>(smem + row * SROW + ch * 16);
+  }
+  if (p.q_out == nullptr) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
+      const int64_t tok = (int64_t)qb * 128 + row;
+      if (tok < p.L) *reinterpret_cast<uint4*>(p.o + (int64_t)h * p.o_stride_h + tok * p.o_stride_l + ch * 8) = tv[it];
+    }
+  } else {
+    // per-128x128-block INT8 quantiser (quant.hip semantics: amax >= 1e-8, 128/amax, RNE, saturate; scale = amax/128)
+    uint32_t mxb = 0u;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const uint32_t w[4] = {tv[it].x, tv[it].y, tv[it].z, tv[it].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t a = w[e] & 0x7fff7fffu;
+        asm("v_pk_max_u16 %0, %0, %1" : "+v"(mxb) : "v"(a));
+      }
+    }
+    uint32_t m16 = max(mxb & 0xffffu, mxb >> 16);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m16 = max(m16, (uint32_t)__shfl_xor((int)m16, o, 64));
+    __syncthreads();  // everyone has read the staged tile; reuse its first words for the 4 wave maxima
+    uint32_t* red = reinterpret_cast<uint32_t*>(smem);
+    if (lane == 0) red[wave] = m16;
+    __syncthreads();
+    m16 = max(max(red[0], red[1]), max(red[2], red[3]));
+    const float amax = fmaxf(half_bits_to_f32<ODT>(m16), 1e-8f);
+    const float mult = 128.0f / amax;
+    if (tid == 0) p.q_scale[(int64_t)qb * p.H + h] = amax / 128.0f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
+      const int64_t tok = (int64_t)qb * 128 + row;
+      if (tok >= p.L) continue;
+      float f[8];
+      unpack8<ODT>(tv[it], f);
+      uint32_t wd[2] = {0, 0};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = rintf(f[j] * mult);  // RNE
+        t = fminf(fmaxf(t, -128.0f), 127.0f);
+        wd[j >> 2] |= ((uint32_t)(int)t & 0xffu) << (8 * (j & 3));
+      }
+      *reinterpret_cast<uint2*>(p.q_out + tok * p.q_ld + (int64_t)h * 128 + ch * 8) = make_uint2(wd[0], wd[1]);
+    }
   }
 }
 
@@ -303,12 +379,20 @@ static int attn_common_checks(const char* who, const void* q, const void* k, con
   TD_REQUIRE(!lut || nsel >= 1, TD_ERR_INVALID, "%s: nsel=%d with a LUT", who, nsel);
   return TD_OK;
 }
+static int attn_stride_check(const char* who, int64_t o_stride_h, int64_t o_stride_l) {
+  TD_REQUIRE(o_stride_h % 8 == 0 && o_stride_l % 8 == 0, TD_ERR_UNSUPPORTED,
+             "%s: output strides must be multiples of 8 elements (16-byte row-contiguous stores)", who);
+  return TD_OK;
+}
 
-extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
-                          const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
-                          int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
-                          int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream) {
-  int rc = attn_common_checks("td_attn_i8", q_i8, k_i8, vt, o, nsel, L, Lk, H, lut);
+extern "C" int td_attn_i8_ex(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                             const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
+                             int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+                             int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out,
+                             float* q_scale, td_stream_t stream) {
+  int rc = attn_common_checks("td_attn_i8", q_i8, k_i8, vt, q_out ? (void*)q_out : o, nsel, L, Lk, H, lut);
+  TD_REQUIRE((q_out == nullptr) == (q_scale == nullptr), TD_ERR_INVALID, "td_attn_i8: q_out/q_scale mismatch");
+  if (!q_out) { rc = attn_stride_check("td_attn_i8", o_stride_h, o_stride_l); if (rc) return rc; }
   if (rc) return rc;
   TD_REQUIRE(q_s && k_s, TD_ERR_INVALID, "td_attn_i8: null scale pointer");
   TD_REQUIRE(out_dtype == TD_F16 || out_dtype == TD_BF16, TD_ERR_UNSUPPORTED,
@@ -316,6 +400,7 @@ extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_
   AttnParams p;
   p.q = q_i8; p.q_s = q_s; p.k = k_i8; p.k_s = k_s; p.vt = (const uint16_t*)vt; p.lut = lut;
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
+  p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
   if (Lk_alloc == 0) Lk_alloc = Lk;
@@ -327,15 +412,27 @@ extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_
   return launch_attn<true, TD_F16, TD_F16>(p, st);
 }
 
-extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel,
-                          void* o, int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale,
-                          int64_t L, int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream) {
-  int rc = attn_common_checks("td_attn_16", q, k, vt, o, nsel, L, Lk, H, lut);
+extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                          const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
+                          int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+                          int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream) {
+  return td_attn_i8_ex(q_i8, q_s, k_i8, k_s, vt, lut, nsel, o, out_dtype, o_stride_h, o_stride_l, sm_scale, L, Lk,
+                       Lk_alloc, H, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int td_attn_16_ex(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel,
+                             void* o, int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale,
+                             int64_t L, int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out,
+                             float* q_scale, td_stream_t stream) {
+  int rc = attn_common_checks("td_attn_16", q, k, vt, q_out ? (void*)q_out : o, nsel, L, Lk, H, lut);
+  TD_REQUIRE((q_out == nullptr) == (q_scale == nullptr), TD_ERR_INVALID, "td_attn_16: q_out/q_scale mismatch");
+  if (!q_out) { rc = attn_stride_check("td_attn_16", o_stride_h, o_stride_l); if (rc) return rc; }
   if (rc) return rc;
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_attn_16: dtype %d", dtype);
   AttnParams p;
   p.q = q; p.q_s = nullptr; p.k = k; p.k_s = nullptr; p.vt = (const uint16_t*)vt; p.lut = lut;
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
+  p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
   if (Lk_alloc == 0) Lk_alloc = Lk;
@@ -345,4 +442,11 @@ extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const in
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16) return launch_attn<false, TD_BF16, TD_BF16>(p, st);
   return launch_attn<false, TD_F16, TD_F16>(p, st);
+}
+
+extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel,
+                          void* o, int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale,
+                          int64_t L, int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream) {
+  return td_attn_16_ex(q, k, vt, lut, nsel, o, dtype, o_stride_h, o_stride_l, sm_scale, L, Lk, Lk_alloc, H, nullptr,
+                       nullptr, nullptr, stream);
 }

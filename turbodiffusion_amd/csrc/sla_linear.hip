@@ -270,7 +270,8 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
                                                          const float* __restrict__ wp,
                                                          const float* __restrict__ bp,
                                                          uint16_t* __restrict__ o, int64_t o_stride_h,
-                                                         int64_t o_stride_l, int64_t L, int Qb) {
+                                                         int64_t o_stride_l, int64_t L, int Qb,
+                                                         uint16_t* __restrict__ t_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_lo[];
   char* kvs = smem_lo;               // kvsum^T [d2][d1] DT, 256-B rows, swizzled
   char* wps = smem_lo + 128 * 256;   // Wp [d3][d2 in MFMA k order] DT
@@ -388,7 +389,25 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
         const frag bf = *reinterpret_cast<const frag*>(&olf[ks]);
         a2 = MmaT<DT>::mma(af, bf, a2);
       }
-      if (ok) {
+      if (t_out != nullptr) {
+        // lane-private layout for the attention kernel's epilogue (same lane = token, register = d mapping there):
+        // [h][qb][wave][c*4+g4][lane] x 8 bytes — every store instruction writes 512 contiguous bytes, no read of o
+        uint2* tp = reinterpret_cast<uint2*>(t_out) + (((int64_t)h * Qb + qb) * 4 + wave) * 16 * 64 + lane;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d3 = 32 * c + 8 * g4 + 4 * hi;
+          const float4 bb = *reinterpret_cast<const float4*>(bp + d3);
+          const float bias[4] = {bb.x, bb.y, bb.z, bb.w};
+          uint32_t res[2];
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            float b0, b1;
+            unpack2<DT>(pack2<DT>(bias[e], bias[e + 1]), b0, b1);                                  // autocast bias
+            res[e >> 1] = pack2<DT>(a2[4 * g4 + e] + b0, a2[4 * g4 + e + 1] + b1);                 // o_l in dt
+          }
+          tp[(c * 4 + g4) * 64] = make_uint2(res[0], res[1]);
+        }
+      } else if (ok) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int d3 = 32 * c + 8 * g4 + 4 * hi;
@@ -411,10 +430,10 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
   }
 }
 
-extern "C" int td_sla_linear_out(const void* q, int dtype, const void* kvsum_t, const void* ksum,
-                                 const float* wp, const float* bp, void* o, int64_t o_stride_h,
-                                 int64_t o_stride_l, int64_t L, int H, int D, td_stream_t stream) {
-  TD_REQUIRE(q && kvsum_t && ksum && wp && bp && o, TD_ERR_INVALID, "td_sla_linear_out: null pointer");
+static int sla_linear_out_impl(const void* q, int dtype, const void* kvsum_t, const void* ksum,
+                               const float* wp, const float* bp, void* o, int64_t o_stride_h,
+                               int64_t o_stride_l, int64_t L, int H, int D, void* t_out, td_stream_t stream) {
+  TD_REQUIRE(q && kvsum_t && ksum && wp && bp && (o || t_out), TD_ERR_INVALID, "td_sla_linear_out: null pointer");
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_linear_out: D=%d (need 128)", D);
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_sla_linear_out: dtype %d", dtype);
   TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sla_linear_out: L=%lld H=%d", (long long)L, H);
@@ -428,14 +447,28 @@ extern "C" int td_sla_linear_out(const void* q, int dtype, const void* kvsum_t, 
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_out_kernel<TD_BF16>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
     linear_out_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
-        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb);
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out);
   } else {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_out_kernel<TD_F16>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
     linear_out_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
-        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb);
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out);
   }
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_sla_linear_out(const void* q, int dtype, const void* kvsum_t, const void* ksum,
+                                 const float* wp, const float* bp, void* o, int64_t o_stride_h,
+                                 int64_t o_stride_l, int64_t L, int H, int D, td_stream_t stream) {
+  TD_REQUIRE(o, TD_ERR_INVALID, "td_sla_linear_out: null output");
+  return sla_linear_out_impl(q, dtype, kvsum_t, ksum, wp, bp, o, o_stride_h, o_stride_l, L, H, D, nullptr, stream);
+}
+
+extern "C" int td_sla_linear_out_t(const void* q, int dtype, const void* kvsum_t, const void* ksum,
+                                   const float* wp, const float* bp, void* t_out, int64_t L, int H, int D,
+                                   td_stream_t stream) {
+  TD_REQUIRE(t_out, TD_ERR_INVALID, "td_sla_linear_out_t: null output");
+  return sla_linear_out_impl(q, dtype, kvsum_t, ksum, wp, bp, nullptr, 4, 4, L, H, D, t_out, stream);
 }

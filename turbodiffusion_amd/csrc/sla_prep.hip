@@ -277,31 +277,46 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
     qs[i] = half_bits_to_f32<DT>(pq[((int64_t)h * Qb + qr) * 128 + d]);
   }
   __syncthreads();
-  for (int j = tid; j < Kb; j += 256) {
-    float acc[TK_ROWS];
+  // scores, 64 keys at a time: the 16 KB of pooled keys are fetched with fully coalesced 16-byte loads into LDS
+  // (rows padded to 272 B), then thread (key = tid & 63, row group = wave) accumulates 4 q rows x 128 d in the same
+  // fp32 fma order as a plain dot product.  (One thread per key reading its 256-B row straight from global touched
+  // 64 cache lines per load instruction: 87 us for 1.5 M scores.)
+  uint4* ktile = reinterpret_cast<uint4*>(smem_tk + TK_ROWS * 128 * 4 + (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15));
+  for (int c0 = 0; c0 < Kb; c0 += 64) {
 #pragma unroll
-    for (int r = 0; r < TK_ROWS; ++r) acc[r] = 0.f;
-    const uint16_t* kr = pk + ((int64_t)h * Kb_alloc + j) * 128;
+    for (int it = 0; it < 4; ++it) {
+      const int idx = tid + 256 * it, key = idx >> 4, v = idx & 15;
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (c0 + key < Kb) val = *reinterpret_cast<const uint4*>(pk + ((int64_t)h * Kb_alloc + c0 + key) * 128 + v * 8);
+      ktile[key * 17 + v] = val;
+    }
+    __syncthreads();
+    {
+      const int key = tid & 63, rg = wave * 4;
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int d8 = 0; d8 < 16; ++d8) {
-      float kf[8];
-      unpack8<DT>(*reinterpret_cast<const uint4*>(kr + d8 * 8), kf);
+      for (int d8 = 0; d8 < 16; ++d8) {
+        float kf[8];
+        unpack8<DT>(ktile[key * 17 + d8], kf);
 #pragma unroll
-      for (int r = 0; r < TK_ROWS; ++r) {
-        const float* qrow = qs + r * 128 + d8 * 8;
+        for (int r = 0; r < 4; ++r) {
+          const float* qrow = qs + (rg + r) * 128 + d8 * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[r] = fmaf(qrow[e], kf[e], acc[r]);
+          for (int e = 0; e < 8; ++e) acc[r] = fmaf(qrow[e], kf[e], acc[r]);
+        }
+      }
+      if (c0 + key < Kb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          uint32_t b = f32_to_half_bits<DT>(acc[r]);
+          // order-preserving map of a 16-bit float to an unsigned key (larger value -> larger key)
+          b = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+          sc[(rg + r) * Kb + c0 + key] = (uint16_t)b;
+        }
       }
     }
-#pragma unroll
-    for (int r = 0; r < TK_ROWS; ++r) {
-      uint32_t b = f32_to_half_bits<DT>(acc[r]);
-      // order-preserving map of a 16-bit float to an unsigned key (larger value -> larger key)
-      b = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
-      sc[r * Kb + j] = (uint16_t)b;
-    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int rr = 0; rr < 4; ++rr) {
     const int r = wave * 4 + rr;
     if (row0 + r >= Qb) break;
@@ -348,18 +363,18 @@ extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* l
   TD_REQUIRE(Kb >= 1 && Kb <= TK_MAXKB, TD_ERR_UNSUPPORTED, "td_sla_topk: Kb=%d (max %d)", Kb, TK_MAXKB);
   TD_REQUIRE(topk >= 1 && topk <= Kb, TD_ERR_INVALID, "td_sla_topk: topk=%d Kb=%d", topk, Kb);
   TD_REQUIRE(H > 0 && Qb > 0, TD_ERR_INVALID, "td_sla_topk: H=%d Qb=%d", H, Qb);
-  const size_t lds = TK_ROWS * 128 * 4 + (size_t)TK_ROWS * Kb * 2;
+  const size_t lds = TK_ROWS * 128 * 4 + (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15) + 64 * 17 * 16;
   dim3 grid((unsigned)td_cdiv(Qb, TK_ROWS), H);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16) {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<TD_BF16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2); a = true; }
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2 + 64 * 17 * 16); a = true; }
     sla_topk_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk);
   } else {
     static bool a = false;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<TD_F16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2); a = true; }
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2 + 64 * 17 * 16); a = true; }
     sla_topk_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk);
   }
   TD_CHECK_LAUNCH();

@@ -280,10 +280,19 @@ def sla_topk(pq, pk, topk, kb=None):
 
 
 # ----------------------------------------------------------------------------- a9 / a12 / a13
-def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
+def _attn_quant_outputs(L_, H, device):
+    return (torch.empty((L_, H * 128), dtype=torch.int8, device=device),
+            torch.empty((cdiv(L_, 128), H), dtype=torch.float32, device=device))
+
+
+def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, add_t=None,
+            quant_out=False):
     """SageAttention INT8-QK/FP16-PV. q_i8 [H,L,128], k_i8 [H,Lk,128], vt f16 tiles; lut or None (dense).
-    out: preallocated 16-bit tensor addressed as out_ptr + h*o_stride_h + l*o_stride_l + d."""
-    require_gpu(q_i8, k_i8, vt, lut, out)
+    out: preallocated 16-bit tensor addressed as out_ptr + h*o_stride_h + l*o_stride_l + d.
+    add_t: o_l from sla_linear_out_t (the output becomes o_s + o_l).  quant_out: instead of ``out`` return the
+    [L, H*128] output block-quantised for the o projection: (int8 [L, H*128], f32 [ceil(L/128), H]); ``out`` then
+    only supplies the 16-bit dtype (a tensor or a torch.dtype)."""
+    require_gpu(q_i8, k_i8, vt, lut, add_t)
     H, L_, D = q_i8.shape
     lk_alloc = k_i8.shape[1]
     Lk = lk_alloc if lk is None else lk  # lk < allocation: rank-padded gathered layout
@@ -291,25 +300,29 @@ def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]
+    odt = out if isinstance(out, torch.dtype) else out.dtype
+    oq, os_ = _attn_quant_outputs(L_, H, q_i8.device) if quant_out else (None, None)
     _timed("td_attn_i8", (H, L_, Lk, nsel), lambda: call(
-        "td_attn_i8", ptr(q_i8), ptr(q_s), ptr(k_i8), ptr(k_s), ptr(vt), ptr(lut), nsel, ptr(out),
-        dt_code(out.dtype), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc, H, stream_ptr()))
-    return out
+        "td_attn_i8_ex", ptr(q_i8), ptr(q_s), ptr(k_i8), ptr(k_s), ptr(vt), ptr(lut), nsel,
+        None if quant_out else ptr(out), dt_code(odt), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc, H,
+        ptr(add_t), ptr(oq), ptr(os_), stream_ptr()))
+    return (oq, os_) if quant_out else out
 
 
-def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
-    """16-bit QK attention (q,k [H,L,128] bf16|f16, vt tiles same dtype)."""
-    require_gpu(q, k, vt, lut, out)
+def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, add_t=None, quant_out=False):
+    """16-bit QK attention (q,k [H,L,128] bf16|f16, vt tiles same dtype); add_t / quant_out as attn_i8."""
+    require_gpu(q, k, vt, lut, add_t)
     H, L_, D = q.shape
     lk_alloc = k.shape[1]
     Lk = lk_alloc if lk is None else lk
-    assert D == 128 and vt.dtype == q.dtype and out.dtype == q.dtype
+    assert D == 128 and vt.dtype == q.dtype and (quant_out or out.dtype == q.dtype)
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]
-    call("td_attn_16", ptr(q), ptr(k), ptr(vt), ptr(lut), nsel, ptr(out), dt_code(q.dtype), o_stride_h,
-         o_stride_l, float(sm_scale), L_, Lk, lk_alloc, H, stream_ptr())
-    return out
+    oq, os_ = _attn_quant_outputs(L_, H, q.device) if quant_out else (None, None)
+    call("td_attn_16_ex", ptr(q), ptr(k), ptr(vt), ptr(lut), nsel, None if quant_out else ptr(out), dt_code(q.dtype),
+         o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc, H, ptr(add_t), ptr(oq), ptr(os_), stream_ptr())
+    return (oq, os_) if quant_out else out
 
 
 # ----------------------------------------------------------------------------- a14
@@ -365,6 +378,18 @@ def sla_linear_kv_final(kv_parts, ks_parts, nch, kv_sh, kv_sc, ks_sh, ks_sc, H, 
     call("td_sla_linear_kv_final", ptr(kv_parts), ptr(ks_parts), nch, kv_sh, kv_sc, ks_sh, ks_sc, ptr(kv_t),
          ptr(ksum), dt_code(dtype), H, D, stream_ptr())
     return kv_t, ksum
+
+
+def sla_linear_out_t(q, kv_t, ksum, wp, bp):
+    """o_l = cast(proj_l((cq @ kvsum) / (1e-5 + cq.ksum))) in the lane-private layout the attention kernels add in their
+    epilogue (``add_t``): 16-bit [H, ceil(L/128), 4, 16, 64, 4]."""
+    require_gpu(q, kv_t, ksum, wp, bp)
+    H, L_, D = q.shape
+    assert wp.dtype == torch.float32 and bp.dtype == torch.float32 and wp.is_contiguous()
+    t = torch.empty((H, cdiv(L_, 128), 4, 16, 64, 4), dtype=q.dtype, device=q.device)
+    call("td_sla_linear_out_t", ptr(q), dt_code(q.dtype), ptr(kv_t), ptr(ksum), ptr(wp), ptr(bp), ptr(t), L_, H, D,
+         stream_ptr())
+    return t
 
 
 def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l):

@@ -25,12 +25,17 @@ def _check_feature_map(feature_map):
 
 
 def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
-                                v_strides, blkq=128, blkk=64, dense=False):
+                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False):
     """Core of both modules on head-major tensors.
 
     q, k: [H, L, D] 16-bit (after RoPE); vt_src: tensor holding V with element (h,l,d) at
     data_ptr + h*v_strides[0] + l*v_strides[1] + d; out: preallocated, element (h,l,d) at
     out_ptr + h*o_stride_h + l*o_stride_l + d.  Returns (out, real_topk, Kb).
+    quant_out: return the [L, H*D] result block-quantised for the o projection ((int8, scales) in place of ``out``,
+    which then only supplies the dtype).
+
+    The linear branch (needs only q, k, v) runs FIRST and leaves o_l in a lane-private layout; the attention kernel adds
+    it in its epilogue (o = o_s + o_l, the 16-bit add of SLA/core.py:253) — no read-modify-write pass over the output.
     """
     H, L_, D = q.shape
     assert D == 128, "head_dim must be 128 on this build (SLA/core.py:207 allows 64|128)"
@@ -40,6 +45,10 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     pdt = torch.float16 if sage else q.dtype
     vt = K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, pdt)
     km = K.seq_mean(k)
+    o_l = None
+    if proj_w is not None:
+        kv_t, ksum = K.sla_linear_kv(k, vt)
+        o_l = K.sla_linear_out_t(q, kv_t, ksum, proj_w, proj_b)
     if dense:
         lut = None
         pq = None
@@ -48,17 +57,14 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
         pk, k_i8, k_s = K.sage_quant_pool(k, km, blkk, want_pool=not dense)
         if not dense:
             lut = K.sla_topk(pq, pk, topk)
-        K.attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l)
+        res = K.attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out)
     else:
         if not dense:
             pq, _, _ = K.sage_quant_pool(q, None, blkq, want_quant=False)
             pk, _, _ = K.sage_quant_pool(k, km, blkk, want_quant=False)
             lut = K.sla_topk(pq, pk, topk)
-        K.attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l)
-    if proj_w is not None:
-        kv_t, ksum = K.sla_linear_kv(k, vt)
-        K.sla_linear_out_(q, kv_t, ksum, proj_w, proj_b, out, o_stride_h, o_stride_l)
-    return out, topk, kb
+        res = K.attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out)
+    return res, topk, kb
 
 
 class _SLABase(nn.Module):

@@ -193,7 +193,7 @@ class WanModel(nn.Module):
         """x2 += Linear(y) * gate.type_as(x2)  (gate fp32 [B, dim] or None), in place (wan2pt1.py:405-406,412-413).
         W8A8 and one batch entry: the GEMM's epilogue applies the residual (same bits, one pass less over [L, dim])."""
         if isinstance(mod, Int8Linear) and (gate is None or gate.shape[0] == 1):
-            yq, ys = K.quant_i8_block128(y)
+            yq, ys = y if isinstance(y, tuple) else K.quant_i8_block128(y)
             return K.gemm_w8a8_residual_(x2, yq, ys, mod.int8_weight, mod.scale, bias=mod.bias, gate=gate)
         return K.gated_residual_(x2, self._lin(mod, y), gate)
 
@@ -250,7 +250,7 @@ class WanModel(nn.Module):
         return F.linear(x, w, b)
 
     # ------------------------------------------------------------------ one transformer block
-    def _self_attention(self, i, blk, h, cos, sin, L_loc, dtype):
+    def _self_attention(self, i, blk, h, cos, sin, L_loc, dtype, quant_out=False):
         """h: [L_loc, dim] modulated input of this rank's tokens (or its (int8, scales) pair when the norm
         already quantised it) -> [L_loc, dim] attention output."""
         f = self._fused_weights(i, blk)
@@ -262,18 +262,21 @@ class WanModel(nn.Module):
             qkv = self._fused_lin(h, f["qkv_w"], f.get("qkv_s"), f["qkv_b"])  # [L, 3*dim]
         q = K.qk_norm_rope(qkv, 0, H, D, sa.norm_q.weight, cos, sin, self.eps)
         k = K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
-        out = torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
+        if self.seq_parallel is not None:
+            quant_out = False
+        out = dtype if quant_out else torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
         if self.seq_parallel is not None:
             return self.seq_parallel.self_attention(self, f, q, k, qkv, out)
         at = self.attention_type
         sage = at in ("sage", "sagesla")
         dense = at in ("original", "sage")
-        sparse_linear_attention_hld(q, k, qkv[:, 2 * dim:], f.get("proj_w") if not dense else None,
-                                    f.get("proj_b") if not dense else None, self.sla_topk, sage, out, D, dim,
-                                    (D, 3 * dim), dense=dense)
-        return out
+        # W8A8: the attention kernel's epilogue hands the o projection its INT8 activation directly
+        res, _, _ = sparse_linear_attention_hld(q, k, qkv[:, 2 * dim:], f.get("proj_w") if not dense else None,
+                                                f.get("proj_b") if not dense else None, self.sla_topk, sage, out, D, dim,
+                                                (D, 3 * dim), dense=dense, quant_out=quant_out)
+        return res
 
-    def _cross_attention(self, i, blk, xn, context):
+    def _cross_attention(self, i, blk, xn, context, quant_out=False):
         """xn [L, dim] (norm3 output), context [Lc, dim] -> [L, dim] (before the o projection)."""
         f = self._fused_weights(i, blk)
         ca = blk.cross_attn
@@ -285,9 +288,8 @@ class WanModel(nn.Module):
         kv = self._fused_lin(context, f["ckv_w"], f.get("ckv_s"), f["ckv_b"])  # [Lc, 2*dim]
         k = K.qk_norm_rope(kv, 0, H, D, ca.norm_k.weight, None, None, self.eps)
         vt = K.v_transpose(kv[:, dim:], D, 2 * dim, Lc, H, D, context.dtype)
-        out = torch.empty((L_, dim), dtype=context.dtype, device=context.device)
-        K.attn_16(q, k, vt, None, out, D, dim)
-        return out
+        out = None if quant_out else torch.empty((L_, dim), dtype=context.dtype, device=context.device)
+        return K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
 
     def _block(self, i, blk, x, e0_B_6_D, cos, sin, context):
         """x: [B, L_loc, dim] (updated in place); e0 fp32 [B, 6, dim]; context [B, Lc, dim]."""
@@ -308,7 +310,8 @@ class WanModel(nn.Module):
         else:
             h = K.layernorm(x2, None, None, self.eps, scale=ec[1], shift=ec[0], rows_per_batch=L_loc)
             hs_ = [h[r] for r in rows]
-        ys = [self._self_attention(i, blk, hb, cos, sin, L_loc, dt) for hb in hs_]
+        qo = self.quant_linear and B == 1 and self.seq_parallel is None  # attention epilogue quantises for the o proj
+        ys = [self._self_attention(i, blk, hb, cos, sin, L_loc, dt, quant_out=qo) for hb in hs_]
         y = ys[0] if B == 1 else torch.cat(ys, 0)
         self._residual_lin_(x2, blk.self_attn.o, y, ec[2])
         # ---- cross attention ----
@@ -320,7 +323,7 @@ class WanModel(nn.Module):
                 xns = [xn[r] for r in rows]
         else:
             xns = [x2[r] for r in rows]
-        cs = [self._cross_attention(i, blk, xns[b], context[b]) for b in range(B)]
+        cs = [self._cross_attention(i, blk, xns[b], context[b], quant_out=self.quant_linear and B == 1) for b in range(B)]
         c = cs[0] if B == 1 else torch.cat(cs, 0)
         self._residual_lin_(x2, blk.cross_attn.o, c, None)
         # ---- FFN ----
