@@ -20,9 +20,8 @@
 // pre-transposed per 64-key block by td_v_transpose with the keys of each 16-group stored in
 // the order the MFMA B fragment delivers P (0-3,8-11 | 4-7,12-15), so a V^T A-fragment is one
 // ds_read_b128.  K and V^T tiles sit in LDS with the 16-B slot XOR-swizzled so the 16-lane
-// groups of ds_read_b128 are bank-conflict free; tiles are double buffered, the next tile's
-// global loads are issued before the current tile's MFMAs and written to LDS after them
-// (one barrier per K block).  Workgroup ids are XCD-remapped so one XCD's L2 serves one head's
+// groups of ds_read_b128 are bank-conflict free; tiles arrive by LDS-DMA into a ring of buffers (three for the INT8
+// kernel: fetch two iterations ahead of use; one barrier per K block).  Workgroup ids are XCD-remapped so one XCD's L2 serves one head's
 // K/V at a time.
 #include "td_common.h"
 
@@ -56,6 +55,7 @@ template <bool QK_I8> struct KTile {
     else return row * 256u + ((slot ^ (row & 15u)) << 4);
   }
 };
+typedef __attribute__((address_space(3))) void* lptr_a;
 #define VT_BYTES (128 * 128)
 #define A_MAGIC_I 0x4B400000
 #define A_MAGIC_F 12582912.0f
@@ -108,36 +108,47 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
   const int nsel = p.lut ? p.nsel : p.Kb;
   const float qs = QK_I8 ? p.q_s[(int64_t)h * p.Qb + qb] : 1.0f;
 
-  // ---- staging: K tile KT::NVEC vectors/thread, V^T tile 4 vectors/thread ----
-  uint4 sk0, sk1, sk2, sk3, sv0, sv1, sv2, sv3;
-  uint32_t koff[4], voff[4];
+  // ---- staging: LDS-DMA (buffer_load_dwordx4 ... lds), a ring of NBUF tile buffers ----
+  // A K/V tile fetch is a scattered 24-32 KB read (the LUT picks the blocks).  The INT8 kernel keeps THREE tiles in
+  // LDS (72 KB, two workgroups per CU) and fetches two iterations ahead; no staging VGPRs, no ds_write.  The LDS
+  // image of a DMA piece is lane-linear, so the bank swizzle of the read side is applied to the global address.
+  constexpr int NBUF = QK_I8 ? 3 : 2;
+  constexpr int KPIECES = KT::BYTES / 1024 / 4;  // per wave: 2 (int8 K) or 4 (16-bit K); V^T: 4
+  constexpr int NPIECES = KPIECES + 4;
+  constexpr uint32_t K_ROWB = QK_I8 ? 128u : 256u;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.k + (int64_t)h * p.k_rows_alloc * KT::ROWB), 0, 0x7fffffff, 0x00020000);
+  const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.vt + (int64_t)h * p.kb_alloc * VT_BYTES), 0, 0x7fffffff, 0x00020000);
+  int krow[KPIECES];       // row of the K tile this lane fetches, per piece
+  uint32_t kchunk[KPIECES], voffs[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int v = tid + 256 * i;
-    if (i < KT::NVEC) koff[i] = KT::off(v / (KT::ROWB / 16), v % (KT::ROWB / 16));
-    voff[i] = vt_off(v >> 3, v & 7);
+  for (int t = 0; t < KPIECES; ++t) {
+    const int c = wave_u + 4 * t;
+    if constexpr (QK_I8) { krow[t] = 8 * c + (lane >> 3); kchunk[t] = (uint32_t)(((lane & 7) ^ ((krow[t] >> 1) & 7)) * 16); }
+    else { krow[t] = 4 * c + (lane >> 4); kchunk[t] = (uint32_t)(((lane & 15) ^ (krow[t] & 15)) * 16); }
   }
-#define KLOAD1(i_, kb_)                                                                    \
-  if (i_ < KT::NVEC) {                                                                     \
-    const int v_ = tid + 256 * i_;                                                         \
-    int64_t kr_ = (int64_t)(kb_) * 64 + v_ / (KT::ROWB / 16);                              \
-    if (kr_ > p.Lk - 1) kr_ = p.Lk - 1;                                                    \
-    sk##i_ = *reinterpret_cast<const uint4*>((const char*)p.k +                            \
-                 ((int64_t)h * p.k_rows_alloc + kr_) * KT::ROWB + (v_ % (KT::ROWB / 16)) * 16);       \
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 8 * (wave_u + 4 * t) + (lane >> 3);
+    voffs[t] = (uint32_t)(row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
   }
-#define VLOAD1(i_, kb_)                                                                    \
-  sv##i_ = *reinterpret_cast<const uint4*>((const char*)p.vt +                             \
-               (((int64_t)h * p.kb_alloc + (kb_)) * VT_BYTES) + (int64_t)(tid + 256 * i_) * 16);
-#define TLOAD(kb_) KLOAD1(0, kb_) KLOAD1(1, kb_) KLOAD1(2, kb_) KLOAD1(3, kb_) \
-                   VLOAD1(0, kb_) VLOAD1(1, kb_) VLOAD1(2, kb_) VLOAD1(3, kb_)
-#define KSTORE1(i_, base_) if (i_ < KT::NVEC) *reinterpret_cast<uint4*>((base_) + koff[i_]) = sk##i_;
-#define VSTORE1(i_, base_) *reinterpret_cast<uint4*>((base_) + KT::BYTES + voff[i_]) = sv##i_;
-#define TSTORE(buf_)                                                                       \
-  {                                                                                        \
-    char* base_ = smem + (buf_) * BUF;                                                     \
-    KSTORE1(0, base_) KSTORE1(1, base_) KSTORE1(2, base_) KSTORE1(3, base_)                \
-    VSTORE1(0, base_) VSTORE1(1, base_) VSTORE1(2, base_) VSTORE1(3, base_)                \
+#define TISSUE(kb_, buf_)                                                                              \
+  {                                                                                                    \
+    char* base_ = smem + (buf_) * BUF;                                                                 \
+    _Pragma("unroll") for (int t = 0; t < KPIECES; ++t) {                                              \
+      int64_t kr_ = (int64_t)(kb_) * 64 + krow[t];                                                     \
+      if (kr_ > p.Lk - 1) kr_ = p.Lk - 1;                                                              \
+      const uint32_t vo_ = (uint32_t)kr_ * K_ROWB + kchunk[t]; /* (a temporary: an expression here loses the host stub) */ \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lptr_a)(base_ + (wave_u + 4 * t) * 1024), 16, \
+                                               vo_, 0, 0, 0);                                          \
+    }                                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lptr_a)(base_ + KT::BYTES + (wave_u + 4 * t) * 1024), 16, \
+                                               voffs[t], (kb_) * VT_BYTES, 0, 0);                      \
   }
+#define TWAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");
 
   v16f oacc[4];
 #pragma unroll
@@ -150,17 +161,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
   for (int r = 0; r < 16; ++r) magic16[r] = A_MAGIC_I;
   if constexpr (QK_I8) asm volatile("" : "+v"(magic16));  // loop-invariant C operand of the first MFMA of every chain
 
-  int kb_next = lut ? lut[0] : 0;
-  TLOAD(kb_next)
-  TSTORE(0)
+  // the Q fragments (plain loads) are older than every DMA piece, so the vmcnt waits below cover them too
+  TISSUE(lut ? lut[0] : 0, 0)
+  if (NBUF == 3 && nsel > 1) {
+    TISSUE(lut ? lut[1] : 1, 1)
+    if constexpr (NPIECES == 6) TWAIT(6) else TWAIT(8)
+  } else {
+    TWAIT(0)
+  }
   __syncthreads();
 
   for (int it = 0; it < nsel; ++it) {
-    const int cur = it & 1;
-    const int kb = kb_next;
-    if (it + 1 < nsel) {
-      kb_next = lut ? lut[it + 1] : it + 1;
-      TLOAD(kb_next)
+    const int cur = it % NBUF;
+    const int kb = lut ? lut[it] : it;
+    // fetch NBUF-1 tiles ahead into the buffer whose last readers passed the barrier at the end of iteration it-1
+    if (it + NBUF - 1 < nsel) {
+      const int nb_ = lut ? lut[it + NBUF - 1] : it + NBUF - 1;
+      TISSUE(nb_, (it + NBUF - 1) % NBUF)
     }
     const char* kt = smem + cur * BUF;
     const char* vtile = kt + KT::BYTES;
@@ -261,7 +278,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         oacc[c] = Mma16<PDT>::mma(vf, pv, oacc[c]);
       }
     }
-    if (it + 1 < nsel) TSTORE(cur ^ 1)
+    // tile it+1 must have landed (this wave's pieces; the barrier makes it everyone's); tile it+2 may stay in flight
+    if (NBUF == 3 && it + 2 < nsel) {
+      if constexpr (NPIECES == 6) TWAIT(6) else TWAIT(8)
+    } else {
+      TWAIT(0)
+    }
     __syncthreads();
   }
 
@@ -358,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 template <bool QK_I8, int PDT, int ODT>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
   auto kern = attn_kernel<QK_I8, PDT, ODT>;
-  constexpr int lds = 2 * (KTile<QK_I8>::BYTES + VT_BYTES);
+  constexpr int lds = (QK_I8 ? 3 : 2) * (KTile<QK_I8>::BYTES + VT_BYTES);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -259,16 +259,20 @@ extern "C" int td_sage_quant_pool(const void* x, const void* km, int dtype, int 
 //            16-bit key for the k-th largest value, then an ordered ballot compaction
 //            (ties at the threshold -> lowest index first) => ascending LUT.
 // ---------------------------------------------------------------------------------------
-#define TK_ROWS 16
+#define TK_ROWS 4
 #define TK_MAXKB 2048
+// One 256-thread workgroup per 4 pooled-Q rows of one head (768 workgroups at the Wan 480p shape: three per CU, so
+// the LDS-latency-bound dot products of one overlap the ballots of another — with 16 rows per workgroup the grid was
+// 192 single-wave-per-SIMD workgroups and the kernel ran 87 us for 1.5 M scores).  Wave w owns row w.
 template <int DT>
 __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restrict__ pq,
                                                        const uint16_t* __restrict__ pk,
                                                        int32_t* __restrict__ lut, int Qb, int Kb,
                                                        int Kb_alloc, int topk) {
   extern __shared__ __attribute__((aligned(16))) char smem_tk[];
-  float* qs = reinterpret_cast<float*>(smem_tk);                           // [16][128] fp32
-  uint16_t* sc = reinterpret_cast<uint16_t*>(smem_tk + TK_ROWS * 128 * 4);  // [16][Kb] sortable keys
+  float* qs = reinterpret_cast<float*>(smem_tk);                           // [4][128] fp32
+  uint16_t* sc = reinterpret_cast<uint16_t*>(smem_tk + TK_ROWS * 128 * 4);  // [4][Kb] sortable keys
+  uint4* ktile = reinterpret_cast<uint4*>(smem_tk + TK_ROWS * 128 * 4 + (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, row0 = blockIdx.x * TK_ROWS;
   for (int i = tid; i < TK_ROWS * 128; i += 256) {
@@ -278,10 +282,7 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
   }
   __syncthreads();
   // scores, 64 keys at a time: the 16 KB of pooled keys are fetched with fully coalesced 16-byte loads into LDS
-  // (rows padded to 272 B), then thread (key = tid & 63, row group = wave) accumulates 4 q rows x 128 d in the same
-  // fp32 fma order as a plain dot product.  (One thread per key reading its 256-B row straight from global touched
-  // 64 cache lines per load instruction: 87 us for 1.5 M scores.)
-  uint4* ktile = reinterpret_cast<uint4*>(smem_tk + TK_ROWS * 128 * 4 + (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15));
+  // (rows padded to 272 B); thread (key = lane, row = wave) accumulates 128 d in the fp32 fma order of a plain dot product
   for (int c0 = 0; c0 < Kb; c0 += 64) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -292,64 +293,61 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
     }
     __syncthreads();
     {
-      const int key = tid & 63, rg = wave * 4;
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+      float acc = 0.f;
+      const float* qrow = qs + wave * 128;
+#pragma unroll
       for (int d8 = 0; d8 < 16; ++d8) {
         float kf[8];
-        unpack8<DT>(ktile[key * 17 + d8], kf);
+        unpack8<DT>(ktile[lane * 17 + d8], kf);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float* qrow = qs + (rg + r) * 128 + d8 * 8;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[r] = fmaf(qrow[e], kf[e], acc[r]);
-        }
+        for (int e = 0; e < 8; ++e) acc = fmaf(qrow[d8 * 8 + e], kf[e], acc);
       }
-      if (c0 + key < Kb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          uint32_t b = f32_to_half_bits<DT>(acc[r]);
-          // order-preserving map of a 16-bit float to an unsigned key (larger value -> larger key)
-          b = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
-          sc[(rg + r) * Kb + c0 + key] = (uint16_t)b;
-        }
+      if (c0 + lane < Kb) {
+        uint32_t b = f32_to_half_bits<DT>(acc);
+        // order-preserving map of a 16-bit float to an unsigned key (larger value -> larger key)
+        b = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+        sc[wave * Kb + c0 + lane] = (uint16_t)b;
       }
     }
     __syncthreads();
   }
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = wave * 4 + rr;
-    if (row0 + r >= Qb) break;
-    const uint16_t* keys = sc + r * Kb;
-    // largest T with count(key >= T) >= topk
-    uint32_t lo = 0, hi = 0xffffu;  // invariant: count(>= lo) >= topk
-    while (lo < hi) {
-      const uint32_t mid = (lo + hi + 1) >> 1;
-      int cnt = 0;
-      for (int j = lane; j < Kb; j += 64) cnt += keys[j] >= mid ? 1 : 0;
-      cnt = (int)wave_sum((float)cnt);
-      if (cnt >= topk) lo = mid; else hi = mid - 1;
+  // selection (wave = row): every count is a sum of ballot popcounts — v_cmp + s_bcnt1, no cross-lane shuffles
+  const int r = wave;
+  if (row0 + r >= Qb) return;
+  const uint16_t* keys = sc + r * Kb;
+  const int nper = (Kb + 63) >> 6;
+  // largest T with count(key >= T) >= topk
+  uint32_t lo = 0, hi = 0xffffu;  // invariant: count(>= lo) >= topk
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1) >> 1;
+    int cnt = 0;
+    for (int t = 0; t < nper; ++t) {
+      const int j = t * 64 + lane;
+      cnt += __popcll(__ballot(j < Kb && keys[j] >= mid));
     }
-    const uint32_t T = lo;
-    int gt = 0;
-    for (int j = lane; j < Kb; j += 64) gt += keys[j] > T ? 1 : 0;
-    gt = (int)wave_sum((float)gt);
-    int need_eq = topk - gt;  // how many ties at T to take (lowest index first)
-    int32_t* out = lut + ((int64_t)h * Qb + row0 + r) * topk;
-    int written = 0, eq_seen = 0;
-    for (int j0 = 0; j0 < Kb; j0 += 64) {
-      const int j = j0 + lane;
-      const uint32_t kv = j < Kb ? keys[j] : 0;
-      const bool is_gt = j < Kb && kv > T;
-      const bool is_eq = j < Kb && kv == T;
-      const unsigned long long meq = __ballot(is_eq);
-      const int eq_before = __popcll(meq & ((1ull << lane) - 1ull));
-      const bool take = is_gt || (is_eq && (eq_seen + eq_before) < need_eq);
-      const unsigned long long mt = __ballot(take);
-      if (take) out[written + __popcll(mt & ((1ull << lane) - 1ull))] = j;
-      written += __popcll(mt);
-      eq_seen += __popcll(meq);
-    }
+    if (cnt >= topk) lo = mid; else hi = mid - 1;
+  }
+  const uint32_t T = lo;
+  int gt = 0;
+  for (int t = 0; t < nper; ++t) {
+    const int j = t * 64 + lane;
+    gt += __popcll(__ballot(j < Kb && keys[j] > T));
+  }
+  const int need_eq = topk - gt;  // how many ties at T to take (lowest index first)
+  int32_t* out = lut + ((int64_t)h * Qb + row0 + r) * topk;
+  int written = 0, eq_seen = 0;
+  for (int t = 0; t < nper; ++t) {
+    const int j = t * 64 + lane;
+    const uint32_t kv = j < Kb ? keys[j] : 0;
+    const bool is_gt = j < Kb && kv > T;
+    const bool is_eq = j < Kb && kv == T;
+    const unsigned long long meq = __ballot(is_eq);
+    const int eq_before = __popcll(meq & ((1ull << lane) - 1ull));
+    const bool take = is_gt || (is_eq && (eq_seen + eq_before) < need_eq);
+    const unsigned long long mt = __ballot(take);
+    if (take) out[written + __popcll(mt & ((1ull << lane) - 1ull))] = j;
+    written += __popcll(mt);
+    eq_seen += __popcll(meq);
   }
 }
 
