@@ -74,7 +74,20 @@ def _write(out, o_stride_h, o_stride_l, val):
     _strided(out, (H, L, D), (o_stride_h, o_stride_l, 1)).copy_(val)
 
 
-def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
+def _finish(o, out, o_stride_h, o_stride_l, add_t, quant_out):
+    """o [H, L, D] 16-bit (+ o_l, the 16-bit add of SLA/core.py:253) -> strided ``out`` or its block-quantised form."""
+    from oracle import ops_ref as O
+    if add_t is not None:
+        o = o + add_t
+    if quant_out:
+        H, L, D = o.shape
+        return O.quant_block128(o.permute(1, 0, 2).reshape(L, H * D).contiguous())
+    _write(out, o_stride_h, o_stride_l, o)
+    return out
+
+
+def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, add_t=None,
+            quant_out=False):
     H, L, D = q_i8.shape
     lk = k_i8.shape[1] if lk is None else lk
     kb = (lk + 63) // 64
@@ -82,21 +95,20 @@ def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale
     lutb = S.dense_lut(1, H, L, 128, 64)[..., :kb] if lut is None else lut[None].long()
     if lut is None:
         lutb = torch.arange(kb).expand(1, H, (L + 127) // 128, kb)
+    odt = out if isinstance(out, torch.dtype) else out.dtype
     o = S.sage_sparse_attn(q_i8[None], q_s[None], k_i8[None, :, :lk], k_s[None, :, :kb], v[None].float(), lutb,
-                           out_dtype=out.dtype)[0]
-    _write(out, o_stride_h, o_stride_l, o)
-    return out
+                           out_dtype=odt)[0]
+    return _finish(o, out, o_stride_h, o_stride_l, add_t, quant_out)
 
 
-def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None):
+def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, add_t=None, quant_out=False):
     H, L, D = q.shape
     lk = k.shape[1] if lk is None else lk
     kb = (lk + 63) // 64
     v = _v_from_tiles(vt, lk)
     lutb = torch.arange(kb).expand(1, H, (L + 127) // 128, kb) if lut is None else lut[None].long()
     o = S.sla_sparse_attn(q[None], k[None, :, :lk], v[None], lutb, 128, 64)[0]
-    _write(out, o_stride_h, o_stride_l, o)
-    return out
+    return _finish(o, out, o_stride_h, o_stride_l, add_t, quant_out)
 
 
 def sla_linear_kv_partial_f32(k, vt, kv_out=None, ks_out=None):
@@ -120,14 +132,21 @@ def sla_linear_kv(k, vt):
     return kv.to(k.dtype).transpose(-1, -2).contiguous(), ks.to(k.dtype)
 
 
-def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l):
-    H, L, D = q.shape
+def sla_linear_out_t(q, kv_t, ksum, wp, bp):
+    """o_l [H, L, D] in q's dtype (the HIP wrapper returns it in a lane-private layout; here the plain tensor —
+    only ``attn_*(add_t=...)`` of this module consumes it)."""
     dt = q.dtype
     cq = F.softmax(q, dim=-1).contiguous().to(dt)
     kvsum = kv_t.transpose(-1, -2).contiguous()
     o_l = (cq @ kvsum) / (1e-5 + (cq * ksum[:, None, :]).sum(dim=-1, keepdim=True))
     with torch.amp.autocast("cpu", dtype=dt):
         o_l = F.linear(o_l, wp, bp)
+    return o_l.to(dt)
+
+
+def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l):
+    H, L, D = q.shape
+    o_l = sla_linear_out_t(q, kv_t, ksum, wp, bp)
     view = _strided(out, (H, L, D), (o_stride_h, o_stride_l, 1))
     view.copy_(view + o_l)
     return out

@@ -185,3 +185,28 @@ def test_module_tree_matches_reference_checkpoint_keys():
         ref_keys = set(ref.state_dict().keys())
         ours_float = {k.replace(".int8_weight", ".weight") for k in keys if not k.endswith(".scale")}
         assert ref_keys <= ours_float | {k for k in ref_keys if "proj_l" in k}, ref_keys - ours_float
+
+
+def test_checkpoint_converter_key_contract():
+    """turbodiffusion_amd.convert: `net.` prefix / state_dict unwrapping / patch-embedding reshape of
+    modify_model.py:161-171, and float -> *-quant.pth key mapping (Int8Linear for every Linear under blocks except
+    proj_l) lands exactly on the model's own state-dict keys."""
+    from turbodiffusion_amd import convert as C
+    from turbodiffusion_amd.wan import WanModel
+    cfg = dict(dim=256, ffn_dim=512, num_heads=2, num_layers=2, in_dim=16, out_dim=16, text_dim=64, freq_dim=64)
+    sd = W.make_state_dict(cfg, 0)
+    wrapped = {"state_dict": {"net." + k: (v.reshape(-1) if k.startswith("patch_embedding") else v) for k, v in sd.items()}}
+    n = C.normalize_checkpoint(wrapped, sd["patch_embedding.weight"].shape, sd["patch_embedding.bias"].shape)
+    assert set(n) == set(sd) and n["patch_embedding.weight"].shape == sd["patch_embedding.weight"].shape
+    with torch.device("meta"):
+        net = WanModel(attention_type="sagesla", quant_linear=True, **cfg)
+    own = set(net.state_dict())
+    mapped = set()
+    for k, v in sd.items():
+        if C._is_block_linear_weight(k, v):
+            mapped |= {k[:-7] + ".int8_weight", k[:-7] + ".scale"}
+        else:
+            mapped.add(k)
+    assert mapped == own, (sorted(mapped - own)[:4], sorted(own - mapped)[:4])
+    assert not any("proj_l" in k and k.endswith("int8_weight") for k in mapped)
+    assert not C.is_quantized(sd) and C.is_quantized({"blocks.0.ffn.0.int8_weight": None})
