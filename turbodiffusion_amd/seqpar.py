@@ -65,6 +65,12 @@ class SeqParallel:
     def all_gather(self, t: torch.Tensor) -> torch.Tensor:
         """[...] -> [world, ...] (rank-major)."""
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            # single-GPU test rig (two ranks on one device, tests/test_gpu_seqpar.py): gloo gathers host memory
+            host = torch.empty(out.shape, dtype=t.dtype)
+            dist.all_gather_into_tensor(host.view(-1), t.contiguous().view(-1).cpu(), group=self.group)
+            out.copy_(host)
+            return out
         dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
         return out
 
