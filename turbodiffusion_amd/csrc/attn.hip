@@ -79,7 +79,12 @@ template <> struct Mma16<TD_BF16> {
 
 // QK_I8: int8 QK; PDT: dtype of P / V^T (and of q,k when !QK_I8); ODT: output dtype
 template <bool QK_I8, int PDT, int ODT>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
+// lut_all / ks_all / qs_all repeat p.lut / p.k_s / p.q_s as __restrict__ kernel arguments: only then are the per-iteration
+// LUT entry and K scale SCALAR loads (s_load, lgkmcnt).  As vector loads they drag an s_waitcnt vmcnt(0) into the loop,
+// which waits for every K/V tile in flight and undoes the fetch-ahead.
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p, const int32_t* __restrict__ lut_all,
+                                                      const float* __restrict__ ks_all,
+                                                      const float* __restrict__ qs_all) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef KTile<QK_I8> KT;
   constexpr int BUF = KT::BYTES + VT_BYTES;
@@ -104,9 +109,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     for (int kc = 0; kc < NQ; ++kc) qf[kc] = *reinterpret_cast<const uint4*>(qp + kc * 32 + hi * 16);
   }
 
-  const int32_t* lut = p.lut ? p.lut + ((int64_t)h * p.Qb + qb) * p.nsel : nullptr;
-  const int nsel = p.lut ? p.nsel : p.Kb;
-  const float qs = QK_I8 ? p.q_s[(int64_t)h * p.Qb + qb] : 1.0f;
+  const bool has_lut = lut_all != nullptr;
+  const int32_t* __restrict__ lut = lut_all + ((int64_t)h * p.Qb + qb) * (has_lut ? p.nsel : 0);  // never read when !has_lut
+  const int nsel = has_lut ? p.nsel : p.Kb;
+  const float qs = QK_I8 ? qs_all[(int64_t)h * p.Qb + qb] : 1.0f;
 
   // ---- staging: LDS-DMA (buffer_load_dwordx4 ... lds), a ring of NBUF tile buffers ----
   // A K/V tile fetch is a scattered 24-32 KB read (the LUT picks the blocks).  The INT8 kernel keeps THREE tiles in
@@ -162,9 +168,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
   if constexpr (QK_I8) asm volatile("" : "+v"(magic16));  // loop-invariant C operand of the first MFMA of every chain
 
   // the Q fragments (plain loads) are older than every DMA piece, so the vmcnt waits below cover them too
-  TISSUE(lut ? lut[0] : 0, 0)
+  TISSUE(has_lut ? lut[0] : 0, 0)
   if (NBUF == 3 && nsel > 1) {
-    TISSUE(lut ? lut[1] : 1, 1)
+    TISSUE(has_lut ? lut[1] : 1, 1)
     if constexpr (NPIECES == 6) TWAIT(6) else TWAIT(8)
   } else {
     TWAIT(0)
@@ -173,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 
   for (int it = 0; it < nsel; ++it) {
     const int cur = it % NBUF;
-    const int kb = lut ? lut[it] : it;
+    const int kb = has_lut ? lut[it] : it;
     // fetch NBUF-1 tiles ahead into the buffer whose last readers passed the barrier at the end of iteration it-1
     if (it + NBUF - 1 < nsel) {
-      const int nb_ = lut ? lut[it + NBUF - 1] : it + NBUF - 1;
+      const int nb_ = has_lut ? lut[it + NBUF - 1] : it + NBUF - 1;
       TISSUE(nb_, (it + NBUF - 1) % NBUF)
     }
     const char* kt = smem + cur * BUF;
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     float s[2][16];
     float mult = p.scale_log2;
     if constexpr (QK_I8) {
-      mult = (qs * p.k_s[(int64_t)h * p.kb_alloc + kb]) * p.scale_log2;
+      mult = (qs * ks_all[(int64_t)h * p.kb_alloc + kb]) * p.scale_log2;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         v16i acc = magic16;
@@ -388,7 +394,7 @@ static int launch_attn(const AttnParams& p, hipStream_t st) {
     attr_set = true;
   }
   const unsigned nwg = (unsigned)p.H * (unsigned)p.Qb;
-  kern<<<nwg, 256, lds, st>>>(p);
+  kern<<<nwg, 256, lds, st>>>(p, p.lut, p.k_s, p.q_s);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
