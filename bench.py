@@ -30,6 +30,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BASELINE_VIDEOS_PER_S = 1.0 / 1.9  # README.md:32,298 — TurboWan2.1-T2V-1.3B-480P, 1x RTX 5090
+# published TurboDiffusion latencies (s per video, 1x RTX 5090) for the other model/resolution pairs
+PUBLISHED_S = {("Wan2.1-1.3B", "480p"): 1.9, ("Wan2.1-14B", "480p"): 9.9, ("Wan2.1-14B", "720p"): 24.0,
+               ("Wan2.2-A14B", "720p"): 38.0}
 HBM_PEAK = 8.0e12                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 I8_PEAK = 5.0e15                   # dense INT8 MFMA (= dense FP8 rate), MI355X_MICROARCH.md
 RES = {"480p": (832, 480), "720p": (1280, 720)}
@@ -250,15 +253,17 @@ def main():
         if roof is None:
             roof = roof_attn
         res = {
-            "metric": "end-to-end videos/sec (4-step rCM denoising loop, Wan2.1-1.3B 480p)",
+            "metric": f"end-to-end videos/sec (4-step rCM denoising loop, {args.model} {args.res})",
             "value": value, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per_video * 1e3, "dit_step_ms": per_video * 1e3 / args.num_steps,
             "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": (value / BASELINE_VIDEOS_PER_S) if (args.workload == "turbo" and args.model == "Wan2.1-1.3B"
-                                                              and args.res == "480p" and not args.layers) else None,
+            "vs_baseline": (value * PUBLISHED_S[(args.model, args.res)]) if (
+                args.workload == "turbo" and (args.model, args.res) in PUBLISHED_S and not args.layers
+                and args.num_steps == 4) else None,
             "dtype": "int8 (W8A8 linears, QK^T) + fp16 PV + bf16 activations" if wl["quant_linear"] else "bf16 (+int8 QK^T)",
             "data": "synthetic (seeded N(0,1) latents/text embedding, random-init weights of the named architecture)",
-            "config": {"workload": wl["desc"], "model": args.model, "resolution": args.res, "tokens": L_tok,
+            "config": {"workload": wl["desc"].replace("Wan2.1-T2V-1.3B 480p", f"{args.model} {args.res}").replace(
+                           "TurboWan2.1-T2V-1.3B-480P", f"Turbo{args.model}-{args.res.upper()}"), "model": args.model, "resolution": args.res, "tokens": L_tok,
                        "sampler_steps": args.num_steps, "sla_topk": args.topk,
                        "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (RCCL all-gather of K/V)"},
             "roofline": roof, "roofline_attention": roof_attn,
