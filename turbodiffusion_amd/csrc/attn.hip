@@ -82,7 +82,7 @@ template <bool QK_I8, int PDT, int ODT>
 // lut_all / ks_all / qs_all repeat p.lut / p.k_s / p.q_s as __restrict__ kernel arguments: only then are the per-iteration
 // LUT entry and K scale SCALAR loads (s_load, lgkmcnt).  As vector loads they drag an s_waitcnt vmcnt(0) into the loop,
 // which waits for every K/V tile in flight and undoes the fetch-ahead.
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p, const int32_t* __restrict__ lut_all,
+__global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, const int32_t* __restrict__ lut_all,
                                                       const float* __restrict__ ks_all,
                                                       const float* __restrict__ qs_all) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p, const int32_
   // A K/V tile fetch is a scattered 24-32 KB read (the LUT picks the blocks).  The INT8 kernel keeps THREE tiles in
   // LDS (72 KB, two workgroups per CU) and fetches two iterations ahead; no staging VGPRs, no ds_write.  The LDS
   // image of a DMA piece is lane-linear, so the bank swizzle of the read side is applied to the global address.
-  constexpr int NBUF = QK_I8 ? 3 : 2;
+  constexpr int NBUF = 2;
   constexpr int KPIECES = KT::BYTES / 1024 / 4;  // per wave: 2 (int8 K) or 4 (16-bit K); V^T: 4
   constexpr int NPIECES = KPIECES + 4;
   constexpr uint32_t K_ROWB = QK_I8 ? 128u : 256u;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p, const int32_
 template <bool QK_I8, int PDT, int ODT>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
   auto kern = attn_kernel<QK_I8, PDT, ODT>;
-  constexpr int lds = (QK_I8 ? 3 : 2) * (KTile<QK_I8>::BYTES + VT_BYTES);
+  constexpr int lds = 2 * (KTile<QK_I8>::BYTES + VT_BYTES);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
