@@ -6,9 +6,13 @@
 
 A "step" is one whole video: the 4 DiT forwards + sampler updates on latents already resident in
 HBM (text encoding / VAE are outside the metric, reference README.md:207).  For N > 1 launch with
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``: the token sequence of
-every DiT step is sharded over the ranks (turbodiffusion_amd.seqpar), so total work is fixed
-("strong" scaling).  Rank 0 prints ONE JSON line.
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.  The N ranks form N/S
+sequence-parallel groups of S GPUs (``--sp S``, default 2): inside a group the token sequence of every DiT step is
+sharded (turbodiffusion_amd.seqpar: one packed RCCL all-gather of the quantised K/V state per self-attention layer),
+the groups generate independent videos — per-GPU work is fixed as N grows ("weak" scaling), ``value`` is the
+whole-job videos/s.  ``--sp N`` shards ONE video over all N GPUs (latency mode, "strong" scaling): at the 1.3B/480p
+shape a rank then owns 4096 tokens — 96-560 GEMM tiles for 256 CUs — so throughput scales far worse than in groups
+of 2.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
   turbo    TurboWan2.1-T2V-1.3B-480P as published: SageSLA top-k 0.1 + W8A8 linears + fused norms
@@ -137,6 +141,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel eagerly instead of replaying "
                     "one captured hipGraph per DiT forward (N=1 only; N>1 is always eager)")
+    ap.add_argument("--sp", type=int, default=0, help="sequence-parallel group size (GPUs sharing one video); "
+                    "0 = 2 when N >= 2.  N/sp groups run independent videos")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("TD_GEMM_VARIANT", "0")),
                     help="W8A8 GEMM kernel selection knob (0 = automatic); all variants are bit-identical")
     args = ap.parse_args()
@@ -148,23 +154,35 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
+    sp = args.sp if args.sp > 0 else (2 if world >= 2 else 1)
+    assert world % sp == 0, f"--sp {sp} must divide the number of GPUs ({world})"
+    dp = world // sp
+    sp_group, my_group = None, rank // sp
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
+        if sp > 1:
+            if dp == 1:
+                sp_group = dist.group.WORLD
+            else:  # every rank creates every group (collective call), keeps its own
+                for gi in range(dp):
+                    grp = dist.new_group(ranks=list(range(gi * sp, (gi + 1) * sp)))
+                    if gi == my_group:
+                        sp_group = grp
 
     from turbodiffusion_amd import kernels as K
     from turbodiffusion_amd.sampler import rcm_sample
 
     wl = WORKLOADS[args.workload]
     net, cfg = build_model(args.model, wl, dev, args.topk, args.layers or None)
-    if world > 1:
+    if sp > 1:
         from turbodiffusion_amd import seqpar
-        seqpar.enable(net, dist.group.WORLD)
+        seqpar.enable(net, sp_group)
 
     w, h = RES[args.res]
     lat_shape = (1, 16, 21, h // 8, w // 8)  # 81 frames -> 21 latent frames, VAE 8x spatial
     L_tok = 21 * (h // 16) * (w // 16)
-    g = torch.Generator(device=dev).manual_seed(0)
+    g = torch.Generator(device=dev).manual_seed(my_group)  # same stream on the ranks of a group, another video per group
     init_noise = torch.randn(lat_shape, dtype=torch.float32, device=dev, generator=g)
     text = torch.randn(1, 512, cfg.get("text_dim", 4096), device=dev, generator=g).bfloat16()
     y = None
@@ -175,7 +193,7 @@ def main():
 
     if args.gemm_variant:
         K.set_tuning(K.TUNE_GEMM_VARIANT, args.gemm_variant)
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (sp == 1) and not args.no_graph  # (the RCCL all-gathers of a sequence-parallel step stay eager)
     run_net = net
     if use_graph:
         from turbodiffusion_amd.graph import GraphedModel
@@ -220,8 +238,8 @@ def main():
     assert torch.isfinite(out).all(), "non-finite latents"
 
     if rank == 0:
-        per_video = elapsed / args.steps
-        value = 1.0 / per_video
+        per_video = elapsed / args.steps   # per sequence-parallel group
+        value = dp / per_video             # whole job: dp groups generate dp videos per step
         summ = timer.summary()
         roof = None
         if "td_gemm_w8a8" in summ and wl["quant_linear"]:
@@ -256,7 +274,7 @@ def main():
             "metric": f"end-to-end videos/sec (4-step rCM denoising loop, {args.model} {args.res})",
             "value": value, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per_video * 1e3, "dit_step_ms": per_video * 1e3 / args.num_steps,
-            "higher_is_better": True, "scaling": "strong",
+            "higher_is_better": True, "scaling": "strong" if (args.sp > 0 and dp == 1 and world > 1) else "weak",
             "vs_baseline": (value * PUBLISHED_S[(args.model, args.res)]) if (
                 args.workload == "turbo" and (args.model, args.res) in PUBLISHED_S and not args.layers
                 and args.num_steps == 4) else None,
@@ -265,7 +283,10 @@ def main():
             "config": {"workload": wl["desc"].replace("Wan2.1-T2V-1.3B 480p", f"{args.model} {args.res}").replace(
                            "TurboWan2.1-T2V-1.3B-480P", f"Turbo{args.model}-{args.res.upper()}"), "model": args.model, "resolution": args.res, "tokens": L_tok,
                        "sampler_steps": args.num_steps, "sla_topk": args.topk,
-                       "parallelism": "single GPU" if world == 1 else f"sequence-parallel x{world} (RCCL all-gather of K/V)"},
+                       "global_batch": dp,
+                       "parallelism": "single GPU" if world == 1 else (
+                           f"dp{dp} x sp{sp}: {dp} independent videos, each sharded by sequence over {sp} GPUs "
+                           f"(RCCL all-gather of the quantised K/V per layer)" if sp > 1 else f"dp{dp}: {dp} independent videos")},
             "roofline": roof, "roofline_attention": roof_attn,
             "launch_mode": ("hipGraph replay, one graph per DiT forward; kernel events from one eager video after "
                             "the timed region" if use_graph else "eager enqueue; kernel events inside the timed region"),
