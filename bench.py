@@ -6,13 +6,18 @@
 
 A "step" is one whole video: the 4 DiT forwards + sampler updates on latents already resident in
 HBM (text encoding / VAE are outside the metric, reference README.md:207).  For N > 1 launch with
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.  The N ranks form N/S
-sequence-parallel groups of S GPUs (``--sp S``, default 2): inside a group the token sequence of every DiT step is
-sharded (turbodiffusion_amd.seqpar: one packed RCCL all-gather of the quantised K/V state per self-attention layer),
-the groups generate independent videos — per-GPU work is fixed as N grows ("weak" scaling), ``value`` is the
-whole-job videos/s.  ``--sp N`` shards ONE video over all N GPUs (latency mode, "strong" scaling): at the 1.3B/480p
-shape a rank then owns 4096 tokens — 96-560 GEMM tiles for 256 CUs — so throughput scales far worse than in groups
-of 2.  Rank 0 prints ONE JSON line.
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
+
+Multi-GPU (one process per GPU, RCCL).  The unit of work is a video and videos are independent, so the headline
+number shards VIDEOS: every rank runs the single-GPU path (hipGraph replay) on its own seeded video, no data-path
+collective, per-GPU work fixed as N grows ("weak" scaling), ``value`` = N videos / max-over-ranks time.  Sharding
+ONE video by sequence (turbodiffusion_amd.seqpar: one packed RCCL all-gather of the quantised K/V state per
+self-attention layer) is the LATENCY mode: per layer every rank must receive 3 B per token-channel of the other
+ranks' K/V over xGMI (C1: 151 MB/layer in total = 1.0 ms at sp=2 over one link, 0.25 ms at sp=8 over seven) beside
+3.3 ms / sp of compute, so it can never reach the videos/s of N independent replicas.  After the timed region the
+same run therefore measures that mode once over all N ranks and reports it in ``sequence_parallel`` (ms per video,
+DiT-step ms, speed-up over one GPU); ``--sp S`` instead makes the timed region itself run N/S sequence-parallel
+groups of S GPUs.  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
   turbo    TurboWan2.1-T2V-1.3B-480P as published: SageSLA top-k 0.1 + W8A8 linears + fused norms
@@ -140,9 +145,12 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug: override num_layers (INVALID as a bench number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel eagerly instead of replaying "
-                    "one captured hipGraph per DiT forward (N=1 only; N>1 is always eager)")
-    ap.add_argument("--sp", type=int, default=0, help="sequence-parallel group size (GPUs sharing one video); "
-                    "0 = 2 when N >= 2.  N/sp groups run independent videos")
+                    "one captured hipGraph per DiT forward (sequence-parallel runs are always eager)")
+    ap.add_argument("--sp", type=int, default=1, help="sequence-parallel group size of the TIMED region (GPUs sharing "
+                    "one video); N/sp groups run independent videos.  Default 1: N independent videos")
+    ap.add_argument("--no-sp-leg", action="store_true", help="N > 1: skip the sequence-parallel latency measurement "
+                    "that follows the timed region")
+    ap.add_argument("--sp-leg-timeout", type=float, default=240.0)
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("TD_GEMM_VARIANT", "0")),
                     help="W8A8 GEMM kernel selection knob (0 = automatic); all variants are bit-identical")
     args = ap.parse_args()
@@ -151,16 +159,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # TD_BENCH_BACKEND=gloo: development rig only — several ranks on the GPUs that exist (one, on the test box), gloo
+    # collectives through host memory; exercises every line of the multi-rank path without an 8-GPU node
+    backend = os.environ.get("TD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    sp = args.sp if args.sp > 0 else (2 if world >= 2 else 1)
+    sp = max(1, args.sp)
     assert world % sp == 0, f"--sp {sp} must divide the number of GPUs ({world})"
     dp = world // sp
     sp_group, my_group = None, rank // sp
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         if sp > 1:
             if dp == 1:
                 sp_group = dist.group.WORLD
@@ -183,6 +199,7 @@ def main():
     lat_shape = (1, 16, 21, h // 8, w // 8)  # 81 frames -> 21 latent frames, VAE 8x spatial
     L_tok = 21 * (h // 16) * (w // 16)
     g = torch.Generator(device=dev).manual_seed(my_group)  # same stream on the ranks of a group, another video per group
+    # (the seed only changes the synthetic latents; every rank does identical work)
     init_noise = torch.randn(lat_shape, dtype=torch.float32, device=dev, generator=g)
     text = torch.randn(1, 512, cfg.get("text_dim", 4096), device=dev, generator=g).bfloat16()
     y = None
@@ -232,10 +249,58 @@ def main():
         eager_elapsed = time.perf_counter() - t1
         K.set_timer(None)
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
     assert torch.isfinite(out).all(), "non-finite latents"
+
+    # ---- latency mode: ONE video sharded by sequence over all N ranks (RCCL all-gathers over xGMI), measured after
+    #      the timed region; a watchdog bounds it so that a collective that never returns cannot cost the headline line
+    sp_leg, sp_hung = None, False
+    if world > 1 and sp == 1 and not args.no_sp_leg:
+        import threading
+        sp_leg = {}
+
+        def run_leg():
+            try:
+                torch.cuda.set_device(local)
+                from turbodiffusion_amd import seqpar
+                g2 = torch.Generator(device=dev).manual_seed(0)   # identical latents on every rank
+                noise2 = torch.randn(lat_shape, dtype=torch.float32, device=dev, generator=g2)
+                text2 = torch.randn(1, 512, cfg.get("text_dim", 4096), device=dev, generator=g2).bfloat16()
+                y2 = None
+                if y is not None:
+                    y2 = y.clone()
+                    y2[:, 4:] = torch.randn(1, 16, *lat_shape[2:], device=dev, generator=g2)
+                seqpar.enable(net, dist.group.WORLD)
+                try:
+                    def video():
+                        return rcm_sample(net, noise2, text2, num_steps=args.num_steps, generator=g2, y=y2)
+                    video()                       # warm-up: RCCL channels for the all-gather sizes, allocator
+                    sync()
+                    n_v = 2
+                    t2 = time.perf_counter()
+                    for _ in range(n_v):
+                        o2 = video()
+                    sync()
+                    dt2 = (time.perf_counter() - t2) / n_v
+                    assert torch.isfinite(o2).all(), "non-finite latents (sequence parallel)"
+                finally:
+                    seqpar.disable(net)
+                sp_leg.update({"ranks": world, "ms_per_video": dt2 * 1e3, "dit_step_ms": dt2 * 1e3 / args.num_steps,
+                               "videos_per_s": 1.0 / dt2, "speedup_vs_one_gpu": (elapsed / args.steps) / dt2,
+                               "videos_timed": n_v, "launch_mode": "eager enqueue",
+                               "collective": "one packed all-gather of int8 K | fp16 V^T | scales | pooled K | linear-branch "
+                                             "partials per self-attention layer + one of the head output per step"})
+            except Exception as e:  # reported, never fatal for the headline number
+                sp_leg["error"] = repr(e)
+
+        th = threading.Thread(target=run_leg, daemon=True)
+        th.start()
+        th.join(args.sp_leg_timeout)
+        if th.is_alive():
+            sp_hung = True
+            sp_leg = {"error": f"no completion within {args.sp_leg_timeout:.0f} s"}
 
     if rank == 0:
         per_video = elapsed / args.steps   # per sequence-parallel group
@@ -274,7 +339,7 @@ def main():
             "metric": f"end-to-end videos/sec (4-step rCM denoising loop, {args.model} {args.res})",
             "value": value, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per_video * 1e3, "dit_step_ms": per_video * 1e3 / args.num_steps,
-            "higher_is_better": True, "scaling": "strong" if (args.sp > 0 and dp == 1 and world > 1) else "weak",
+            "higher_is_better": True, "scaling": "strong" if (dp == 1 and world > 1) else "weak",
             "vs_baseline": (value * PUBLISHED_S[(args.model, args.res)]) if (
                 args.workload == "turbo" and (args.model, args.res) in PUBLISHED_S and not args.layers
                 and args.num_steps == 4) else None,
@@ -293,6 +358,8 @@ def main():
         }
         if eager_elapsed is not None:
             res["eager_videos_per_s"] = 1.0 / eager_elapsed
+        if sp_leg is not None:
+            res["sequence_parallel"] = sp_leg
         if args.layers:
             res["config"]["DEBUG_num_layers_override"] = args.layers
         if world == 1 and not args.no_cpu_baseline:
@@ -302,6 +369,9 @@ def main():
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
+        if sp_hung or (sp_leg is not None and "error" in sp_leg):
+            sys.stdout.flush()
+            os._exit(0)   # ranks may be stuck inside a collective: leave without a teardown handshake
         dist.destroy_process_group()
 
 

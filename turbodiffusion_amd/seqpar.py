@@ -62,17 +62,21 @@ class SeqParallel:
         s, e = self.plan(x.shape[1])
         return x[:, s:e].contiguous(), cos[s:e].contiguous(), sin[s:e].contiguous()
 
-    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
-        """[...] -> [world, ...] (rank-major)."""
+    def all_gather(self, t: torch.Tensor, async_op: bool = False):
+        """[...] -> [world, ...] (rank-major).  ``async_op``: returns (out, work); with RCCL the gather runs on the
+        communicator's own stream and ``work.wait()`` makes the compute stream wait for it, so kernels enqueued in
+        between overlap the transfer."""
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        work = None
         if t.is_cuda and dist.get_backend(self.group) == "gloo":
             # single-GPU test rig (two ranks on one device, tests/test_gpu_seqpar.py): gloo gathers host memory
             host = torch.empty(out.shape, dtype=t.dtype)
             dist.all_gather_into_tensor(host.view(-1), t.contiguous().view(-1).cpu(), group=self.group)
             out.copy_(host)
-            return out
-        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
-        return out
+        else:
+            work = dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group,
+                                               async_op=async_op)
+        return (out, work) if async_op else out
 
     def gather_tokens(self, out_loc, L):
         """[B, L_loc, C] -> [B, L, C] on every rank (cat_outputs_cp)."""
@@ -149,7 +153,14 @@ class SeqParallel:
             slot("kv", torch.float32, (H, D, D)).copy_(kv32)
             slot("kss", torch.float32, (H, D)).copy_(ks32)
 
-        allb = self.all_gather(pack)  # [W, bytes]
+        allb, work = self.all_gather(pack, async_op=True)  # [W, bytes]; in flight while the Q side is prepared
+        pq = q_q = q_s = None
+        if sage:
+            pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
+        elif not dense:
+            pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
+        if work is not None:
+            work.wait()
 
         def gathered(name, dtype, shape):  # [W, *shape] strided VIEW of one field (no copy)
             n = sizes[name]
@@ -171,13 +182,11 @@ class SeqParallel:
             pk_all = seq_major(gathered("pk", dt, (H, kbp, D)))                    # [H, W*kbp, D]
             topk = min(kb_tot, int(topk_ratio * kb_tot))
         if sage:
-            pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
             if not dense:
                 lut = ops.sla_topk(pq, pk_all, topk, kb=kb_tot)
             ops.attn_i8(q_q, q_s, k_all, ks_all, vt_all, lut, out, o_stride_h, o_stride_l, lk=L)
         else:
             if not dense:
-                pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
                 lut = ops.sla_topk(pq, pk_all, topk, kb=kb_tot)
             ops.attn_16(q, k_all, vt_all, lut, out, o_stride_h, o_stride_l, lk=L)
         if linear:
