@@ -73,7 +73,7 @@ def test_gemm_w8a8(K, m, n, k, bias, gelu):
                                    (9000, 2304, 256)])
 @pytest.mark.parametrize("bias,gelu", [(False, False), (True, True)])
 def test_gemm_variants_bit_identical(K, m, n, k, bias, gelu):
-    """128x128-tile kernel, the three 256x256-tile LDS-DMA kernels and the oracle: same bits (ragged M and N tails)."""
+    """128x128-tile kernel, the four 256x256-tile LDS-DMA kernels and the oracle: same bits (ragged M and N tails)."""
     g = torch.Generator().manual_seed(m + n + k)
     xq = torch.randint(-128, 128, (m, k), generator=g, dtype=torch.int8)
     wq = torch.randint(-128, 128, (n, k), generator=g, dtype=torch.int8)
@@ -81,7 +81,7 @@ def test_gemm_variants_bit_identical(K, m, n, k, bias, gelu):
     ws = torch.rand((n + 127) // 128, k // 128, generator=g) * 0.02 + 1e-3
     b = (torch.randn(n, generator=g) * 0.1).to(torch.bfloat16) if bias else None
     outs = []
-    for var in (1, 2, 3, 4):
+    for var in (1, 2, 3, 4, 5):
         K.set_tuning(K.TUNE_GEMM_VARIANT, var)
         try:
             outs.append(K.gemm_w8a8(xq.to(DEV), xs.to(DEV), wq.to(DEV), ws.to(DEV), torch.bfloat16,
@@ -97,7 +97,8 @@ def test_gemm_variants_bit_identical(K, m, n, k, bias, gelu):
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 1536, 384), (3000, 8960, 256), (300, 272, 256), (1111, 1552, 1280),
                                    (77, 128, 128)])
 @pytest.mark.parametrize("bias,gelu", [(True, True), (False, False), (True, False)])
-def test_gemm_fused_output_quant_bit_exact(K, m, n, k, bias, gelu):
+@pytest.mark.parametrize("variant", [4, 5])
+def test_gemm_fused_output_quant_bit_exact(K, m, n, k, bias, gelu, variant):
     """td_gemm_w8a8_quant == td_quant_i8_block128(td_gemm_w8a8(...)): codes and scales bit for bit, incl. ragged
     M / N tails (zero-filled like the stand-alone quantiser) and realistic value ranges."""
     x = act_like(m, k, torch.bfloat16, seed=m + n + k)
@@ -107,14 +108,19 @@ def test_gemm_fused_output_quant_bit_exact(K, m, n, k, bias, gelu):
     wq, ws = K.quant_i8_block128(w.to(DEV))
     y = K.gemm_w8a8(xq, xs, wq, ws, torch.bfloat16, bias=b, gelu_tanh=gelu)
     q_ref, s_ref = K.quant_i8_block128(y)
-    q, s = K.gemm_w8a8_quant(xq, xs, wq, ws, torch.bfloat16, bias=b, gelu_tanh=gelu)
+    K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
+    try:
+        q, s = K.gemm_w8a8_quant(xq, xs, wq, ws, torch.bfloat16, bias=b, gelu_tanh=gelu)
+    finally:
+        K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
     assert torch.equal(s, s_ref), "scales"
     assert torch.equal(q, q_ref), f"codes differ at {(q != q_ref).sum().item()} positions"
 
 
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 1536, 384), (300, 264, 256), (1111, 1544, 1280), (4096, 1536, 1536)])
 @pytest.mark.parametrize("bias,gated", [(True, True), (True, False), (False, True)])
-def test_gemm_fused_residual_bit_exact(K, m, n, k, bias, gated):
+@pytest.mark.parametrize("variant", [4, 5])
+def test_gemm_fused_residual_bit_exact(K, m, n, k, bias, gated, variant):
     """td_gemm_w8a8_residual == td_gated_residual(x, td_gemm_w8a8(...), gate) bit for bit (ragged M / N tails)."""
     g = torch.Generator().manual_seed(m + n)
     a = act_like(m, k, torch.bfloat16, seed=m + n + k)
@@ -125,7 +131,11 @@ def test_gemm_fused_residual_bit_exact(K, m, n, k, bias, gated):
     aq, as_ = K.quant_i8_block128(a.to(DEV))
     wq, ws = K.quant_i8_block128(w.to(DEV))
     ref = K.gated_residual_(x0.clone(), K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b), gate)
-    out = K.gemm_w8a8_residual_(x0.clone(), aq, as_, wq, ws, bias=b, gate=gate)
+    K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
+    try:
+        out = K.gemm_w8a8_residual_(x0.clone(), aq, as_, wq, ws, bias=b, gate=gate)
+    finally:
+        K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
     assert torch.equal(out, ref), f"differ at {(out != ref).sum().item()} positions"
 
 

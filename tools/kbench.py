@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from turbodiffusion_amd import kernels as K  # noqa: E402
 
 HBM, I8, F16 = 8.0e12, 5.0e15, 2.5e15
-GEMM_VARIANTS = (1, 2, 3, 4)
+GEMM_VARIANTS = (1, 2, 3, 4, 5)
 
 
 def timeit(fn, iters, warm=3):

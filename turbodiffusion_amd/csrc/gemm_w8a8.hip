@@ -210,6 +210,10 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
     TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 4 needs ldd %% 8 == 0");
     return td_gemm_w8a8_fi(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
   }
+  if (variant == 5) {  // 32x32x32-MFMA twin of variant 4 (gemm_w8a8_m32.hip)
+    TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 5 needs ldd %% 8 == 0");
+    return td_gemm_w8a8_m32(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
+  }
   if (variant == 3) {
     TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 3 needs ldd %% 8 == 0");
     return td_gemm_w8a8_pp(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
@@ -241,6 +245,8 @@ extern "C" int td_gemm_w8a8_quant(const int8_t* a, const float* a_s, const int8_
   TD_REQUIRE(epilogue == TD_EPI_NONE || epilogue == TD_EPI_GELU_TANH, TD_ERR_UNSUPPORTED,
              "td_gemm_w8a8_quant: epilogue %d", epilogue);
   if (m == 0 || n == 0) return TD_OK;
+  if (td_tuning(TD_TUNE_GEMM_VARIANT) == 5)
+    return td_gemm_w8a8_m32_q(a, a_s, b, b_s, bias, d_q, d_s, act_dtype, epilogue, m, n, k, (hipStream_t)stream);
   return td_gemm_w8a8_fi_q(a, a_s, b, b_s, bias, d_q, d_s, act_dtype, epilogue, m, n, k, (hipStream_t)stream);
 }
 
@@ -255,5 +261,7 @@ extern "C" int td_gemm_w8a8_residual(const int8_t* a, const float* a_s, const in
   TD_REQUIRE(n % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_residual: n=%lld must be a multiple of 8", (long long)n);
   TD_REQUIRE(ldx >= n && ldx % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_residual: bad ldx=%lld", (long long)ldx);
   if (m == 0 || n == 0) return TD_OK;
+  if (td_tuning(TD_TUNE_GEMM_VARIANT) == 5)
+    return td_gemm_w8a8_m32_res(a, a_s, b, b_s, bias, x, gate, dtype, m, n, k, ldx, (hipStream_t)stream);
   return td_gemm_w8a8_fi_res(a, a_s, b, b_s, bias, x, gate, dtype, m, n, k, ldx, (hipStream_t)stream);
 }
