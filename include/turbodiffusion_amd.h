@@ -119,9 +119,10 @@ int td_layernorm(const void* x, int in_dtype, const float* w, const float* b, co
 
 /* ---- a6 + a7 -> a16 fused: LayerNorm (+ affine, + AdaLN modulate) whose 16-bit result is block-quantised for the
  * Int8Linear that consumes it: q int8 [m,n], qs f32 [ceil(m/128), ceil(n/128)] == td_quant_i8_block128(td_layernorm(...))
- * bit for bit (x, and the intermediate, in `dtype` = f16|bf16).  Requires n % 8 == 0 and n <= 1536. */
+ * bit for bit (x, and the intermediate, in `dtype` = f16|bf16).  stats_ws: caller-owned scratch of 2*m floats (the rows'
+ * mean / rstd between the two passes).  Requires n % 8 == 0, n <= 8192. */
 int td_layernorm_quant(const void* x, int dtype, const float* w, const float* b, const float* scale,
-                       const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float eps,
+                       const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float* stats_ws, float eps,
                        int64_t m, int64_t n, td_stream_t stream);
 
 /* ---- a7: gated residual  x = x + y*gate.type_as(x)  (wan2pt1.py:405-406,412-413) ----

@@ -182,7 +182,8 @@ def test_layernorm_modulate(K, m, n, affine, mod):
     assert (ulp > 0).float().mean().item() < 0.02
 
 
-@pytest.mark.parametrize("m,n", [(7, 1536), (300, 256), (1000, 1536), (129, 1024), (256, 520), (4096, 1536)])
+@pytest.mark.parametrize("m,n", [(7, 1536), (300, 256), (1000, 1536), (129, 1024), (256, 520), (4096, 1536), (300, 5120),
+                                 (1002, 264)])
 @pytest.mark.parametrize("affine,mod", [(False, True), (True, False), (False, False), (True, True)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_layernorm_quant_bit_exact(K, m, n, affine, mod, dtype):

@@ -71,6 +71,10 @@ def main():
         sc = torch.randn(1, dim, device=dev)
         t = timeit(lambda: K.layernorm(x, None, None, 1e-6, sc, sc), args.iters)
         rep("layernorm+modulate [L,dim]", t, bytes_=4 * L * dim)
+        t = timeit(lambda: K.quant_i8_block128(K.layernorm(x, None, None, 1e-6, sc, sc)), args.iters)
+        rep("layernorm+modulate -> quant (two operators) [L,dim]", t, bytes_=7 * L * dim)
+        t = timeit(lambda: K.layernorm_quant(x, None, None, 1e-6, sc, sc), args.iters)
+        rep("layernorm_quant (stats + per-block apply) [L,dim]", t, bytes_=5 * L * dim)
         w = torch.ones(dim, device=dev)
         t = timeit(lambda: K.rmsnorm(x, w, 1e-6), args.iters)
         rep("rmsnorm [L,dim]", t, bytes_=4 * L * dim)

@@ -32,7 +32,7 @@ SIGNATURES = {
     "td_gemm_w8a8_residual": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp],
     "td_rmsnorm": [_vp, _i32, _vp, _vp, _i32, _f32, _i64, _i64, _vp],
     "td_layernorm": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _i64, _i64, _vp],
-    "td_layernorm_quant": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _i64, _i64, _vp],
+    "td_layernorm_quant": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _i64, _i64, _vp],
     "td_gated_residual": [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "td_qk_norm_rope": [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _i64, _i32, _i32, _vp],
     "td_v_transpose": [_vp, _i32, _i64, _i64, _vp, _i32, _i64, _i32, _i32, _vp],

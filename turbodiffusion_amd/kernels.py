@@ -175,7 +175,7 @@ def gemm_w8a8_residual_(x, a_q, a_s, b_q, b_s, bias=None, gate=None):
     return x
 
 
-LNQ_MAX_N = 1536  # td_layernorm_quant keeps a 128-row block on chip; wider rows use layernorm + quant_i8_block128
+LNQ_MAX_N = 8192
 
 
 def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0):
@@ -184,21 +184,23 @@ def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0):
     require_gpu(x, w, b, scale, shift)
     assert x.is_contiguous() and x.dim() == 2, "Input must be a contiguous 2-D tensor"
     m, n = x.shape
-    if n > LNQ_MAX_N or n % 8:
+    if scale is not None and rows_per_batch == 0:
+        nb = scale.numel() // n
+        assert m % nb == 0
+        rows_per_batch = m // nb
+    if n > LNQ_MAX_N or n % 8 or (scale is not None and rows_per_batch < 128):
         return quant_i8_block128(layernorm(x, w, b, eps, scale, shift, rows_per_batch))
     if w is not None:
         w = w.float().contiguous()
-        b = b.float().contiguous() if b is not None else torch.zeros_like(w)
+        b = b.float().contiguous() if b is not None else None
     if scale is not None:
         scale = scale.float().contiguous().reshape(-1, n)
         shift = shift.float().contiguous().reshape(-1, n)
-        if rows_per_batch == 0:
-            assert m % scale.shape[0] == 0
-            rows_per_batch = m // scale.shape[0]
     q = torch.empty((m, n), dtype=torch.int8, device=x.device)
     s = torch.empty((cdiv(m, 128), cdiv(n, 128)), dtype=torch.float32, device=x.device)
+    ws = torch.empty((m, 2), dtype=torch.float32, device=x.device)   # rows' (mean, rstd) between the two passes
     call("td_layernorm_quant", ptr(x), dt_code(x.dtype), ptr(w), ptr(b), ptr(scale), ptr(shift), rows_per_batch,
-         ptr(q), ptr(s), float(eps), m, n, stream_ptr())
+         ptr(q), ptr(s), ptr(ws), float(eps), m, n, stream_ptr())
     return q, s
 
 

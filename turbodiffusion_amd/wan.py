@@ -143,7 +143,7 @@ class WanModel(nn.Module):
         self._fused = {}
         self._rope_cache = {}
         self.seq_parallel = None  # set by turbodiffusion_amd.seqpar.enable(...)
-        self.fuse_norm_quant = False
+        self.fuse_norm_quant = True
 
     # ------------------------------------------------------------------ weights
     @torch.no_grad()
@@ -298,9 +298,9 @@ class WanModel(nn.Module):
         ec = [e[:, j].contiguous() for j in range(6)]
         x2 = x.view(B * L_loc, dim)
         dt = x.dtype
-        # optional: the norms emit the INT8 activation of their consumer directly (td_layernorm_quant == td_layernorm +
-        # td_quant_i8_block128 bit for bit).  Off by default: measured on MI355X the one-workgroup-per-CU fused kernel
-        # (66 us at [32760, 1536]) does not yet beat the two streaming kernels (35 + 27 us).
+        # the norms emit the INT8 activation of their consumer directly (td_layernorm_quant == td_layernorm +
+        # td_quant_i8_block128 bit for bit; row statistics pass + per-128x128-block apply/quantise pass: 18 + 28 us at
+        # [32760, 1536] on MI355X against 36 + 25 us for the two operators)
         fuse = self.fuse_norm_quant and self.quant_linear and dim <= K.LNQ_MAX_N
         rows = [slice(b * L_loc, (b + 1) * L_loc) for b in range(B)]
         # ---- self attention ----
