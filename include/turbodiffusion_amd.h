@@ -223,9 +223,11 @@ int td_attn_16_ex(const void* q, const void* k, const void* vt, const int32_t* l
  * pass 1: ck = cast(softmax_D(k)); kvsum[h] = cast(ck^T @ v) ; ksum[h] = cast(sum_L ck)
  *   k [H, L, D] dtype; vt = the V^T tiles of td_v_transpose (vt_dtype); ws_kv f32 [H,TD_SLA_NCH,D,D] and
  *   ws_ks f32 [H,TD_SLA_NCH,D] are scratch (partials summed in order: deterministic);
- *   outputs kvsum_t [H, D(d2), D(d1)] dtype (TRANSPOSED: the A operand of pass 2), ksum [H, D]. */
+ *   outputs kvsum_t [H, D(d2), D(d1)] dtype (TRANSPOSED: the A operand of pass 2), ksum [H, D].
+ *   Optional (both or neither NULL): ws_km f32 [H,TD_SLA_NCH,D] scratch + km [H, D] dtype = the smooth-K mean of
+ *   td_seq_mean, accumulated during the same pass over K (so block-sparse SLA needs no separate td_seq_mean). */
 int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
-                     float* ws_ks, void* kvsum_t, void* ksum, int64_t L, int H, int D,
+                     float* ws_ks, void* kvsum_t, void* ksum, float* ws_km, void* km, int64_t L, int H, int D,
                      td_stream_t stream);
 /* the two stages of pass 1 (sequence parallelism: partial on each rank's tokens, all-gather, final).
  * final sums `nch` partials found at ws_kv + h*kv_stride_h + c*kv_stride_c (+i) [same for ks] and writes

@@ -127,9 +127,10 @@ def sla_linear_kv_final(kv_parts, ks_parts, nch, kv_sh, kv_sc, ks_sh, ks_sc, H, 
     return kvs.to(dtype).transpose(-1, -2).contiguous(), kss.to(dtype)
 
 
-def sla_linear_kv(k, vt):
+def sla_linear_kv(k, vt, want_kmean=False):
     kv, ks = sla_linear_kv_partial_f32(k, vt)
-    return kv.to(k.dtype).transpose(-1, -2).contiguous(), ks.to(k.dtype)
+    out = (kv.to(k.dtype).transpose(-1, -2).contiguous(), ks.to(k.dtype))
+    return out + (seq_mean(k),) if want_kmean else out
 
 
 def sla_linear_out_t(q, kv_t, ksum, wp, bp):

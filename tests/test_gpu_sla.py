@@ -178,6 +178,23 @@ def test_attn_softmax_rescale_spike(K):
     assert rel_l2(out[0, 37], ref[0, 37]) < 1e-2
 
 
+@pytest.mark.parametrize("H,L", [(2, 300), (12, 1111), (3, 4100)])
+def test_linear_kv_pass_also_yields_the_smooth_k_mean(K, H, L):
+    """td_sla_linear_kv with a km output: kvsum / ksum unchanged (bit for bit) and km == td_seq_mean(k) up to the
+    rounding of a different (still fixed) fp32 summation tree, and within a 16-bit ulp of the exact mean."""
+    _, k, v = qkv(H, L, 4)
+    kd = k[0].contiguous().to(DEV)
+    vt = K.v_transpose(v[0].contiguous().to(DEV), L * 128, 128, L, H, 128, torch.float16)
+    kv_t, ksum = K.sla_linear_kv(kd, vt)
+    kv_t2, ksum2, km = K.sla_linear_kv(kd, vt, want_kmean=True)
+    assert torch.equal(kv_t, kv_t2) and torch.equal(ksum, ksum2)
+    km_ref = K.seq_mean(kd)
+    tol = 2.0 ** -8 * km_ref.float().abs().clamp_min(1e-2)
+    assert ((km.float() - km_ref.float()).abs() <= tol).all()
+    exact = S.seq_mean(k)[0, :, 0]
+    assert ulp_diff_bf16(km, exact).max().item() <= 1 or ((km.float().cpu() - exact.float()).abs() <= 1e-4).all()
+
+
 @pytest.mark.parametrize("H,L,ratio", [(2, 300, 0.5), (3, 1000, 0.3), (12, 1664, 0.2)])
 def test_attention_epilogue_fusions_bit_exact(K, H, L, ratio):
     """add_t (o_l added in the attention epilogue) and quant_out (epilogue block-quantiser) reproduce the separate

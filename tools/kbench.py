@@ -153,6 +153,8 @@ def main():
         kv_t, ksum = K.sla_linear_kv(k, vt)
         t = timeit(lambda: K.sla_linear_kv(k, vt), args.iters)
         rep("sla_linear_kv", t, bytes_=4 * L * dim)
+        t = timeit(lambda: K.sla_linear_kv(k, vt, want_kmean=True), args.iters)
+        rep("sla_linear_kv + smooth-K mean", t, bytes_=4 * L * dim)
         wp = torch.randn(D, D, device=dev) * 0.05
         bp = torch.zeros(D, device=dev)
         t = timeit(lambda: K.sla_linear_out_(q, kv_t, ksum, wp, bp, out, D, H * D), args.iters)

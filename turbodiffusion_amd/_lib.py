@@ -48,7 +48,7 @@ SIGNATURES = {
     "td_sla_linear_out_t": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_kv_partial": [_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_kv_final": [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _vp],
-    "td_sla_linear_kv": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "td_sla_linear_kv": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_out": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
 }
 

@@ -57,7 +57,8 @@ template <int KDT, int VDT>
 __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* __restrict__ k,
                                                                 const uint16_t* __restrict__ vt,
                                                                 float* __restrict__ ws_kv,
-                                                                float* __restrict__ ws_ks, int64_t L,
+                                                                float* __restrict__ ws_ks,
+                                                                float* __restrict__ ws_km, int64_t L,
                                                                 int Kb) {
   __shared__ __attribute__((aligned(16))) char ckT[128 * 128];  // [d1][64 positions] 16-bit
   __shared__ __attribute__((aligned(16))) char vT[128 * 128];   // [d2][64 positions] 16-bit
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float ks_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float km_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // plain column sums of k (rows past L are loaded as 0): the smooth-K mean
 
   for (int kb = kb_lo; kb < kb_hi; ++kb) {
     // global loads first: the V^T tile (contiguous 16 KB) and this thread's 4 K rows
@@ -108,6 +110,8 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
       const bool ok = (int64_t)kb * 64 + 4 * tg + t < L;
       float f[8];
       unpack8<KDT>(kr[t], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) km_acc[j] += f[j];
       float mx = f[0];
 #pragma unroll
       for (int j = 1; j < 8; ++j) mx = fmaxf(mx, f[j]);
@@ -173,6 +177,18 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
     for (int r = 0; r < 16; ++r) s += ksred[r][tid];
     ws_ks[((int64_t)h * LK_NCH + ch) * 128 + tid] = s;
   }
+  if (ws_km != nullptr) {  // first stage of td_seq_mean on the way (second stage: td_seq_mean_final over LK_NCH partials)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ksred[tg][c8 * 8 + j] = km_acc[j];
+    __syncthreads();
+    if (tid < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += ksred[r][tid];
+      ws_km[((int64_t)h * LK_NCH + ch) * 128 + tid] = s;
+    }
+  }
 }
 
 // pass 1b: sum partials in order, round once; kvsum is written TRANSPOSED ([d2][d1]) because
@@ -184,12 +200,22 @@ __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __res
                                                               int64_t kv_sh, int64_t kv_sc, int64_t ks_sh,
                                                               int64_t ks_sc, void* __restrict__ kv_out,
                                                               void* __restrict__ ks_out) {
-  const int h = blockIdx.x, part = blockIdx.y;  // 16 workgroups per head, 1024 kv elements each
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int i = part * 1024 + e * 256 + threadIdx.x;
-    float s = 0.f;
-    for (int c = 0; c < nch; ++c) s += ws_kv[h * kv_sh + c * kv_sc + i];  // in order: deterministic
+  // 64 workgroups per head, one kv element per thread; the partials are summed in a fixed tree (four interleaved
+  // running sums, then ((s0+s1)+(s2+s3))) with four loads in flight: deterministic, and not a chain of nch latencies
+  const int h = blockIdx.x, part = blockIdx.y;
+  {
+    const int i = part * 256 + threadIdx.x;
+    const float* p = ws_kv + h * kv_sh + i;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < nch; c += 4) {
+      s0 += p[(int64_t)c * kv_sc];
+      s1 += p[(int64_t)(c + 1) * kv_sc];
+      s2 += p[(int64_t)(c + 2) * kv_sc];
+      s3 += p[(int64_t)(c + 3) * kv_sc];
+    }
+    for (; c < nch; ++c) s0 += p[(int64_t)c * kv_sc];
+    const float s = (s0 + s1) + (s2 + s3);
     if constexpr (ROUND) {
       const int d1 = i >> 7, d2 = i & 127;
       ((uint16_t*)kv_out)[(int64_t)h * 128 * 128 + d2 * 128 + d1] = (uint16_t)f32_to_half_bits<DT>(s);
@@ -198,16 +224,24 @@ __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __res
     }
   }
   if (part == 0 && threadIdx.x < 128) {
-    float s = 0.f;
-    for (int c = 0; c < nch; ++c) s += ws_ks[h * ks_sh + c * ks_sc + threadIdx.x];
+    const float* p = ws_ks + h * ks_sh + threadIdx.x;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < nch; c += 4) {
+      s0 += p[(int64_t)c * ks_sc];
+      s1 += p[(int64_t)(c + 1) * ks_sc];
+      s2 += p[(int64_t)(c + 2) * ks_sc];
+      s3 += p[(int64_t)(c + 3) * ks_sc];
+    }
+    for (; c < nch; ++c) s0 += p[(int64_t)c * ks_sc];
+    const float s = (s0 + s1) + (s2 + s3);
     if constexpr (ROUND) ((uint16_t*)ks_out)[h * 128 + threadIdx.x] = (uint16_t)f32_to_half_bits<DT>(s);
     else ((float*)ks_out)[h * 128 + threadIdx.x] = s;
   }
 }
 
-extern "C" int td_sla_linear_kv_partial(const void* k, int dtype, const void* vt, int vt_dtype,
-                                        float* ws_kv, float* ws_ks, int64_t L, int H, int D,
-                                        td_stream_t stream) {
+static int sla_linear_kv_partial_impl(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
+                                      float* ws_ks, float* ws_km, int64_t L, int H, int D, td_stream_t stream) {
   TD_REQUIRE(k && vt && ws_kv && ws_ks, TD_ERR_INVALID, "td_sla_linear_kv_partial: null pointer");
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_linear_kv_partial: D=%d (need 128)", D);
   TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sla_linear_kv_partial: L=%lld H=%d", (long long)L, H);
@@ -215,17 +249,23 @@ extern "C" int td_sla_linear_kv_partial(const void* k, int dtype, const void* vt
   dim3 grid(LK_NCH, H);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16 && vt_dtype == TD_F16)
-    linear_kv_partial_kernel<TD_BF16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+    linear_kv_partial_kernel<TD_BF16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb);
   else if (dtype == TD_BF16 && vt_dtype == TD_BF16)
-    linear_kv_partial_kernel<TD_BF16, TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+    linear_kv_partial_kernel<TD_BF16, TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb);
   else if (dtype == TD_F16 && vt_dtype == TD_F16)
-    linear_kv_partial_kernel<TD_F16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, L, Kb);
+    linear_kv_partial_kernel<TD_F16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb);
   else {
     td_set_error("td_sla_linear_kv_partial: unsupported dtypes k=%d vt=%d", dtype, vt_dtype);
     return TD_ERR_UNSUPPORTED;
   }
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_sla_linear_kv_partial(const void* k, int dtype, const void* vt, int vt_dtype,
+                                        float* ws_kv, float* ws_ks, int64_t L, int H, int D,
+                                        td_stream_t stream) {
+  return sla_linear_kv_partial_impl(k, dtype, vt, vt_dtype, ws_kv, ws_ks, nullptr, L, H, D, stream);
 }
 
 extern "C" int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, int nch, int64_t kv_stride_h,
@@ -236,11 +276,11 @@ extern "C" int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, in
   TD_REQUIRE(D == 128 && nch > 0 && H > 0, TD_ERR_UNSUPPORTED, "td_sla_linear_kv_final: D=%d nch=%d", D, nch);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == TD_BF16)
-    linear_kv_final_kernel<TD_BF16, true><<<dim3(H, 16), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_BF16, true><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
   else if (out_dtype == TD_F16)
-    linear_kv_final_kernel<TD_F16, true><<<dim3(H, 16), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_F16, true><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
   else if (out_dtype == TD_F32)
-    linear_kv_final_kernel<TD_F32, false><<<dim3(H, 16), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_F32, false><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
   else {
     td_set_error("td_sla_linear_kv_final: out dtype %d", out_dtype);
     return TD_ERR_UNSUPPORTED;
@@ -250,13 +290,16 @@ extern "C" int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, in
 }
 
 extern "C" int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
-                                float* ws_ks, void* kvsum_t, void* ksum, int64_t L, int H, int D,
-                                td_stream_t stream) {
+                                float* ws_ks, void* kvsum_t, void* ksum, float* ws_km, void* km, int64_t L, int H,
+                                int D, td_stream_t stream) {
   TD_REQUIRE(kvsum_t && ksum, TD_ERR_INVALID, "td_sla_linear_kv: null pointer");
-  int rc = td_sla_linear_kv_partial(k, dtype, vt, vt_dtype, ws_kv, ws_ks, L, H, D, stream);
+  TD_REQUIRE((ws_km == nullptr) == (km == nullptr), TD_ERR_INVALID, "td_sla_linear_kv: ws_km / km must come together");
+  int rc = sla_linear_kv_partial_impl(k, dtype, vt, vt_dtype, ws_kv, ws_ks, ws_km, L, H, D, stream);
   if (rc) return rc;
-  return td_sla_linear_kv_final(ws_kv, ws_ks, LK_NCH, (int64_t)LK_NCH * 128 * 128, 128 * 128,
-                                (int64_t)LK_NCH * 128, 128, kvsum_t, ksum, dtype, H, D, stream);
+  rc = td_sla_linear_kv_final(ws_kv, ws_ks, LK_NCH, (int64_t)LK_NCH * 128 * 128, 128 * 128,
+                              (int64_t)LK_NCH * 128, 128, kvsum_t, ksum, dtype, H, D, stream);
+  if (rc || km == nullptr) return rc;
+  return td_seq_mean_final(ws_km, LK_NCH, (int64_t)LK_NCH * 128, 128, km, dtype, L, H, D, stream);
 }
 
 // ---------------------------------------------------------------------------------------

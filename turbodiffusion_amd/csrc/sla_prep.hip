@@ -107,14 +107,32 @@ __global__ __launch_bounds__(256) void seq_mean_partial_kernel(const uint16_t* _
     ws[((int64_t)h * SM_CHUNKS + chunk) * 128 + tid] = s;
   }
 }
+// second stage: 8 slices of the partial list per head in parallel (1024 threads), each summed in order with 4
+// independent loads in flight, then the slices in order: a fixed summation tree, so still deterministic
 template <int DT>
-__global__ __launch_bounds__(128) void seq_mean_final_kernel(const float* __restrict__ ws, int nch,
-                                                             int64_t stride_h, int64_t stride_c,
-                                                             uint16_t* __restrict__ km, int64_t L) {
-  const int h = blockIdx.x, d = threadIdx.x;
-  float s = 0.f;
-  for (int c = 0; c < nch; ++c) s += ws[h * stride_h + c * stride_c + d];
-  km[h * 128 + d] = (uint16_t)f32_to_half_bits<DT>(s / (float)L);
+__global__ __launch_bounds__(1024) void seq_mean_final_kernel(const float* __restrict__ ws, int nch,
+                                                              int64_t stride_h, int64_t stride_c,
+                                                              uint16_t* __restrict__ km, int64_t L) {
+  __shared__ float part[8][128];
+  const int h = blockIdx.x, d = threadIdx.x & 127, sl = threadIdx.x >> 7;
+  const float* p = ws + h * stride_h + d;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c = sl;
+  for (; c + 24 < nch; c += 32) {
+    s0 += p[(int64_t)c * stride_c];
+    s1 += p[(int64_t)(c + 8) * stride_c];
+    s2 += p[(int64_t)(c + 16) * stride_c];
+    s3 += p[(int64_t)(c + 24) * stride_c];
+  }
+  for (; c < nch; c += 8) s0 += p[(int64_t)c * stride_c];
+  part[sl][d] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += part[q][d];
+    km[h * 128 + d] = (uint16_t)f32_to_half_bits<DT>(s / (float)L);
+  }
 }
 
 extern "C" int td_seq_sum_partial(const void* k, float* ws, int dtype, int64_t L, int H, int D,
@@ -138,8 +156,8 @@ extern "C" int td_seq_mean_final(const float* ws, int nch, int64_t stride_h, int
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_seq_mean_final: dtype %d", dtype);
   TD_REQUIRE(nch > 0 && L_total > 0 && H > 0, TD_ERR_INVALID, "td_seq_mean_final: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TD_BF16) seq_mean_final_kernel<TD_BF16><<<H, 128, 0, st>>>(ws, nch, stride_h, stride_c, (uint16_t*)km, L_total);
-  else seq_mean_final_kernel<TD_F16><<<H, 128, 0, st>>>(ws, nch, stride_h, stride_c, (uint16_t*)km, L_total);
+  if (dtype == TD_BF16) seq_mean_final_kernel<TD_BF16><<<H, 1024, 0, st>>>(ws, nch, stride_h, stride_c, (uint16_t*)km, L_total);
+  else seq_mean_final_kernel<TD_F16><<<H, 1024, 0, st>>>(ws, nch, stride_h, stride_c, (uint16_t*)km, L_total);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }

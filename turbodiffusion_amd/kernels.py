@@ -331,16 +331,19 @@ def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, 
 SLA_NCH = 32  # TD_SLA_NCH in include/turbodiffusion_amd.h
 
 
-def sla_linear_kv(k, vt):
+def sla_linear_kv(k, vt, want_kmean=False):
+    """-> (kvsum_t, ksum) of the linear branch [, km = seq_mean(k) accumulated during the same pass over K]."""
     require_gpu(k, vt)
     H, L_, D = k.shape
+    ws_km = torch.empty((H, SLA_NCH, D), dtype=torch.float32, device=k.device) if want_kmean else None
+    km = torch.empty((H, D), dtype=k.dtype, device=k.device) if want_kmean else None
     ws_kv = torch.empty((H, SLA_NCH, D, D), dtype=torch.float32, device=k.device)
     ws_ks = torch.empty((H, SLA_NCH, D), dtype=torch.float32, device=k.device)
     kv_t = torch.empty((H, D, D), dtype=k.dtype, device=k.device)
     ksum = torch.empty((H, D), dtype=k.dtype, device=k.device)
     call("td_sla_linear_kv", ptr(k), dt_code(k.dtype), ptr(vt), dt_code(vt.dtype), ptr(ws_kv), ptr(ws_ks),
-         ptr(kv_t), ptr(ksum), L_, H, D, stream_ptr())
-    return kv_t, ksum
+         ptr(kv_t), ptr(ksum), ptr(ws_km), ptr(km), L_, H, D, stream_ptr())
+    return (kv_t, ksum, km) if want_kmean else (kv_t, ksum)
 
 
 def seq_sum_partial(k, out=None):

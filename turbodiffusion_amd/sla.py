@@ -25,12 +25,13 @@ def _check_feature_map(feature_map):
 
 
 def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
-                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False):
+                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None):
     """Core of both modules on head-major tensors.
 
     q, k: [H, L, D] 16-bit (after RoPE); vt_src: tensor holding V with element (h,l,d) at
     data_ptr + h*v_strides[0] + l*v_strides[1] + d; out: preallocated, element (h,l,d) at
     out_ptr + h*o_stride_h + l*o_stride_l + d.  Returns (out, real_topk, Kb).
+    km: the per-head sequence mean of k [H, D] when the caller already has it (K.qk_norm_rope_pair), else computed here.
     quant_out: return the [L, H*D] result block-quantised for the o projection ((int8, scales) in place of ``out``,
     which then only supplies the dtype).
 
@@ -44,11 +45,16 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     topk = min(kb, int(topk_ratio * kb))
     pdt = torch.float16 if sage else q.dtype
     vt = K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, pdt)
-    km = K.seq_mean(k)
     o_l = None
     if proj_w is not None:
-        kv_t, ksum = K.sla_linear_kv(k, vt)
+        # the linear branch's pass over K also accumulates the smooth-K mean (k.mean(dim=-2), SLA/core.py:197)
+        if km is None:
+            kv_t, ksum, km = K.sla_linear_kv(k, vt, want_kmean=True)
+        else:
+            kv_t, ksum = K.sla_linear_kv(k, vt)
         o_l = K.sla_linear_out_t(q, kv_t, ksum, proj_w, proj_b)
+    elif km is None and (sage or not dense):
+        km = K.seq_mean(k)
     if dense:
         lut = None
         pq = None
