@@ -54,8 +54,10 @@ def test_seq_mean(K, H, L):
     assert ulp_diff_bf16(km, ref).max().item() <= 1
 
 
-@pytest.mark.parametrize("H,L", [(2, 300), (3, 1000), (1, 64)])
+@pytest.mark.parametrize("H,L", [(2, 300), (3, 1000), (1, 64), (12, 8192)])
 def test_sage_quant_pool_bit_exact(K, H, L):
+    """(12, 8192): 12.6 M quotients per operand — the kernel's reciprocal + exact-remainder division must round like the
+    oracle's IEEE division on every one of them."""
     q, k, _ = qkv(H, L, 3)
     km = S.seq_mean(k)  # same km on both sides -> codes/scales must be bit-exact
     for x, kmx, blk in ((q, None, 128), (k, km, 64)):

@@ -1,0 +1,16 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+R=$PWD
+timeout 900 python -m pytest tests/test_gpu_sla.py tests/test_gpu_ops.py tests/test_gpu_wan.py -m gpu -q --no-header -p no:cacheprovider -x 2>&1 | tail -4
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_b26 -o k --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph > $R/gpurun_out/prof_b26.log 2>&1)
+python - <<'PY'
+import csv,glob
+f=glob.glob('gpurun_out/prof_b26/*kernel_stats.csv')[0]
+rows=list(csv.DictReader(open(f)))
+tot=sum(float(r['TotalDurationNs']) for r in rows)
+for r in rows[:22]:
+    print(r['Name'][:64].ljust(64), r['Calls'].rjust(5), ('%.1f'%(float(r['AverageNs'])/1e3)).rjust(8), ('%.2f%%'%(100*float(r['TotalDurationNs'])/tot)).rjust(7))
+print('total kernel ms per forward', tot/1e6/8)
+PY
+find gpurun_out/prof_b26 -name '*kernel_trace*' -size +20M -delete
+for i in 1 2; do timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/bench_b26_$i.log 2>&1; grep '^{' gpurun_out/bench_b26_$i.log | cut -c1-330; done

@@ -23,7 +23,7 @@ template <int DT> struct RowIO {  // 8 consecutive elements per lane
   }
   __device__ static __forceinline__ float rnd(float v) {
     if constexpr (DT == TD_F32) return v;
-    else return half_bits_to_f32<DT>(f32_to_half_bits<DT>(v));
+    else return round_half<DT>(v);  // hardware RNE pack (v_cvt_pk_*): same value as the software rounding, 2 VALU not 7
   }
   __device__ static __forceinline__ void store(void* p, int64_t off, const float* f) {
     if constexpr (DT == TD_F32) {

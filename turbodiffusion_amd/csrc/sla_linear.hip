@@ -53,7 +53,7 @@ template <> struct MmaT<TD_BF16> {
 // 4 coalesced 16-B row loads, the row softmax is a 16-lane butterfly, and the transposed image ck^T[d][tok]
 // is written as 8-byte pieces (4 consecutive tokens of one channel are 4 consecutive MFMA positions).
 // ---------------------------------------------------------------------------------------
-template <int KDT, int VDT>
+template <int KDT, int VDT, bool WANT_KM>
 __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* __restrict__ k,
                                                                 const uint16_t* __restrict__ vt,
                                                                 float* __restrict__ ws_kv,
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
 
   for (int kb = kb_lo; kb < kb_hi; ++kb) {
     // global loads first: the V^T tile (contiguous 16 KB) and this thread's 4 K rows
+    // (a register-level prefetch of block kb+1 was tried: the extra 32 VGPRs spill, 59 -> 141 us)
     uint4 vv[4], kr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -110,8 +111,10 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
       const bool ok = (int64_t)kb * 64 + 4 * tg + t < L;
       float f[8];
       unpack8<KDT>(kr[t], f);
+      if constexpr (WANT_KM) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) km_acc[j] += f[j];
+        for (int j = 0; j < 8; ++j) km_acc[j] += f[j];
+      }
       float mx = f[0];
 #pragma unroll
       for (int j = 1; j < 8; ++j) mx = fmaxf(mx, f[j]);
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
     for (int r = 0; r < 16; ++r) s += ksred[r][tid];
     ws_ks[((int64_t)h * LK_NCH + ch) * 128 + tid] = s;
   }
-  if (ws_km != nullptr) {  // first stage of td_seq_mean on the way (second stage: td_seq_mean_final over LK_NCH partials)
+  if constexpr (WANT_KM) {  // first stage of td_seq_mean on the way (second stage: td_seq_mean_final over LK_NCH partials)
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) ksred[tg][c8 * 8 + j] = km_acc[j];
@@ -248,12 +251,14 @@ static int sla_linear_kv_partial_impl(const void* k, int dtype, const void* vt, 
   const int Kb = (int)td_cdiv(L, 64);
   dim3 grid(LK_NCH, H);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TD_BF16 && vt_dtype == TD_F16)
-    linear_kv_partial_kernel<TD_BF16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb);
-  else if (dtype == TD_BF16 && vt_dtype == TD_BF16)
-    linear_kv_partial_kernel<TD_BF16, TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb);
-  else if (dtype == TD_F16 && vt_dtype == TD_F16)
-    linear_kv_partial_kernel<TD_F16, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb);
+#define TD_LKP(KD_, VD_)                                                                                         \
+  {                                                                                                               \
+    if (ws_km) linear_kv_partial_kernel<KD_, VD_, true><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb); \
+    else linear_kv_partial_kernel<KD_, VD_, false><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb);     \
+  }
+  if (dtype == TD_BF16 && vt_dtype == TD_F16) TD_LKP(TD_BF16, TD_F16)
+  else if (dtype == TD_BF16 && vt_dtype == TD_BF16) TD_LKP(TD_BF16, TD_BF16)
+  else if (dtype == TD_F16 && vt_dtype == TD_F16) TD_LKP(TD_F16, TD_F16)
   else {
     td_set_error("td_sla_linear_kv_partial: unsupported dtypes k=%d vt=%d", dtype, vt_dtype);
     return TD_ERR_UNSUPPORTED;
@@ -307,7 +312,7 @@ extern "C" int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt
 // ---------------------------------------------------------------------------------------
 #define LO_QB_PER_WG 8
 template <int DT>
-__global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restrict__ q,
+__global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __restrict__ q,
                                                          const uint16_t* __restrict__ kvT,
                                                          const uint16_t* __restrict__ ksum,
                                                          const float* __restrict__ wp,
@@ -323,6 +328,17 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
   const int li = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y;
 
+  // q of the first Q block: issued before the LDS staging so that its latency overlaps it; inside the loop the next
+  // block's q is fetched while the current one is processed (a workgroup walks LO_QB_PER_WG blocks one after the other
+  // and only ~6 waves fit a CU beside the 64 KB of LDS, so an un-prefetched load is a fully exposed HBM round trip)
+  uint4 qraw[8];
+  {
+    int64_t tok0 = (int64_t)blockIdx.x * LO_QB_PER_WG * 128 + wave * 32 + li;
+    if (tok0 > L - 1) tok0 = L - 1;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      qraw[ks] = *reinterpret_cast<const uint4*>(q + ((int64_t)h * L + tok0) * 128 + 16 * ks + 8 * hi);
+  }
   for (int i = tid; i < 128 * 16; i += 256) {  // 16-B vectors of kvsum^T
     const int row = i >> 4, slot = i & 15;
     *reinterpret_cast<uint4*>(kvs + sw256(row, slot)) =
@@ -355,9 +371,16 @@ __global__ __launch_bounds__(256) void linear_out_kernel(const uint16_t* __restr
     float mx = -INFINITY;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      unpack8<DT>(*reinterpret_cast<const uint4*>(q + ((int64_t)h * L + tok) * 128 + 16 * ks + 8 * hi), qf[ks]);
+      unpack8<DT>(qraw[ks], qf[ks]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) mx = fmaxf(mx, qf[ks][e]);
+    }
+    if (qq + 1 < LO_QB_PER_WG && qb + 1 < Qb) {
+      int64_t tokn = (int64_t)(qb + 1) * 128 + wave * 32 + li;
+      if (tokn > L - 1) tokn = L - 1;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+        qraw[ks] = *reinterpret_cast<const uint4*>(q + ((int64_t)h * L + tokn) * 128 + 16 * ks + 8 * hi);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mb = mx * TD_LOG2E;

@@ -193,19 +193,32 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
     raw[it] = make_uint4(0, 0, 0, 0);
     if (l < L) raw[it] = *reinterpret_cast<const uint4*>(x + ((int64_t)h * L + l) * 128 + c8 * 8);
   }
+  // (VALU diet: this kernel was instruction-bound at ~35 VALU per element; hardware RNE packs, the quotient by the
+  //  block scale as a reciprocal + one exact-remainder correction, v_med3 clamp and a magic-number byte extraction
+  //  bring it to ~16 and the kernel back under the HBM time)
   float psum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float amax = 0.f;
+  float xf[NIT][8];   // x - km in fp32: the quantiser's input, kept for the second phase
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int64_t l = (int64_t)blk * BLK + it * 16 + r0;
-    if (l >= L) continue;
-    float f[8];
-    unpack8<DT>(raw[it], f);
+    const bool ok = l < L;
+    const uint32_t wds[4] = {raw[it].x, raw[it].y, raw[it].z, raw[it].w};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xf = f[j] - kmf[j];                                   // fp32 (quant input)
-      amax = fmaxf(amax, fabsf(xf));
-      psum[j] += half_bits_to_f32<DT>(f32_to_half_bits<DT>(xf));        // dtype-rounded (pool input)
+    for (int p = 0; p < 4; ++p) {
+      float a0, a1;
+      unpack2<DT>(wds[p], a0, a1);
+      a0 = a0 - kmf[2 * p];
+      a1 = a1 - kmf[2 * p + 1];
+      xf[it][2 * p] = a0;
+      xf[it][2 * p + 1] = a1;
+      if (ok) {
+        amax = fmaxf(amax, fmaxf(fabsf(a0), fabsf(a1)));
+        float r0_, r1_;
+        unpack2<DT>(pack2<DT>(a0, a1), r0_, r1_);   // dtype-rounded (pool input)
+        psum[2 * p] += r0_;
+        psum[2 * p + 1] += r1_;
+      }
     }
   }
   // pooled mean
@@ -228,22 +241,28 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
   amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
   const float scale = amax / 127.0f + 1e-7f;
   if (tid == 0) xs[(int64_t)h * nb + blk] = scale;
+  // y = x / scale, correctly rounded (== the IEEE division of the oracle): rinv = RN(1/scale) by one Newton step on
+  // v_rcp_f32, then q0 = RN(x*rinv), r = x - q0*scale exactly (fma), q = RN(q0 + r*rinv)  (Markstein's correction)
+  float rinv = __builtin_amdgcn_rcpf(scale);
+  rinv = fmaf(fmaf(-scale, rinv, 1.0f), rinv, rinv);
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int64_t l = (int64_t)blk * BLK + it * 16 + r0;
-    if (l >= L) continue;
-    float f[8];
-    unpack8<DT>(raw[it], f);
-    uint32_t w[2] = {0, 0};
+    uint32_t c[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float y = (f[j] - kmf[j]) / scale;          // IEEE division
-      y = y + (y >= 0.f ? 0.5f : -0.5f);
+      const float x_ = xf[it][j];
+      const float q0 = x_ * rinv;
+      const float rr = fmaf(-q0, scale, x_);
+      float y = fmaf(rr, rinv, q0);
+      y = y + __builtin_copysignf(0.5f, y);        // round half away from zero: +-0.5 then truncate
       y = truncf(y);
-      y = fminf(fmaxf(y, -128.f), 127.f);
-      w[j >> 2] |= ((uint32_t)(int)y & 0xffu) << (8 * (j & 3));
+      y = __builtin_amdgcn_fmed3f(y, -128.f, 127.f);
+      c[j] = __float_as_uint(y + 12582912.0f);     // integer in [-128, 127]: the low byte of 1.5*2^23 + y is its code
     }
-    *reinterpret_cast<uint2*>(xq + ((int64_t)h * L + l) * 128 + c8 * 8) = make_uint2(w[0], w[1]);
+    const uint32_t w0 = __builtin_amdgcn_perm(c[1], c[0], 0x0c0c0400u) | __builtin_amdgcn_perm(c[3], c[2], 0x04000c0cu);
+    const uint32_t w1 = __builtin_amdgcn_perm(c[5], c[4], 0x0c0c0400u) | __builtin_amdgcn_perm(c[7], c[6], 0x04000c0cu);
+    if (l < L) *reinterpret_cast<uint2*>(xq + ((int64_t)h * L + l) * 128 + c8 * 8) = make_uint2(w0, w1);
   }
 }
 
