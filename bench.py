@@ -94,7 +94,7 @@ def build_model(name, wl, dev, topk, num_layers=None):
 def pmc_traffic(prefixes):
     """HBM-side bytes per launch (fetch + write) of the kernels whose names start with one of ``prefixes``, from the
     committed rocprofv3 PMC summary of this same command (profiles/r01_pmc_hbm_traffic.json, produced by
-    tools/_g10.sh + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 fetch correction).
+    tools/gpu/pmc_hbm_traffic.sh + tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, gfx950 x2 fetch correction).
     bench.py itself cannot collect counters while it times; None if the summary is absent."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
     if not os.path.exists(path):

@@ -8,4 +8,4 @@ timeout 600 python tools/kbench.py --iters 10 > gpurun_out/kbench_$T.log 2>&1
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$T -o bench --output-format csv -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph > $R/gpurun_out/prof_$T.log 2>&1)
 f=$(find gpurun_out/prof_$T -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/kernel_stats_$T.csv
 find gpurun_out/prof_$T -name '*kernel_trace*' -size +20M -delete
-bash tools/_g10.sh $T > gpurun_out/pmc_$T.log 2>&1; tail -8 gpurun_out/pmc_$T.log
+bash tools/gpu/pmc_hbm_traffic.sh $T > gpurun_out/pmc_$T.log 2>&1; tail -8 gpurun_out/pmc_$T.log
