@@ -153,6 +153,8 @@ def main():
     ap.add_argument("--sp-leg-timeout", type=float, default=240.0)
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("TD_GEMM_VARIANT", "0")),
                     help="W8A8 GEMM kernel selection knob (0 = automatic); all variants are bit-identical")
+    ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
+                    help="td_set_tuning knob for A/B runs (integers, include/turbodiffusion_amd.h: TD_TUNE_*)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,6 +212,9 @@ def main():
 
     if args.gemm_variant:
         K.set_tuning(K.TUNE_GEMM_VARIANT, args.gemm_variant)
+    for kv in args.tune:
+        key, val = kv.split("=")
+        K.set_tuning(int(key), int(val))
     use_graph = (sp == 1) and not args.no_graph  # (the RCCL all-gathers of a sequence-parallel step stay eager)
     run_net = net
     if use_graph:
