@@ -215,6 +215,10 @@ def main():
     for kv in args.tune:
         key, val = kv.split("=")
         K.set_tuning(int(key), int(val))
+    for kv in filter(None, os.environ.get("TD_BENCH_MODEL_FLAGS", "").split(",")):   # A/B runs: fuse_* attributes of WanModel
+        key, val = kv.split("=")
+        assert hasattr(net, key), key
+        setattr(net, key, bool(int(val)))
     use_graph = (sp == 1) and not args.no_graph  # (the RCCL all-gathers of a sequence-parallel step stay eager)
     run_net = net
     if use_graph:

@@ -217,6 +217,17 @@ int td_attn_16_ex(const void* q, const void* k, const void* vt, const int32_t* l
                   int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale,
                   td_stream_t stream);
 
+/* td_attn_16_ex with Q taken straight from a [L, ld_q] linear output (head h = columns [128h, 128h+128)) and its
+ * full-width RMSNorm applied on load: q = cast(x * q_rstd[l] * q_w[c]) — td_qk_norm_rope without RoPE (cross-attention
+ * Q, wan2pt1.py:289) minus the 4-byte-per-element round trip of the normalised copy.  q_rstd f32 [L] from td_rms_stats
+ * (1/sqrt(mean(x^2)+eps) over the n = H*128 columns, same summation order as td_qk_norm_rope), q_w f32 [H*128]. */
+int td_rms_stats(const void* src, int64_t ld_src, int dtype, float* rstd, float eps, int64_t L, int64_t n,
+                 td_stream_t stream);
+int td_attn_16_qnorm(const void* q_src, int64_t ld_q, const float* q_rstd, const float* q_w, const void* k,
+                     const void* vt, const int32_t* lut, int nsel, void* o, int dtype, int64_t o_stride_h,
+                     int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int64_t Lk_alloc, int H,
+                     const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream);
+
 #define TD_SLA_NCH 32 /* partial-sum chunks per head of td_sla_linear_kv* (workspace leading extent) */
 
 /* ---- a14: linear-attention branch (SLA/core.py:243-253, feature_map = softmax) ----

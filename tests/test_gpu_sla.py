@@ -180,6 +180,41 @@ def test_attn_softmax_rescale_spike(K):
     assert rel_l2(out[0, 37], ref[0, 37]) < 1e-2
 
 
+@pytest.mark.parametrize("H,L,Lk,dtype", [(2, 300, 512, torch.bfloat16), (12, 1111, 77, torch.bfloat16), (3, 640, 512, torch.float16)])
+@pytest.mark.parametrize("quant_out", [False, True])
+def test_attn_16_qnorm_bit_exact(K, H, L, Lk, dtype, quant_out):
+    """Q normalised where the attention kernel loads it (td_rms_stats + td_attn_16_qnorm on the [L, H*128] linear
+    output) == td_qk_norm_rope (no RoPE) followed by td_attn_16, bit for bit, also with the quantising epilogue."""
+    g = torch.Generator().manual_seed(H * L + Lk)
+    dim = H * 128
+    src = (torch.randn(L, dim + 64, generator=g) * 1.7).to(dtype).to(DEV)[:, :dim]   # row stride > dim
+    w = (torch.rand(dim, generator=g) + 0.5).to(DEV)
+    kk = torch.randn(H, Lk, 128, generator=g).to(dtype).to(DEV)
+    v = torch.randn(Lk, H, 128, generator=g).to(dtype).to(DEV)
+    vt = K.v_transpose(v, 128, H * 128, Lk, H, 128, dtype)
+    q = K.qk_norm_rope(src, 0, H, 128, w, None, None, 1e-6)
+    out_ref = torch.empty(L, dim, dtype=dtype, device=DEV)
+    out = torch.empty(L, dim, dtype=dtype, device=DEV)
+    rstd = K.rms_stats(src, dim, 1e-6)
+    exact = dtype == torch.bfloat16   # (the model's dtype.  fp16: the two-step path rounds q twice and loses fp16
+    #                                    subnormals on the way — ~5e-5 of the elements differ, the outputs by < 1e-3)
+    if quant_out:
+        q_ref, s_ref = K.attn_16(q, kk, vt, None, out_ref, 128, dim, quant_out=True)
+        q_new, s_new = K.attn_16_qnorm(src, rstd, w, kk, vt, None, out, 128, dim, quant_out=True)
+        if exact:
+            assert torch.equal(s_ref, s_new) and torch.equal(q_ref, q_new)
+        else:
+            assert (q_ref.int() - q_new.int()).abs().max().item() <= 1
+            torch.testing.assert_close(s_new, s_ref, rtol=1e-3, atol=0)
+    else:
+        K.attn_16(q, kk, vt, None, out_ref, 128, dim)
+        K.attn_16_qnorm(src, rstd, w, kk, vt, None, out, 128, dim)
+        if exact:
+            assert torch.equal(out_ref, out)
+        else:
+            torch.testing.assert_close(out, out_ref, rtol=0, atol=1e-3)
+
+
 @pytest.mark.parametrize("H,L", [(2, 300), (12, 1111), (3, 4100)])
 def test_linear_kv_pass_also_yields_the_smooth_k_mean(K, H, L):
     """td_sla_linear_kv with a km output: kvsum / ksum unchanged (bit for bit) and km == td_seq_mean(k) up to the

@@ -44,6 +44,10 @@ struct AttnParams {
   int8_t* q_out;          // optional: block-quantised output int8 [L, q_ld] instead of o ...
   float* q_scale;         // ... with scales [ceil(L/128), H]  (== td_quant_i8_block128 of the [L, H*128] output)
   int64_t q_ld;
+  // optional (16-bit kernel): Q read straight from a [L, ld] GEMM output with its RMSNorm applied on load
+  int64_t q_stride_h, q_stride_l;   // bytes; 0 = the packed [H, L, 128] layout
+  const float* q_rstd;              // [L] 1/rms of the row over the FULL model dim (td_rms_stats), or null
+  const float* q_w;                 // [H*128] RMSNorm weight
 };
 
 template <bool QK_I8> struct KTile {
@@ -105,8 +109,29 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
   uint4 qf[NQ];
   {
     const char* qp = (const char*)p.q + ((int64_t)h * p.L + qrow) * (QK_I8 ? 128 : 256);
+    if constexpr (!QK_I8) {
+      if (p.q_stride_l != 0) qp = (const char*)p.q + (int64_t)h * p.q_stride_h + qrow * p.q_stride_l;
+    }
 #pragma unroll
     for (int kc = 0; kc < NQ; ++kc) qf[kc] = *reinterpret_cast<const uint4*>(qp + kc * 32 + hi * 16);
+    if constexpr (!QK_I8) {
+      if (p.q_rstd != nullptr) {
+        // q = cast(rmsnorm(x) * w) exactly as td_qk_norm_rope computes it (no RoPE: cross-attention), applied to the 64
+        // elements this lane holds — the head-major normalised copy of Q is never written
+        const float rs = p.q_rstd[qrow];
+#pragma unroll
+        for (int kc = 0; kc < NQ; ++kc) {
+          const float* wp_ = p.q_w + h * 128 + kc * 16 + hi * 8;
+          const float4 w0 = *reinterpret_cast<const float4*>(wp_), w1 = *reinterpret_cast<const float4*>(wp_ + 4);
+          const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+          float f[8];
+          unpack8<PDT>(qf[kc], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = (f[e] * rs) * wv[e];
+          qf[kc] = pack8<PDT>(f);
+        }
+      }
+    }
   }
 
   const bool has_lut = lut_all != nullptr;
@@ -429,6 +454,7 @@ extern "C" int td_attn_i8_ex(const int8_t* q_i8, const float* q_s, const int8_t*
   p.q = q_i8; p.q_s = q_s; p.k = k_i8; p.k_s = k_s; p.vt = (const uint16_t*)vt; p.lut = lut;
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
+  p.q_stride_h = 0; p.q_stride_l = 0; p.q_rstd = nullptr; p.q_w = nullptr;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
   if (Lk_alloc == 0) Lk_alloc = Lk;
@@ -448,19 +474,20 @@ extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_
                        Lk_alloc, H, nullptr, nullptr, nullptr, stream);
 }
 
-extern "C" int td_attn_16_ex(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel,
-                             void* o, int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale,
-                             int64_t L, int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out,
-                             float* q_scale, td_stream_t stream) {
-  int rc = attn_common_checks("td_attn_16", q, k, vt, q_out ? (void*)q_out : o, nsel, L, Lk, H, lut);
-  TD_REQUIRE((q_out == nullptr) == (q_scale == nullptr), TD_ERR_INVALID, "td_attn_16: q_out/q_scale mismatch");
-  if (!q_out) { rc = attn_stride_check("td_attn_16", o_stride_h, o_stride_l); if (rc) return rc; }
+static int attn_16_impl(const char* who, const void* q, int64_t q_stride_h, int64_t q_stride_l, const float* q_rstd,
+                        const float* q_w, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
+                        int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
+                        int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream) {
+  int rc = attn_common_checks(who, q, k, vt, q_out ? (void*)q_out : o, nsel, L, Lk, H, lut);
+  TD_REQUIRE((q_out == nullptr) == (q_scale == nullptr), TD_ERR_INVALID, "%s: q_out/q_scale mismatch", who);
+  if (!q_out) { rc = attn_stride_check(who, o_stride_h, o_stride_l); if (rc) return rc; }
   if (rc) return rc;
-  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_attn_16: dtype %d", dtype);
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "%s: dtype %d", who, dtype);
   AttnParams p;
   p.q = q; p.q_s = nullptr; p.k = k; p.k_s = nullptr; p.vt = (const uint16_t*)vt; p.lut = lut;
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
+  p.q_stride_h = q_stride_h; p.q_stride_l = q_stride_l; p.q_rstd = q_rstd; p.q_w = q_w;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
   if (Lk_alloc == 0) Lk_alloc = Lk;
@@ -472,9 +499,30 @@ extern "C" int td_attn_16_ex(const void* q, const void* k, const void* vt, const
   return launch_attn<false, TD_F16, TD_F16>(p, st);
 }
 
-extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel,
-                          void* o, int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale,
-                          int64_t L, int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream) {
+extern "C" int td_attn_16_ex(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel,
+                             void* o, int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale,
+                             int64_t L, int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out,
+                             float* q_scale, td_stream_t stream) {
+  return attn_16_impl("td_attn_16", q, 0, 0, nullptr, nullptr, k, vt, lut, nsel, o, dtype, o_stride_h, o_stride_l,
+                      sm_scale, L, Lk, Lk_alloc, H, add_t, q_out, q_scale, stream);
+}
+
+extern "C" int td_attn_16(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
+                          int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+                          int64_t Lk, int64_t Lk_alloc, int H, td_stream_t stream) {
   return td_attn_16_ex(q, k, vt, lut, nsel, o, dtype, o_stride_h, o_stride_l, sm_scale, L, Lk, Lk_alloc, H, nullptr,
                        nullptr, nullptr, stream);
+}
+
+// Q taken straight from a [L, ld_q] linear output (head h = columns [128h, 128h+128)) with its full-width RMSNorm
+// applied on load: q = cast(x * rstd[l] * w) — td_qk_norm_rope without RoPE (the cross-attention Q of
+// WanT2VCrossAttention.forward, wan2pt1.py:289) minus its 4-byte-per-element round trip.  rstd from td_rms_stats.
+extern "C" int td_attn_16_qnorm(const void* q_src, int64_t ld_q, const float* q_rstd, const float* q_w, const void* k,
+                                const void* vt, const int32_t* lut, int nsel, void* o, int dtype, int64_t o_stride_h,
+                                int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int64_t Lk_alloc, int H,
+                                const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream) {
+  TD_REQUIRE(q_rstd && q_w, TD_ERR_INVALID, "td_attn_16_qnorm: null rstd / weight");
+  TD_REQUIRE(ld_q >= (int64_t)H * 128 && ld_q % 8 == 0, TD_ERR_INVALID, "td_attn_16_qnorm: ld_q=%lld", (long long)ld_q);
+  return attn_16_impl("td_attn_16_qnorm", q_src, 256, ld_q * 2, q_rstd, q_w, k, vt, lut, nsel, o, dtype, o_stride_h,
+                      o_stride_l, sm_scale, L, Lk, Lk_alloc, H, add_t, q_out, q_scale, stream);
 }

@@ -244,6 +244,63 @@ extern "C" int td_gated_residual(void* x, const void* y, const float* gate, int6
 }
 
 // ---------------------------------------------------------------------------------------
+// row statistic of RMSNorm alone: rstd[l] = 1/sqrt(mean(x[l,:]^2) + eps), same summation order as
+// qk_norm_rope_kernel, for consumers that apply the normalisation themselves (td_attn_16_qnorm)
+// ---------------------------------------------------------------------------------------
+template <int NV, int DT>
+__global__ __launch_bounds__(256) void rms_stats_kernel(const uint16_t* __restrict__ src, int64_t ld_src,
+                                                        float* __restrict__ rstd, float eps, int64_t L, int n) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= L) return;
+  float sq = 0.f;
+  uint4 raw[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int col = (v * 64 + lane) * 8;
+    raw[v] = make_uint4(0, 0, 0, 0);
+    if (col < n) raw[v] = *reinterpret_cast<const uint4*>(src + row * ld_src + col);
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    float f[8];
+    unpack8<DT>(raw[v], f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sq += f[j] * f[j];
+  }
+  const float r = 1.0f / sqrtf(wave_sum(sq) / (float)n + eps);
+  if (lane == 0) rstd[row] = r;
+}
+
+extern "C" int td_rms_stats(const void* src, int64_t ld_src, int dtype, float* rstd, float eps, int64_t L, int64_t n,
+                            td_stream_t stream) {
+  TD_REQUIRE(src && rstd, TD_ERR_INVALID, "td_rms_stats: null pointer");
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_rms_stats: dtype %d", dtype);
+  TD_REQUIRE(n > 0 && n % 8 == 0 && n <= 8192 && ld_src >= n && ld_src % 8 == 0, TD_ERR_UNSUPPORTED,
+             "td_rms_stats: n=%lld ld=%lld", (long long)n, (long long)ld_src);
+  if (L == 0) return TD_OK;
+  const int nv = (int)td_cdiv(n, 512);
+  dim3 grid((unsigned)td_cdiv(L, 4));
+  hipStream_t st = (hipStream_t)stream;
+#define TD_RS_NV(NV_)                                                                                        \
+  do {                                                                                                       \
+    if (dtype == TD_BF16) rms_stats_kernel<NV_, TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)src, ld_src, rstd, eps, L, (int)n); \
+    else rms_stats_kernel<NV_, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)src, ld_src, rstd, eps, L, (int)n);                   \
+  } while (0)
+  if (nv <= 1) TD_RS_NV(1);
+  else if (nv <= 2) TD_RS_NV(2);
+  else if (nv <= 3) TD_RS_NV(3);
+  else if (nv <= 4) TD_RS_NV(4);
+  else if (nv <= 6) TD_RS_NV(6);
+  else if (nv <= 8) TD_RS_NV(8);
+  else if (nv <= 10) TD_RS_NV(10);
+  else TD_RS_NV(16);
+#undef TD_RS_NV
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // q/k: RMSNorm over the full model dim -> cast -> interleaved RoPE (fp32) -> cast -> [H,L,D]
 // ---------------------------------------------------------------------------------------
 template <int NV, int DT>

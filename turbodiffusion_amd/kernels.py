@@ -327,6 +327,32 @@ def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, 
     return (oq, os_) if quant_out else out
 
 
+def rms_stats(src, n, eps):
+    """src [L, ld] 16-bit -> rstd f32 [L] = 1/sqrt(mean(src[:, :n]^2) + eps) (the row statistic of td_qk_norm_rope)."""
+    require_gpu(src)
+    assert src.dim() == 2 and src.stride(1) == 1
+    rstd = torch.empty((src.shape[0],), dtype=torch.float32, device=src.device)
+    call("td_rms_stats", ptr(src), src.stride(0), dt_code(src.dtype), ptr(rstd), float(eps), src.shape[0], n, stream_ptr())
+    return rstd
+
+
+def attn_16_qnorm(q_src, rstd, w, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, quant_out=False):
+    """attn_16 whose Q is a [L, H*128] linear output normalised on load (== attn_16(qk_norm_rope(q_src, w, no RoPE), ...))."""
+    require_gpu(q_src, rstd, w, k, vt, lut)
+    H, lk_alloc, D = k.shape
+    L_ = q_src.shape[0]
+    Lk = lk_alloc if lk is None else lk
+    assert D == 128 and vt.dtype == q_src.dtype and q_src.stride(1) == 1 and w.dtype == torch.float32
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    nsel = 0 if lut is None else lut.shape[-1]
+    oq, os_ = _attn_quant_outputs(L_, H, q_src.device) if quant_out else (None, None)
+    call("td_attn_16_qnorm", ptr(q_src), q_src.stride(0), ptr(rstd), ptr(w), ptr(k), ptr(vt), ptr(lut), nsel,
+         None if quant_out else ptr(out), dt_code(q_src.dtype), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc,
+         H, None, ptr(oq), ptr(os_), stream_ptr())
+    return (oq, os_) if quant_out else out
+
+
 # ----------------------------------------------------------------------------- a14
 SLA_NCH = 32  # TD_SLA_NCH in include/turbodiffusion_amd.h
 

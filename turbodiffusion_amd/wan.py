@@ -144,6 +144,7 @@ class WanModel(nn.Module):
         self._rope_cache = {}
         self.seq_parallel = None  # set by turbodiffusion_amd.seqpar.enable(...)
         self.fuse_norm_quant = True
+        self.fuse_cross_q_norm = True
 
     # ------------------------------------------------------------------ weights
     @torch.no_grad()
@@ -284,11 +285,16 @@ class WanModel(nn.Module):
         L_ = xn[0].shape[0] if isinstance(xn, tuple) else xn.shape[0]
         Lc = context.shape[0]
         qc = self._lin_q(ca.q, xn[0], xn[1], context.dtype) if isinstance(xn, tuple) else self._lin(ca.q, xn)
-        q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
         kv = self._fused_lin(context, f["ckv_w"], f.get("ckv_s"), f["ckv_b"])  # [Lc, 2*dim]
         k = K.qk_norm_rope(kv, 0, H, D, ca.norm_k.weight, None, None, self.eps)
         vt = K.v_transpose(kv[:, dim:], D, 2 * dim, Lc, H, D, context.dtype)
         out = None if quant_out else torch.empty((L_, dim), dtype=context.dtype, device=context.device)
+        if self.fuse_cross_q_norm:
+            # RMSNorm(q) applied where the attention kernel loads Q: the head-major normalised copy is never written
+            # (one statistics pass over q instead of td_qk_norm_rope's read + write; bit-identical)
+            rstd = K.rms_stats(qc, dim, self.eps)
+            return K.attn_16_qnorm(qc, rstd, ca.norm_q.weight, k, vt, None, out, D, dim, quant_out=quant_out)
+        q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
         return K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
 
     def _block(self, i, blk, x, e0_B_6_D, cos, sin, context):
