@@ -86,23 +86,33 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
   float ks_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   float km_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // plain column sums of k (rows past L are loaded as 0): the smooth-K mean
 
+  // The V^T tile (contiguous 16 KB) and this thread's 4 K rows of block kb+1 are requested as soon as block kb's copies
+  // have been consumed (V^T: after its LDS write; K: after the softmax) INTO THE SAME REGISTERS, so the HBM round trip
+  // runs under the softmax / MFMA phase without a second set of staging registers (a separate prefetch set spilled).
+  uint4 vv[4], kr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    vv[i] = make_uint4(0, 0, 0, 0);
+    if (kb_lo < kb_hi)
+      vv[i] = *reinterpret_cast<const uint4*>(vt + ((int64_t)h * Kb + kb_lo) * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int64_t l = (int64_t)kb_lo * 64 + 4 * tg + t;
+    kr[t] = make_uint4(0, 0, 0, 0);
+    if (kb_lo < kb_hi && l < L) kr[t] = *reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8);
+  }
   for (int kb = kb_lo; kb < kb_hi; ++kb) {
-    // global loads first: the V^T tile (contiguous 16 KB) and this thread's 4 K rows
-    // (a register-level prefetch of block kb+1 was tried: the extra 32 VGPRs spill, 59 -> 141 us)
-    uint4 vv[4], kr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      vv[i] = *reinterpret_cast<const uint4*>(vt + ((int64_t)h * Kb + kb) * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int64_t l = (int64_t)kb * 64 + 4 * tg + t;
-      kr[t] = make_uint4(0, 0, 0, 0);
-      if (l < L) kr[t] = *reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8);
-    }
+    const bool more = kb + 1 < kb_hi;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int v = tid + 256 * i;
       *reinterpret_cast<uint4*>(vT + sw128(v >> 3, v & 7)) = vv[i];
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        vv[i] = *reinterpret_cast<const uint4*>(vt + ((int64_t)h * Kb + kb + 1) * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
     }
     // softmax over D (16 lanes share a row), rounded to KDT; ck[t][j]
     float ck[4][8];
@@ -133,6 +143,14 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
         unpack2<KDT>(w, ck[t][j], ck[t][j + 1]);
         ks_acc[j] += ck[t][j];
         ks_acc[j + 1] += ck[t][j + 1];
+      }
+    }
+    if (more) {  // this thread's K rows of the next block (the current ones are consumed)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int64_t l = (int64_t)(kb + 1) * 64 + 4 * tg + t;
+        kr[t] = make_uint4(0, 0, 0, 0);
+        if (l < L) kr[t] = *reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8);
       }
     }
     // transposed write: for channel d1 = 8c8+j the 4 tokens are one 8-byte piece
