@@ -299,8 +299,9 @@ def main():
                 sp_leg.update({"ranks": world, "ms_per_video": dt2 * 1e3, "dit_step_ms": dt2 * 1e3 / args.num_steps,
                                "videos_per_s": 1.0 / dt2, "speedup_vs_one_gpu": (elapsed / args.steps) / dt2,
                                "videos_timed": n_v, "launch_mode": "eager enqueue",
-                               "collective": "one packed all-gather of int8 K | fp16 V^T | scales | pooled K | linear-branch "
-                                             "partials per self-attention layer + one of the head output per step"})
+                               "collective": "packed all-gather of int8 K | fp16 V^T | scales | pooled K | linear-branch partials per "
+                                             "self-attention layer (4 head-group pieces, attention pipelined behind them) + one "
+                                             "of the head output per step"})
             except Exception as e:  # reported, never fatal for the headline number
                 sp_leg["error"] = repr(e)
 

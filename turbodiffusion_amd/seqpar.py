@@ -6,7 +6,9 @@ therefore whole 64-key K blocks).  Everything in a transformer block is token-lo
 self-attention, which needs the K side of every rank.  Per self-attention layer:
 
   1. tiny all-gather of the per-head K column sums (-> the global smooth-K mean, SLA/core.py:197);
-  2. ONE all-gather of a packed per-rank buffer holding the rank's *quantised* K-side state:
+  2. an all-gather (issued as ``head_groups`` consecutive asynchronous pieces, one per group of heads, so that
+     attention on the first heads runs while the later heads' bytes are still on the links) of a packed per-rank
+     buffer holding the rank's *quantised* K-side state:
          K int8 [H, per, 128] | V^T fp16 MFMA tiles [H, per/64, 128, 64] | K scales | pooled K blocks |
          fp32 linear-branch partials (ck^T v [H,128,128], sum ck [H,128])
      (3 B per token-channel instead of the reference Ulysses path's 4 all-to-alls of bf16 q,k,v,o:
@@ -44,6 +46,7 @@ class SeqParallel:
             from . import kernels as ops  # HIP; raises on CPU tensors
         self.ops = ops
         self.L = None
+        self.head_groups = 4   # self-attention K/V exchange and attention pipelined over this many head groups
 
     # ------------------------------------------------------------------ token sharding
     def plan(self, L: int):
@@ -122,79 +125,92 @@ class SeqParallel:
         if linear:
             kv32, ks32 = ops.sla_linear_kv_partial_f32(k, vt)
 
+        # ---- (2) + (3), pipelined over head groups: every group's K-side state is packed and its all-gather issued
+        # (asynchronously, RCCL's own stream executes them in order); then, group by group, the gather is awaited and
+        # that group's block map / attention / linear branch run while the later groups' bytes are still on the links.
+        # The bytes on the wire are the same as with one gather; what changes is that attention — about a third of a
+        # layer's compute — now overlaps most of the exchange instead of waiting for all of it.
         k_elem = 1 if sage else 2
-        sizes = {
-            "k": H * per * D * k_elem,
-            "vt": H * kbp * D * 64 * 2,
-            "ks": H * kbp * 4 if sage else 0,
-            "pk": H * kbp * D * 2 if not dense else 0,
-            "kv": H * D * D * 4 if linear else 0,
-            "kss": H * D * 4 if linear else 0,
-        }
-        offs, o = {}, 0
-        for name, sz in sizes.items():
-            offs[name] = o
-            o += _cdiv(sz, 256) * 256
-        pack = torch.zeros(o, dtype=torch.uint8, device=dev)
-
-        def slot(name, dtype, shape):
-            n = sizes[name]
-            return pack[offs[name]:offs[name] + n].view(dtype).view(shape)
-
-        if sage:
-            slot("k", torch.int8, (H, per, D))[:, :L_loc] = k_q
-            slot("ks", torch.float32, (H, kbp))[:, :kb_loc] = k_s
-        else:
-            slot("k", dt, (H, per, D))[:, :L_loc] = k
-        slot("vt", pdt, (H, kbp, D, 64))[:, :kb_loc] = vt
-        if not dense:
-            slot("pk", dt, (H, kbp, D))[:, :kb_loc] = pk
-        if linear:
-            slot("kv", torch.float32, (H, D, D)).copy_(kv32)
-            slot("kss", torch.float32, (H, D)).copy_(ks32)
-
-        allb, work = self.all_gather(pack, async_op=True)  # [W, bytes]; in flight while the Q side is prepared
+        n_groups = min(self.head_groups, H)
+        bounds = [(H * g) // n_groups for g in range(n_groups + 1)]
         pq = q_q = q_s = None
-        if sage:
-            pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
-        elif not dense:
-            pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
-        if work is not None:
-            work.wait()
+        inflight = []
+        for g in range(n_groups):
+            h0, h1 = bounds[g], bounds[g + 1]
+            Hg = h1 - h0
+            sizes = {
+                "k": Hg * per * D * k_elem,
+                "vt": Hg * kbp * D * 64 * 2,
+                "ks": Hg * kbp * 4 if sage else 0,
+                "pk": Hg * kbp * D * 2 if not dense else 0,
+                "kv": Hg * D * D * 4 if linear else 0,
+                "kss": Hg * D * 4 if linear else 0,
+            }
+            offs, o = {}, 0
+            for name, sz in sizes.items():
+                offs[name] = o
+                o += _cdiv(sz, 256) * 256
+            pack = torch.zeros(o, dtype=torch.uint8, device=dev)
 
-        def gathered(name, dtype, shape):  # [W, *shape] strided VIEW of one field (no copy)
-            n = sizes[name]
-            return allb[:, offs[name]:offs[name] + n].view(dtype).view((W,) + shape)
+            def slot(name, dtype, shape, pack=pack, sizes=sizes, offs=offs):
+                n = sizes[name]
+                return pack[offs[name]:offs[name] + n].view(dtype).view(shape)
 
-        def seq_major(t):  # [W, H, n, ...] -> [H, W*n, ...]
+            if sage:
+                slot("k", torch.int8, (Hg, per, D))[:, :L_loc] = k_q[h0:h1]
+                slot("ks", torch.float32, (Hg, kbp))[:, :kb_loc] = k_s[h0:h1]
+            else:
+                slot("k", dt, (Hg, per, D))[:, :L_loc] = k[h0:h1]
+            slot("vt", pdt, (Hg, kbp, D, 64))[:, :kb_loc] = vt[h0:h1]
+            if not dense:
+                slot("pk", dt, (Hg, kbp, D))[:, :kb_loc] = pk[h0:h1]
+            if linear:
+                slot("kv", torch.float32, (Hg, D, D)).copy_(kv32[h0:h1])
+                slot("kss", torch.float32, (Hg, D)).copy_(ks32[h0:h1])
+            allb, work = self.all_gather(pack, async_op=True)  # [W, bytes]
+            inflight.append((h0, h1, sizes, offs, allb, work))
+            if g == 0:  # the Q side of this rank (all heads) is prepared under the first transfers
+                if sage:
+                    pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
+                elif not dense:
+                    pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
+
+        def seq_major(t):  # [W, Hg, n, ...] -> [Hg, W*n, ...]
             return t.permute(1, 0, 2, *range(3, t.dim())).reshape(t.shape[1], W * t.shape[2], *t.shape[3:]).contiguous()
 
-        vt_all = seq_major(gathered("vt", pdt, (H, kbp, D, 64)))                  # [H, W*kbp, D, 64]
-        if sage:
-            k_all = seq_major(gathered("k", torch.int8, (H, per, D)))              # [H, W*per, D]
-            ks_all = seq_major(gathered("ks", torch.float32, (H, kbp)))            # [H, W*kbp]
-        else:
-            k_all = seq_major(gathered("k", dt, (H, per, D)))
+        topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
+        for (h0, h1, sizes, offs, allb, work) in inflight:
+            if work is not None:
+                work.wait()
+            Hg = h1 - h0
 
-        # ---- (3) this rank's Q blocks against the global K/V ----
-        lut = None
-        if not dense:
-            pk_all = seq_major(gathered("pk", dt, (H, kbp, D)))                    # [H, W*kbp, D]
-            topk = min(kb_tot, int(topk_ratio * kb_tot))
-        if sage:
-            if not dense:
-                lut = ops.sla_topk(pq, pk_all, topk, kb=kb_tot)
-            ops.attn_i8(q_q, q_s, k_all, ks_all, vt_all, lut, out, o_stride_h, o_stride_l, lk=L)
-        else:
-            if not dense:
-                lut = ops.sla_topk(pq, pk_all, topk, kb=kb_tot)
-            ops.attn_16(q, k_all, vt_all, lut, out, o_stride_h, o_stride_l, lk=L)
-        if linear:
-            kv_parts = gathered("kv", torch.float32, (H, D, D))   # [W, H, D, D]
-            ks_parts = gathered("kss", torch.float32, (H, D))     # [W, H, D]
-            kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D,
-                                                 ks_parts.stride(0), H, D, dt)
-            ops.sla_linear_out_(q, kv_t, ksum, proj_w, proj_b, out, o_stride_h, o_stride_l)
+            def gathered(name, dtype, shape, allb=allb, sizes=sizes, offs=offs):  # [W, *shape] strided VIEW (no copy)
+                n = sizes[name]
+                return allb[:, offs[name]:offs[name] + n].view(dtype).view((W,) + shape)
+
+            vt_all = seq_major(gathered("vt", pdt, (Hg, kbp, D, 64)))              # [Hg, W*kbp, D, 64]
+            out_g = out.view(-1)[h0 * o_stride_h:]   # same buffer, origin moved to the group's first head
+            lut = None
+            if sage:
+                k_all = seq_major(gathered("k", torch.int8, (Hg, per, D)))         # [Hg, W*per, D]
+                ks_all = seq_major(gathered("ks", torch.float32, (Hg, kbp)))       # [Hg, W*kbp]
+                if not dense:
+                    pk_all = seq_major(gathered("pk", dt, (Hg, kbp, D)))           # [Hg, W*kbp, D]
+                    lut = ops.sla_topk(pq[h0:h1].contiguous(), pk_all, topk, kb=kb_tot)
+                ops.attn_i8(q_q[h0:h1].contiguous(), q_s[h0:h1].contiguous(), k_all, ks_all, vt_all, lut, out_g,
+                            o_stride_h, o_stride_l, lk=L)
+            else:
+                k_all = seq_major(gathered("k", dt, (Hg, per, D)))
+                if not dense:
+                    pk_all = seq_major(gathered("pk", dt, (Hg, kbp, D)))
+                    lut = ops.sla_topk(pq[h0:h1].contiguous(), pk_all, topk, kb=kb_tot)
+                ops.attn_16(q[h0:h1].contiguous(), k_all, vt_all, lut, out_g, o_stride_h, o_stride_l, lk=L)
+            if linear:
+                kv_parts = gathered("kv", torch.float32, (Hg, D, D))   # [W, Hg, D, D]
+                ks_parts = gathered("kss", torch.float32, (Hg, D))     # [W, Hg, D]
+                kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D,
+                                                     ks_parts.stride(0), Hg, D, dt)
+                ops.sla_linear_out_(q[h0:h1].contiguous(), kv_t, ksum, proj_w, proj_b, out_g, o_stride_h, o_stride_l)
         return out
 
 
