@@ -289,61 +289,92 @@ extern "C" int td_sage_quant_pool(const void* x, const void* km, int dtype, int 
 }
 
 // ---------------------------------------------------------------------------------------
-// pooled score + top-k.  One workgroup per 16 Q-block rows of one head:
-//   phase 1: thread t computes the 16 scores of K-block column j = c*256 + t (fp32 dot over
-//            D = 128, rounded to the 16-bit dtype like the reference's bf16 matmul)
-//   phase 2: each wave selects the top-k of 4 rows: binary search on the order-preserving
-//            16-bit key for the k-th largest value, then an ordered ballot compaction
-//            (ties at the threshold -> lowest index first) => ascending LUT.
+// pooled score + top-k.  One 256-thread workgroup per 4 pooled-Q rows of one head (768 workgroups at the Wan 480p
+// shape):
+//   phase 1: scores of the 4 rows against 64 pooled keys at a time on v_mfma_f32_16x16x32 (the 4 rows are rows 0-3 of
+//            the 16-row A operand; wave w owns keys 16w..16w+15 of the chunk), fp32 accumulate, rounded to the 16-bit
+//            dtype like the reference's bf16 matmul (SLA/utils.py:59).  (The first version accumulated the 128 products
+//            per score with scalar FMAs: 176 VALU + 48 LDS reads per thread and chunk made the kernel instruction-bound
+//            at 37 us for 1.5 M scores.)
+//   phase 2: wave w selects the top-k of row w: binary search on the order-preserving 16-bit key for the k-th
+//            largest value, then an ordered ballot compaction (ties at the threshold -> lowest index first) =>
+//            ascending LUT.
 // ---------------------------------------------------------------------------------------
 #define TK_ROWS 4
 #define TK_MAXKB 2048
-// One 256-thread workgroup per 4 pooled-Q rows of one head (768 workgroups at the Wan 480p shape: three per CU, so
-// the LDS-latency-bound dot products of one overlap the ballots of another — with 16 rows per workgroup the grid was
-// 192 single-wave-per-SIMD workgroups and the kernel ran 87 us for 1.5 M scores).  Wave w owns row w.
-template <int DT>
+template <int DT> struct TkMma;
+template <> struct TkMma<TD_BF16> {
+  typedef v8bf frag;
+  __device__ static __forceinline__ v4f mma(frag a, frag b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct TkMma<TD_F16> {
+  typedef v8h frag;
+  __device__ static __forceinline__ v4f mma(frag a, frag b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+template <int DT, int NPER>   // NPER >= ceil(Kb / 64): the wave's row lives in NPER registers per lane during the selection
 __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restrict__ pq,
                                                        const uint16_t* __restrict__ pk,
                                                        int32_t* __restrict__ lut, int Qb, int Kb,
                                                        int Kb_alloc, int topk) {
   extern __shared__ __attribute__((aligned(16))) char smem_tk[];
-  float* qs = reinterpret_cast<float*>(smem_tk);                           // [4][128] fp32
-  uint16_t* sc = reinterpret_cast<uint16_t*>(smem_tk + TK_ROWS * 128 * 4);  // [4][Kb] sortable keys
-  uint4* ktile = reinterpret_cast<uint4*>(smem_tk + TK_ROWS * 128 * 4 + (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15));
+  uint16_t* sc = reinterpret_cast<uint16_t*>(smem_tk);                      // [4][Kb] sortable keys
+  uint4* ktile = reinterpret_cast<uint4*>(smem_tk + (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15));
+  typedef typename TkMma<DT>::frag frag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, lq = lane >> 4;
   const int h = blockIdx.y, row0 = blockIdx.x * TK_ROWS;
-  for (int i = tid; i < TK_ROWS * 128; i += 256) {
-    const int r = i >> 7, d = i & 127;
-    const int qr = row0 + r < Qb ? row0 + r : Qb - 1;
-    qs[i] = half_bits_to_f32<DT>(pq[((int64_t)h * Qb + qr) * 128 + d]);
+  // A fragments: pooled-Q row l16 (rows 4..15 of the operand are zero), d = 32*ks + 8*lq .. +7
+  uint4 qa[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qa[ks] = make_uint4(0, 0, 0, 0);
+    if (l16 < TK_ROWS) {
+      const int qr = row0 + l16 < Qb ? row0 + l16 : Qb - 1;
+      qa[ks] = *reinterpret_cast<const uint4*>(pq + ((int64_t)h * Qb + qr) * 128 + 32 * ks + 8 * lq);
+    }
   }
-  __syncthreads();
   // scores, 64 keys at a time: the 16 KB of pooled keys are fetched with fully coalesced 16-byte loads into LDS
-  // (rows padded to 272 B); thread (key = lane, row = wave) accumulates 128 d in the fp32 fma order of a plain dot product
+  // (rows padded to 272 B: lane = key reads are conflict-free); the next chunk is requested before this one is used
+  uint4 nxt[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = tid + 256 * it, key = idx >> 4, v = idx & 15;
+    nxt[it] = make_uint4(0, 0, 0, 0);
+    if (key < Kb) nxt[it] = *reinterpret_cast<const uint4*>(pk + ((int64_t)h * Kb_alloc + key) * 128 + v * 8);
+  }
   for (int c0 = 0; c0 < Kb; c0 += 64) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int idx = tid + 256 * it, key = idx >> 4, v = idx & 15;
-      uint4 val = make_uint4(0, 0, 0, 0);
-      if (c0 + key < Kb) val = *reinterpret_cast<const uint4*>(pk + ((int64_t)h * Kb_alloc + c0 + key) * 128 + v * 8);
-      ktile[key * 17 + v] = val;
+      ktile[key * 17 + v] = nxt[it];
+    }
+    if (c0 + 64 < Kb) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 256 * it, key = idx >> 4, v = idx & 15;
+        nxt[it] = make_uint4(0, 0, 0, 0);
+        if (c0 + 64 + key < Kb) nxt[it] = *reinterpret_cast<const uint4*>(pk + ((int64_t)h * Kb_alloc + c0 + 64 + key) * 128 + v * 8);
+      }
     }
     __syncthreads();
     {
-      float acc = 0.f;
-      const float* qrow = qs + wave * 128;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int d8 = 0; d8 < 16; ++d8) {
-        float kf[8];
-        unpack8<DT>(ktile[lane * 17 + d8], kf);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(qrow[d8 * 8 + e], kf[e], acc);
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint4 kb_ = ktile[(16 * wave + l16) * 17 + 4 * ks + lq];   // B: key 16*wave + l16, d = 32*ks + 8*lq .. +7
+        acc = TkMma<DT>::mma(*reinterpret_cast<const frag*>(&qa[ks]), *reinterpret_cast<const frag*>(&kb_), acc);
       }
-      if (c0 + lane < Kb) {
-        uint32_t b = f32_to_half_bits<DT>(acc);
-        // order-preserving map of a 16-bit float to an unsigned key (larger value -> larger key)
-        b = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
-        sc[wave * Kb + c0 + lane] = (uint16_t)b;
+      // D[i][j]: lane holds key j = l16 and rows i = 4*lq + r; the 4 real rows are r = 0..3 of the lanes with lq == 0
+      const int key = c0 + 16 * wave + l16;
+      if (lq == 0 && key < Kb) {
+#pragma unroll
+        for (int r = 0; r < TK_ROWS; ++r) {
+          uint32_t b = f32_to_half_bits<DT>(acc[r]);
+          // order-preserving map of a 16-bit float to an unsigned key (larger value -> larger key)
+          b = (b & 0x8000u) ? (~b & 0xffffu) : (b | 0x8000u);
+          sc[r * Kb + key] = (uint16_t)b;
+        }
       }
     }
     __syncthreads();
@@ -354,30 +385,34 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
   const uint16_t* keys = sc + r * Kb;
   const int nper = (Kb + 63) >> 6;
   // largest T with count(key >= T) >= topk
-  uint32_t lo = 0, hi = 0xffffu;  // invariant: count(>= lo) >= topk
+  // the row's Kb sortable keys: key t*64 + lane in register t (0 = below every real key, never selected); every count
+  // of the search is then NPER compares + scalar popcounts, no memory access
+  uint32_t kv[NPER];
+#pragma unroll
+  for (int t = 0; t < NPER; ++t) {
+    const int j = t * 64 + lane;
+    kv[t] = j < Kb ? keys[j] : 0u;
+  }
+  uint32_t lo = 1, hi = 0xffffu;  // invariant: count(>= lo) >= topk   (real keys are >= 1)
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1) >> 1;
     int cnt = 0;
-    for (int t = 0; t < nper; ++t) {
-      const int j = t * 64 + lane;
-      cnt += __popcll(__ballot(j < Kb && keys[j] >= mid));
-    }
+#pragma unroll
+    for (int t = 0; t < NPER; ++t) cnt += __popcll(__ballot(kv[t] >= mid));
     if (cnt >= topk) lo = mid; else hi = mid - 1;
   }
   const uint32_t T = lo;
   int gt = 0;
-  for (int t = 0; t < nper; ++t) {
-    const int j = t * 64 + lane;
-    gt += __popcll(__ballot(j < Kb && keys[j] > T));
-  }
+#pragma unroll
+  for (int t = 0; t < NPER; ++t) gt += __popcll(__ballot(kv[t] > T));
   const int need_eq = topk - gt;  // how many ties at T to take (lowest index first)
   int32_t* out = lut + ((int64_t)h * Qb + row0 + r) * topk;
   int written = 0, eq_seen = 0;
-  for (int t = 0; t < nper; ++t) {
+#pragma unroll
+  for (int t = 0; t < NPER; ++t) {
     const int j = t * 64 + lane;
-    const uint32_t kv = j < Kb ? keys[j] : 0;
-    const bool is_gt = j < Kb && kv > T;
-    const bool is_eq = j < Kb && kv == T;
+    const bool is_gt = kv[t] > T;
+    const bool is_eq = kv[t] == T;
     const unsigned long long meq = __ballot(is_eq);
     const int eq_before = __popcll(meq & ((1ull << lane) - 1ull));
     const bool take = is_gt || (is_eq && (eq_seen + eq_before) < need_eq);
@@ -398,20 +433,24 @@ extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* l
   TD_REQUIRE(Kb >= 1 && Kb <= TK_MAXKB, TD_ERR_UNSUPPORTED, "td_sla_topk: Kb=%d (max %d)", Kb, TK_MAXKB);
   TD_REQUIRE(topk >= 1 && topk <= Kb, TD_ERR_INVALID, "td_sla_topk: topk=%d Kb=%d", topk, Kb);
   TD_REQUIRE(H > 0 && Qb > 0, TD_ERR_INVALID, "td_sla_topk: H=%d Qb=%d", H, Qb);
-  const size_t lds = TK_ROWS * 128 * 4 + (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15) + 64 * 17 * 16;
+  const size_t lds = (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15) + 64 * 17 * 16;
   dim3 grid((unsigned)td_cdiv(Qb, TK_ROWS), H);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TD_BF16) {
-    static bool a = false;
-    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<TD_BF16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2 + 64 * 17 * 16); a = true; }
-    sla_topk_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk);
-  } else {
-    static bool a = false;
-    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<TD_F16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 8192 + TK_ROWS * TK_MAXKB * 2 + 64 * 17 * 16); a = true; }
-    sla_topk_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk);
+  const int nper = (Kb + 63) / 64;
+#define TD_TK(DT_, NP_)                                                                                            \
+  {                                                                                                                \
+    static bool a = false;                                                                                         \
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<DT_, NP_>),                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, TK_ROWS * TK_MAXKB * 2 + 16 + 64 * 17 * 16); a = true; } \
+    sla_topk_kernel<DT_, NP_><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk); \
   }
+#define TD_TK_DT(DT_)                                                                                              \
+  {                                                                                                                \
+    if (nper <= 8) TD_TK(DT_, 8) else if (nper <= 16) TD_TK(DT_, 16) else if (nper <= 24) TD_TK(DT_, 24) else TD_TK(DT_, 32) \
+  }
+  if (dtype == TD_BF16) TD_TK_DT(TD_BF16) else TD_TK_DT(TD_F16)
+#undef TD_TK_DT
+#undef TD_TK
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
