@@ -383,7 +383,6 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
   const int r = wave;
   if (row0 + r >= Qb) return;
   const uint16_t* keys = sc + r * Kb;
-  const int nper = (Kb + 63) >> 6;
   // largest T with count(key >= T) >= topk
   // the row's Kb sortable keys: key t*64 + lane in register t (0 = below every real key, never selected); every count
   // of the search is then NPER compares + scalar popcounts, no memory access
