@@ -4,7 +4,6 @@ TEST INFRASTRUCTURE (see oracle/__init__.py).  torch-CPU, IEEE fp32.
 """
 from __future__ import annotations
 
-import math
 import torch
 
 BLOCK = 128  # turbodiffusion/ops/quant/quant.hpp:38 (BlockSize), gemm tile K

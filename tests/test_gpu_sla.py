@@ -1,6 +1,5 @@
 """-m gpu parity tests: attention path (block map, Sage quant, sparse/dense attention, linear branch)
 through the C-ABI vs the CPU oracle."""
-import math
 
 import pytest
 import torch

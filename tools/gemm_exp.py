@@ -1,6 +1,6 @@
 """GEMM experiments (profiling aid): row-stride padding (L2 channel spread), raster group size, DMA schedule.
 Results of padded runs are garbage by construction (the operands are read with a different stride); only time matters."""
-import ctypes, math, sys, os, json
+import sys, os, json
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from turbodiffusion_amd import kernels as K, _lib as L

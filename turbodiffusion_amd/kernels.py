@@ -8,7 +8,7 @@ status for everything it cannot run.
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

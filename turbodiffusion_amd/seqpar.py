@@ -26,9 +26,6 @@ without a GPU.  There is no silent fallback: ``ops=None`` means HIP.
 """
 from __future__ import annotations
 
-import math
-from typing import Optional
-
 import torch
 import torch.distributed as dist
 
