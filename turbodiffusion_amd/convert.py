@@ -81,6 +81,7 @@ def load_checkpoint(net: WanModel, ckpt: Dict) -> WanModel:
             raise KeyError(f"checkpoint/model mismatch: unexpected {unexpected[:4]}, missing {missing[:4]}")
         net.load_state_dict({k: v.to(own[k].device) for k, v in sd.items()}, assign=False)
         net._fused.clear()
+        net._ckv_all = None
     else:
         dev = next(net.parameters()).device
         net.load_from_float_state_dict({k: (v.to(dev).to(own[k].dtype) if k in own else v.to(dev)) for k, v in sd.items()})

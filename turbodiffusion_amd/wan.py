@@ -145,6 +145,8 @@ class WanModel(nn.Module):
         self.seq_parallel = None  # set by turbodiffusion_amd.seqpar.enable(...)
         self.fuse_norm_quant = True
         self.fuse_cross_q_norm = True
+        self.batch_text_kv = True
+        self._ckv_all = None
 
     # ------------------------------------------------------------------ weights
     @torch.no_grad()
@@ -173,6 +175,7 @@ class WanModel(nn.Module):
             raise KeyError(f"missing keys {missing[:5]} ...")
         self.load_state_dict(new, assign=False)
         self._fused.clear()
+        self._ckv_all = None
 
     def _lin(self, mod, x, gelu=False):
         """One Linear of a block on a [M, K] activation: W8A8 (HIP) or the plain bf16 library GEMM."""
@@ -244,6 +247,22 @@ class WanModel(nn.Module):
         self._fused[i] = f
         return f
 
+    def _text_kv_all(self, context):
+        """[Lc, dim] text tokens -> [Lc, nblk * 2 * dim]: cross-attention k|v projections of every block, block i in columns
+        [i*2*dim, (i+1)*2*dim).  The concatenated weights replace the per-block copies (views), so nothing is duplicated."""
+        if self._ckv_all is None:
+            fs = [self._fused_weights(i, blk) for i, blk in enumerate(self.blocks)]
+            n2 = 2 * self.dim
+            allw = {k: torch.cat([f[k] for f in fs], 0).contiguous() for k in ("ckv_w", "ckv_s", "ckv_b") if k in fs[0]}
+            for i, f in enumerate(fs):   # per-block entries become views of the concatenation
+                f["ckv_w"] = allw["ckv_w"][i * n2:(i + 1) * n2]
+                f["ckv_b"] = allw["ckv_b"][i * n2:(i + 1) * n2]
+                if "ckv_s" in allw:
+                    f["ckv_s"] = allw["ckv_s"][i * (n2 // 128):(i + 1) * (n2 // 128)]
+            self._ckv_all = allw
+        a = self._ckv_all
+        return self._fused_lin(context, a["ckv_w"], a.get("ckv_s"), a["ckv_b"])
+
     def _fused_lin(self, x, w, s, b):
         if s is not None:
             xq, xs = K.quant_i8_block128(x)
@@ -277,7 +296,7 @@ class WanModel(nn.Module):
                                                 (D, 3 * dim), dense=dense, quant_out=quant_out)
         return res
 
-    def _cross_attention(self, i, blk, xn, context, quant_out=False):
+    def _cross_attention(self, i, blk, xn, context, quant_out=False, text_kv=None):
         """xn [L, dim] (norm3 output), context [Lc, dim] -> [L, dim] (before the o projection)."""
         f = self._fused_weights(i, blk)
         ca = blk.cross_attn
@@ -285,9 +304,12 @@ class WanModel(nn.Module):
         L_ = xn[0].shape[0] if isinstance(xn, tuple) else xn.shape[0]
         Lc = context.shape[0]
         qc = self._lin_q(ca.q, xn[0], xn[1], context.dtype) if isinstance(xn, tuple) else self._lin(ca.q, xn)
-        kv = self._fused_lin(context, f["ckv_w"], f.get("ckv_s"), f["ckv_b"])  # [Lc, 2*dim]
+        if text_kv is not None:   # this block's columns of the all-blocks text K|V projection (forward)
+            kv = text_kv[:, i * 2 * dim:(i + 1) * 2 * dim]
+        else:
+            kv = self._fused_lin(context, f["ckv_w"], f.get("ckv_s"), f["ckv_b"])  # [Lc, 2*dim]
         k = K.qk_norm_rope(kv, 0, H, D, ca.norm_k.weight, None, None, self.eps)
-        vt = K.v_transpose(kv[:, dim:], D, 2 * dim, Lc, H, D, context.dtype)
+        vt = K.v_transpose(kv[:, dim:], D, kv.stride(0), Lc, H, D, context.dtype)
         out = None if quant_out else torch.empty((L_, dim), dtype=context.dtype, device=context.device)
         if self.fuse_cross_q_norm:
             # RMSNorm(q) applied where the attention kernel loads Q: the head-major normalised copy is never written
@@ -297,7 +319,7 @@ class WanModel(nn.Module):
         q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
         return K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
 
-    def _block(self, i, blk, x, e0_B_6_D, cos, sin, context):
+    def _block(self, i, blk, x, e0_B_6_D, cos, sin, context, tkv=None):
         """x: [B, L_loc, dim] (updated in place); e0 fp32 [B, 6, dim]; context [B, Lc, dim]."""
         B, L_loc, dim = x.shape
         e = (blk.modulation.float() + e0_B_6_D)  # fp32 [B, 6, dim]  (wan2pt1.py:400)
@@ -329,7 +351,8 @@ class WanModel(nn.Module):
                 xns = [xn[r] for r in rows]
         else:
             xns = [x2[r] for r in rows]
-        cs = [self._cross_attention(i, blk, xns[b], context[b], quant_out=self.quant_linear and B == 1) for b in range(B)]
+        cs = [self._cross_attention(i, blk, xns[b], context[b], quant_out=self.quant_linear and B == 1,
+                                    text_kv=None if tkv is None else tkv[b]) for b in range(B)]
         c = cs[0] if B == 1 else torch.cat(cs, 0)
         self._residual_lin_(x2, blk.cross_attn.o, c, None)
         # ---- FFN ----
@@ -381,8 +404,13 @@ class WanModel(nn.Module):
         e_B_D = F.linear(F.silu(e), te[2].weight.float(), te[2].bias.float())
         e0 = F.linear(F.silu(e_B_D), tp[1].weight.float(), tp[1].bias.float()).unflatten(1, (6, self.dim))
         context = self.text_embedding(crossattn_emb.to(dt)).contiguous()  # [B, Lc, dim]
+        tkv = None
+        if self.batch_text_kv:
+            # the cross-attention K|V projections of ALL blocks read the same 512 text tokens: one [Lc, nblk*2*dim] GEMM
+            # (2880 tiles) and one quantisation of the text instead of one 96-tile GEMM + quantisation per block
+            tkv = [self._text_kv_all(context[b]) for b in range(B)]
         for i, blk in enumerate(self.blocks):
-            x = self._block(i, blk, x, e0, cos, sin, context)
+            x = self._block(i, blk, x, e0, cos, sin, context, tkv)
         # head (wan2pt1.py:444-454): fp32 modulate of the (bf16) norm, fp32 Linear
         em = (self.head.modulation.float() + e_B_D.unsqueeze(1))  # [B, 2, dim]
         L_loc = x.shape[1]
