@@ -43,6 +43,10 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     assert blkq == 128 and blkk == 64, "MI355X kernels are built for BLKQ=128, BLKK=64"
     kb = K.cdiv(L_, blkk)
     topk = min(kb, int(topk_ratio * kb))
+    if not dense and topk < 1:
+        # SLA/utils.py:61-62 would select zero blocks here (and divide 0 by 0 downstream): refuse instead
+        raise ValueError(f"block-sparse attention with topk ratio {topk_ratio} selects no block of {kb} "
+                         f"(L = {L_} tokens): use a longer sequence or a larger ratio")
     pdt = torch.float16 if sage else q.dtype
     vt = K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, pdt)
     o_l = None
