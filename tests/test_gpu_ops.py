@@ -139,6 +139,36 @@ def test_gemm_fused_residual_bit_exact(K, m, n, k, bias, gated, variant):
     assert torch.equal(out, ref), f"differ at {(out != ref).sum().item()} positions"
 
 
+@pytest.mark.parametrize("m,n,k", [(1000, 1536, 1536), (2050, 264, 384), (1111, 1544, 1280), (3000, 512, 8960)])
+@pytest.mark.parametrize("variant", [4, 5])
+@pytest.mark.parametrize("G", [2, 4, 8])
+@pytest.mark.parametrize("outliers", [False, True])
+def test_gemm_fast_dequant_within_stated_bound(K, m, n, k, variant, G, outliers):
+    """TD_TUNE_GEMM_FAST = G (one-VALU dequant, re-centred every G K blocks) against the exact kernel: the fp32
+    accumulators differ by at most 0.75 (G+1) sum_k s_k (csrc/gemm_w8a8_fi.hip), i.e. the 16-bit outputs by that
+    plus one rounding; and on realistic operands the two agree to rel-L2 < 1e-3 (measured ~1e-4)."""
+    x = act_like(m, k, torch.bfloat16, seed=m + n + k, outliers=outliers).to(DEV)
+    w = (torch.randn(n, k, generator=torch.Generator().manual_seed(k)) / k ** 0.5).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(n, generator=torch.Generator().manual_seed(3)) * 0.1).to(torch.bfloat16).to(DEV)
+    xq, xs = K.quant_i8_block128(x)
+    wq, ws = K.quant_i8_block128(w)
+    K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
+    try:
+        K.set_tuning(K.TUNE_GEMM_FAST, 1)
+        exact = K.gemm_w8a8(xq, xs, wq, ws, torch.bfloat16, bias=b).float()
+        K.set_tuning(K.TUNE_GEMM_FAST, G)
+        fast = K.gemm_w8a8(xq, xs, wq, ws, torch.bfloat16, bias=b).float()
+    finally:
+        K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
+        K.set_tuning(K.TUNE_GEMM_FAST, 0)
+    ssum = (xs[:, None, :] * ws[None, :, :]).sum(-1)
+    bound = 0.75 * (G + 1) * ssum.repeat_interleave(128, 0)[:m].repeat_interleave(128, 1)[:, :n]
+    one_ulp = exact.abs().clamp_min(1e-30) * 2.0 ** -7      # a bf16 ulp is <= 2^-7 |x|
+    d = (fast - exact).abs()
+    assert (d <= bound + one_ulp).all(), f"bound exceeded by {(d / (bound + one_ulp)).max().item():.2f}x"
+    assert rel_l2(fast, exact) < 1e-3
+
+
 def test_gemm_rejects_bad_k(K):
     from turbodiffusion_amd._lib import TurboDiffusionAMDError
     a = torch.zeros(128, 192, dtype=torch.int8, device=DEV)

@@ -23,6 +23,13 @@ extern "C" int td_set_tuning(int key, int value) {
   return TD_OK;
 }
 
+// W8A8 GEMM dequant mode (TD_TUNE_GEMM_FAST).  The C-ABI default is the exact arithmetic of the reference
+// (ops/gemm/utils.hpp:116-121); the one-VALU form is opt-in.
+int td_gemm_fast_g(void) {
+  const int v = g_tuning[TD_TUNE_GEMM_FAST];
+  return (v == 2 || v == 4 || v == 8) ? v : 0;
+}
+
 // profiling aid shared by the GEMM kernels' DBG instantiations: 256 x 64-bit s_memtime stamps in device memory
 static unsigned long long* g_dbg_buf = nullptr;
 unsigned long long* td_dbg_buffer(void) {

@@ -76,7 +76,16 @@ __device__ __forceinline__ uint32_t f_swz(uint32_t row, uint32_t chunk) {
 // RES: the epilogue applies the block's gated residual in place (a7, wan2pt1.py:405-406,412-413):
 //   D[m,n] = D[m,n] + cast(cast(y[m,n]) * cast(gate[n]))  (gate == nullptr: plain add), y = this GEMM's 16-bit result —
 // bit-identical to td_gemm_w8a8 followed by td_gated_residual, minus a 2-byte write, a 2-byte read and a launch.
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false>
+// FAST = G > 0: ONE-VALU dequant (NOT bit-identical to the exact kernel, see the bound below).  The chain's int32 result,
+// read as fp32, IS 1.5*2^23 + isum, so `acc = fma(raw, s, acc)` adds isum*s + M*s (M = 1.5*2^23) with one instruction
+// instead of two; the M*s terms are taken out again every G K blocks by one v_add per accumulator with
+// c = -(fp32)(sum of M*s_k over the group), formed in fp64 with the rounding remainder carried into the next group (and
+// the last remainder applied in the drain), so that exactly M * sum_k s_k is subtracted in total.  What is lost: while
+// up to G+1 offsets ride on an accumulator, each fma rounds at magnitude <= (G+1)*M*s instead of |acc|:
+//   |fast - exact| <= 2^-24 * (G+1) * 1.5*2^23 * sum_k s_k = 0.75 (G+1) sum_k s_k     (fp32, before the 16-bit cast)
+// i.e. < 4 counts of a K block's integer sum per block for G = 4, against typical |isum| ~ 1e4 (rel. ~1e-4..3e-4, an
+// order below the bf16 rounding of the result).  1.25 VALU per element and K block instead of 2.
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
@@ -201,6 +210,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 #define F_FMAC4(acc_, v_, sc_)                                                                    \
   _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
     asm volatile("v_fmac_f32 %0, %1, %2" : "+v"((acc_)[r]) : "s"(sc_), "v"((v_)[r]));
+#define F_ADDC4(acc_, c_)                                                                         \
+  _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                   \
+    asm volatile("v_add_f32 %0, %1, %0" : "+v"((acc_)[r]) : "s"(c_));
 
   // ---- prologue: stage 0 and stage 1 in flight; wait for stage 0; fragments of group (0,0) ----
 #pragma unroll
@@ -223,9 +235,27 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // block scales live in SGPRs: sc_old = K block of the group being dequantised at i == 0 (the previous
   // block's last group), sc_new = this block's.  (sa*sb) formed first, kernel.hpp:418.
   float sc_old = 0.f;
-  float sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, as_row[0] * bs_row[0])));
+  const float sv0 = as_row[0] * bs_row[0];
+  float sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sv0)));
+  // FAST: sum of M*s_k not yet taken out of the accumulators (fp64, per-wave uniform), fed from the VECTOR copy of each
+  // scale so that the SGPR copies only have the fmacs as users
+  double c_sum = FAST > 0 ? (double)sv0 * (double)F_MAGIC_F : 0.0;
 
-  for (int kb = 0; kb < nk; ++kb) {
+  constexpr int UNR = FAST > 0 ? FAST : 1;   // FAST: the K loop is unrolled by the recentring period (no branch in the stream)
+  float c_neg = 0.f;
+  for (int kb0 = 0; kb0 < nk; kb0 += UNR) {
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int kb = kb0 + u;
+    if (UNR > 1 && kb >= nk) break;
+    const bool recentre = FAST > 0 && u == UNR - 1;
+    if constexpr (FAST > 0) {
+      if (recentre) {
+        const float c_hi = (float)c_sum;
+        c_sum -= (double)c_hi;
+        c_neg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -c_hi)));
+      }
+    }
     const char* st = smem + (kb & 1) * F_STAGE;
     const char* stn = smem + ((kb + 1) & 1) * F_STAGE;
     const bool more = kb + 1 < nk;
@@ -247,7 +277,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         F_MFMA0(t[cur][j], wf[j][0], xf[cur][0])
-        F_ADD4(t[prv][j])
+        if constexpr (FAST == 0) { F_ADD4(t[prv][j]) }
+        else if (recentre) { F_ADDC4(accf[pi][j], c_neg) }
       }
       F_FENCE()
       if (i == 7 && more) { F_LOAD_W(stn, 0) }
@@ -283,7 +314,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       }
     }
     sc_old = sc_new;
-    sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sa_n * sb_n)));
+    const float sv = sa_n * sb_n;
+    sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sv)));
+    if constexpr (FAST > 0) c_sum = __builtin_fma((double)sv, (double)F_MAGIC_F, c_sum);
+  }
   }
   if constexpr (DBG == 1) {
     if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
@@ -293,10 +327,23 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // ---- drain: dequant of the last group (nk-1, 7); its MFMAs were issued >= 4 slots ago, the last one
   //      just now: give the matrix pipe its 4 passes before the VALU reads ----
   asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+  if constexpr (FAST == 0) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { F_ADD4(t[1][j]) }
+    for (int j = 0; j < 4; ++j) { F_ADD4(t[1][j]) }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { F_FMAC4(accf[7][j], t[1][j], sc_old) }
+  if constexpr (FAST > 0) {
+    // whatever M*s_k has not been taken out yet (the last, partial group + the fp64 -> fp32 remainders)
+    const float c_hi = (float)c_sum;
+    const float c_lo = (float)(c_sum - (double)c_hi);
+    const float c_last = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -c_hi)));
+    const float c_last2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -c_lo)));
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { F_ADDC4(accf[i][j], c_last) F_ADDC4(accf[i][j], c_last2) }
+  }
 
   // ---- epilogue ----
   // lane owns m = ..+l16; accumulator (i,j) holds n_local = 16j + r + 8(lq&1) + 4(lq>>1).
@@ -477,11 +524,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false>
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0>
 static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
-  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES>;
+  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -521,6 +568,14 @@ int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const fl
       default: break;
     }
   }
+  if (out_dtype == TD_BF16 && bias && epilogue == TD_EPI_NONE) {  // one-VALU dequant (the model's instantiations only)
+    switch (td_gemm_fast_g()) {
+      case 2: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, false, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      case 4: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, false, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      case 8: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, false, 8>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      default: break;
+    }
+  }
   if (td_tuning(TD_TUNE_GEMM_ABLATE) == 7)  // s_memtime trace, L2 prefetch
     return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 1, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
 #define TD_GEMM_CASE(ODT)                                                                              \
@@ -540,6 +595,14 @@ int td_gemm_w8a8_fi_q(const int8_t* a, const float* a_s, const int8_t* b, const 
                       int8_t* d_q, float* d_s, int act_dtype, int epilogue, int64_t m, int64_t n, int64_t k,
                       hipStream_t st) {
   const int64_t ldqs = td_cdiv(n, 128);
+  if (act_dtype == TD_BF16 && bias && epilogue == TD_EPI_GELU_TANH) {
+    switch (td_gemm_fast_g()) {
+      case 2: return launch_gemm_fi<TD_BF16, TD_EPI_GELU_TANH, true, 0, 0, true, false, 2>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
+      case 4: return launch_gemm_fi<TD_BF16, TD_EPI_GELU_TANH, true, 0, 0, true, false, 4>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
+      case 8: return launch_gemm_fi<TD_BF16, TD_EPI_GELU_TANH, true, 0, 0, true, false, 8>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
+      default: break;
+    }
+  }
 #define TD_GEMM_CASE(ODT)                                                                                   \
   if (epilogue == TD_EPI_GELU_TANH) {                                                                       \
     return bias ? launch_gemm_fi<ODT, TD_EPI_GELU_TANH, true, 0, 0, true>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs)  \
@@ -556,6 +619,14 @@ int td_gemm_w8a8_fi_q(const int8_t* a, const float* a_s, const int8_t* b, const 
 int td_gemm_w8a8_fi_res(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
                         void* x, const float* gate, int dtype, int64_t m, int64_t n, int64_t k, int64_t ldx,
                         hipStream_t st) {
+  if (dtype == TD_BF16 && bias) {
+    switch (td_gemm_fast_g()) {
+      case 2: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, true, 2>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+      case 4: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, true, 4>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+      case 8: return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, true, 8>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+      default: break;
+    }
+  }
   if (dtype == TD_BF16)
     return bias ? launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate)
                 : launch_gemm_fi<TD_BF16, TD_EPI_NONE, false, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);

@@ -53,7 +53,13 @@ __device__ __forceinline__ uint32_t g_swz(uint32_t row, uint32_t chunk) {
   }
 
 // DBG = 2: phase stamps (prologue / main loop / epilogue) as in gemm_w8a8_fi.hip
-template <int ODT, int EPI, bool HAS_BIAS, bool QOUT = false, bool RES = false, int DBG = 0>
+// FAST = G > 0: one-VALU dequant, re-centred every G K blocks (gemm_w8a8_fi.hip has the derivation and the bound).
+// A 16-register constant C operand does not fit beside 128 accumulators, so the chain starts from the INLINE constant
+// 1/(2*pi) = 0x3E22F983: |isum| <= 128*128*128 = 2^21 < 0x22F983 keeps 0x3E22F983 + isum inside the binade
+// [0.125, 0.25) (ulp 2^-26), i.e. the int32 result read as fp32 is M' + isum * 2^-26 with M' = 10680707 * 2^-26, and
+// `acc = fma(raw, s * 2^26, acc)` adds isum*s + 10680707*s.  The two v_cvt blocks of a chain disappear; their slots
+// carry the recentring adds when one is due.  |fast - exact| <= 2^-24 * (G+1) * 10680707 * sum_k s_k = 0.64 (G+1) sum_k s_k.
+template <int ODT, int EPI, bool HAS_BIAS, bool QOUT = false, bool RES = false, int DBG = 0, int FAST = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
@@ -86,18 +92,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
   const int64_t m0 = (int64_t)tm * G_BM, n0 = (int64_t)tn * G_BN;
   const int nk = (int)(K / 128);
 
-  // ---- LDS-DMA pieces: wave w moves chunks c = w + 8t (8 rows x 128 B) of both operand tiles ----
-  uint32_t ga[4], gb[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int c = wave + 8 * t;
-    const int row = 8 * c + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (LDS image is lane-linear)
-    int64_t am = m0 + row; if (am > M - 1) am = M - 1;   // tail rows: clamp (never stored)
-    int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
-    ga[t] = (uint32_t)(am * K + chunk * 16);
-    gb[t] = (uint32_t)(bn * K + chunk * 16);
+  // ---- LDS-DMA pieces: wave w moves chunks c = w + 8t (8 rows x 128 B) of both operand tiles.  One VGPR offset per
+  //      operand (chunk t = 0); chunk t adds 64 rows through the instruction's SGPR offset.  Rows past the end of the
+  //      matrix are out of the buffer's range and read as zero (never stored).
+  uint32_t ga0, gb0;
+  {
+    const int row = 8 * wave + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (LDS image is lane-linear); row + 64t keeps it
+    ga0 = (uint32_t)((m0 + row) * K + chunk * 16);
+    gb0 = (uint32_t)((n0 + row) * K + chunk * 16);
   }
+  const uint32_t row64 = (uint32_t)(64 * K);
   const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(uint32_t)(M * K), 0x00020000);
   const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(uint32_t)(N * K), 0x00020000);
   // piece p of stage kb_ into buffer (kb_ & 1): p = 0..3 activation chunks, 4..7 weight chunks
@@ -106,10 +111,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
     char* sb_ = smem + ((kb_) & 1) * G_STAGE + wave * 1024;                                       \
     if ((p_) < 4)                                                                                 \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (g_lptr_t)(sb_ + ((p_) & 3) * 8192), 16,   \
-                                               ga[(p_) & 3], (kb_) * 128, 0, 0);                  \
+                                               ga0, (kb_) * 128 + ((p_) & 3) * row64, 0, 0);      \
     else                                                                                          \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (g_lptr_t)(sb_ + G_TILE + ((p_) & 3) * 8192), \
-                                               16, gb[(p_) & 3], (kb_) * 128, 0, 0);              \
+                                               16, gb0, (kb_) * 128 + ((p_) & 3) * row64, 0, 0);  \
   }
 
   // ---- fragment read offsets within a stage.  32x32x32 operand: lane holds row (lane & 31), k bytes 16*(lane >> 5)..+15
@@ -149,6 +154,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
 #define G_LOAD_W(st_, jj_, ks_) wf[jj_][ks_] = *reinterpret_cast<const v4i*>((st_) + woff[ks_] + (jj_) * 4096);
 #define G_MFMA0(d_, a_, b_) \
   asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=&v"(d_) : "v"(a_), "v"(b_));
+#define G_MFMA0M(d_, a_, b_) \
+  asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0.15915494" : "=&v"(d_) : "v"(a_), "v"(b_));
+#define G_ADDC8(acc_, h_, c_)                                                                     \
+  _Pragma("unroll") for (int r = 0; r < 8; ++r)                                                   \
+    asm volatile("v_add_f32 %0, %1, %0" : "+v"((acc_)[8 * (h_) + r]) : "s"(c_));
 #define G_MFMA1(d_, a_, b_) \
   asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(d_) : "v"(a_), "v"(b_));
 #define G_CVT8(v_, h_)                                                                            \
@@ -181,9 +191,29 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
   // block scales live in SGPRs: sc_old = previous K block (its last two chains are dequantised during this block's
   // first two), sc_new = this block's.  (sa*sb) formed first, kernel.hpp:418.
   float sc_old = 0.f;
-  float sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, as_row[0] * bs_row[0])));
+  // FAST: the scales are kept multiplied by 2^26 (exact): the fmac multiplies raw = M' + isum * 2^-26 by s * 2^26
+  constexpr float G_S26 = FAST > 0 ? 67108864.0f : 1.0f;
+  const float sv0 = (as_row[0] * bs_row[0]) * G_S26;
+  float sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sv0)));
+  // FAST: sum of M' * s'_k (s' = s * 2^26, M' = 0x3E22F983 = 10680707 * 2^-26) not yet taken out of the accumulators;
+  // fp64, fed from the VECTOR copy of each scale so that the SGPR copies only have the fmacs as users
+  double c_sum = FAST > 0 ? (double)sv0 * (10680707.0 / 67108864.0) : 0.0;
 
-  for (int kb = 0; kb < nk; ++kb) {
+  constexpr int UNR = FAST > 0 ? FAST : 1;   // FAST: the K loop is unrolled by the recentring period
+  float c_neg = 0.f;
+  for (int kb0 = 0; kb0 < nk; kb0 += UNR) {
+#pragma unroll
+  for (int u = 0; u < UNR; ++u) {
+    const int kb = kb0 + u;
+    if (UNR > 1 && kb >= nk) break;
+    const bool recentre = FAST > 0 && u == UNR - 1;
+    if constexpr (FAST > 0) {
+      if (recentre) {
+        const float c_hi = (float)c_sum;
+        c_sum -= (double)c_hi;
+        c_neg = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -c_hi)));
+      }
+    }
     const char* st = smem + (kb & 1) * G_STAGE;
     const char* stn = smem + ((kb + 1) & 1) * G_STAGE;
     const bool more = kb + 1 < nk;
@@ -201,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
       G_STAMP()
       // -- slot 0: second fmac half of chain c-2, then the first MFMA of this chain overwrites t[jj]
       G_FMAC8(acc[i2][jj], t[jj], 1, sc2)
-      G_MFMA0(t[jj], wf[jj][0], xf[0])
+      if constexpr (FAST > 0) { G_MFMA0M(t[jj], wf[jj][0], xf[0]) } else { G_MFMA0(t[jj], wf[jj][0], xf[0]) }
       G_FENCE()
       if (ch == 7 && more) { G_LOAD_W(stn, 0, 0) }
       if (jj == 1) { if (i < 3) { G_LOAD_X(st, i + 1, 0) } else if (more) { G_LOAD_X(stn, 0, 0) } }
@@ -217,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
       G_FENCE()
       // -- slot 1
       G_MFMA1(t[jj], wf[jj][1], xf[1])
-      G_CVT8(t[jj ^ 1], 0)
+      if constexpr (FAST == 0) { G_CVT8(t[jj ^ 1], 0) } else if (recentre) { G_ADDC8(acc[i][jj], 0, c_neg) }
       G_FENCE()
       if (ch == 7 && more) { G_LOAD_W(stn, 0, 1) }
       if (jj == 1) { if (i < 3) { G_LOAD_X(st, i + 1, 1) } else if (more) { G_LOAD_X(stn, 0, 1) } }
@@ -225,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
       G_FENCE()
       // -- slot 2
       G_MFMA1(t[jj], wf[jj][2], xf[2])
-      G_CVT8(t[jj ^ 1], 1)
+      if constexpr (FAST == 0) { G_CVT8(t[jj ^ 1], 1) } else if (recentre) { G_ADDC8(acc[i][jj], 1, c_neg) }
       G_FENCE()
       if (ch == 7 && more) { G_LOAD_W(stn, 0, 2) }
       if (jj == 1) { if (i < 3) { G_LOAD_X(st, i + 1, 2) } else if (more) { G_LOAD_X(stn, 0, 2) } }
@@ -247,7 +277,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
       G_FENCE()
     }
     sc_old = sc_new;
-    sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sa_n * sb_n)));
+    const float sv = (sa_n * sb_n) * G_S26;
+    sc_new = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sv)));
+    if constexpr (FAST > 0) c_sum = __builtin_fma((double)sv, 10680707.0 / 67108864.0, c_sum);
+  }
   }
   if constexpr (DBG == 1) {
     if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0)
@@ -256,11 +289,26 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
   if constexpr (DBG >= 2) c_t2 = __builtin_amdgcn_s_memtime();
   // ---- drain: chain (3,0)'s second fmac half, then all of chain (3,1) (last MFMA just issued: 12 wait states) ----
   G_FMAC8(acc[3][0], t[0], 1, sc_old)
-  asm volatile("s_nop 7" ::: "memory");
-  G_CVT8(t[1], 0)
-  G_CVT8(t[1], 1)
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+  if constexpr (FAST == 0) {
+    G_CVT8(t[1], 0)
+    G_CVT8(t[1], 1)
+  }
   G_FMAC8(acc[3][1], t[1], 0, sc_old)
   G_FMAC8(acc[3][1], t[1], 1, sc_old)
+  if constexpr (FAST > 0) {
+    // whatever M*s_k has not been taken out yet (the last, partial group + the fp64 -> fp32 remainders)
+    const float c_hi = (float)c_sum;
+    const float c_lo = (float)(c_sum - (double)c_hi);
+    const float c_last = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -c_hi)));
+    const float c_last2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -c_lo)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { G_ADDC8(acc[i][j], h, c_last) G_ADDC8(acc[i][j], h, c_last2) }
+  }
 
   // ---- epilogue ----
   // lane owns row m = ..+32i+l32; accumulator (i, jj)[4q + r] holds n_local = 32jj + 8q + 4hi + r.  With j8 = 4jj + q:
@@ -427,11 +475,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS, bool QOUT = false, bool RES = false, int DBG = 0>
+template <int ODT, int EPI, bool HAS_BIAS, bool QOUT = false, bool RES = false, int DBG = 0, int FAST = 0>
 static int launch_gemm_m32(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                            const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                            hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
-  auto kern = gemm_w8a8_m32_kernel<ODT, EPI, HAS_BIAS, QOUT, RES, DBG>;
+  auto kern = gemm_w8a8_m32_kernel<ODT, EPI, HAS_BIAS, QOUT, RES, DBG, FAST>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
@@ -454,6 +502,16 @@ int td_gemm_w8a8_m32(const int8_t* a, const float* a_s, const int8_t* b, const f
     return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
   if (td_tuning(TD_TUNE_GEMM_ABLATE) == 9)  // s_memtime at every chain start of K blocks 8 and 9 (tools/gemm_trace.py)
     return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+  if (out_dtype == TD_BF16 && bias && epilogue == TD_EPI_NONE) {
+    const bool ph = td_tuning(TD_TUNE_GEMM_ABLATE) == 16;  // phase stamps of the FAST instantiation
+    switch (td_gemm_fast_g()) {
+      case 2: return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 0, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      case 4: return ph ? launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 2, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st)
+                        : launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 0, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      case 8: return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 0, 8>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+      default: break;
+    }
+  }
 #define TD_GEMM_CASE(ODT)                                                                              \
   if (epilogue == TD_EPI_GELU_TANH) {                                                                  \
     return bias ? launch_gemm_m32<ODT, TD_EPI_GELU_TANH, true>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st)  \
@@ -471,6 +529,14 @@ int td_gemm_w8a8_m32_q(const int8_t* a, const float* a_s, const int8_t* b, const
                        int8_t* d_q, float* d_s, int act_dtype, int epilogue, int64_t m, int64_t n, int64_t k,
                        hipStream_t st) {
   const int64_t ldqs = td_cdiv(n, 128);
+  if (act_dtype == TD_BF16 && bias && epilogue == TD_EPI_GELU_TANH) {
+    switch (td_gemm_fast_g()) {
+      case 2: return launch_gemm_m32<TD_BF16, TD_EPI_GELU_TANH, true, true, false, 0, 2>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
+      case 4: return launch_gemm_m32<TD_BF16, TD_EPI_GELU_TANH, true, true, false, 0, 4>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
+      case 8: return launch_gemm_m32<TD_BF16, TD_EPI_GELU_TANH, true, true, false, 0, 8>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
+      default: break;
+    }
+  }
 #define TD_GEMM_CASE(ODT)                                                                                   \
   if (epilogue == TD_EPI_GELU_TANH) {                                                                       \
     return bias ? launch_gemm_m32<ODT, TD_EPI_GELU_TANH, true, true>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs)  \
@@ -487,6 +553,14 @@ int td_gemm_w8a8_m32_q(const int8_t* a, const float* a_s, const int8_t* b, const
 int td_gemm_w8a8_m32_res(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
                          void* x, const float* gate, int dtype, int64_t m, int64_t n, int64_t k, int64_t ldx,
                          hipStream_t st) {
+  if (dtype == TD_BF16 && bias) {
+    switch (td_gemm_fast_g()) {
+      case 2: return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true, 0, 2>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+      case 4: return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true, 0, 4>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+      case 8: return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true, 0, 8>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+      default: break;
+    }
+  }
   if (dtype == TD_BF16)
     return bias ? launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate)
                 : launch_gemm_m32<TD_BF16, TD_EPI_NONE, false, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);

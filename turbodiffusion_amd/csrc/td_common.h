@@ -37,6 +37,7 @@ void td_set_error(const char* fmt, ...);
 
 // tuning knobs (td_set_tuning); 0 = automatic choice
 int td_tuning(int key);
+int td_gemm_fast_g(void);                  // resolved TD_TUNE_GEMM_FAST: 0 = exact dequant, else the recentring period G
 unsigned long long* td_dbg_buffer(void);  // 256 x u64 device scratch for the DBG kernel instantiations
 // internal kernel entry points shared between translation units
 int td_gemm_w8a8_pp(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,

@@ -58,10 +58,13 @@ def _timed(name, meta, fn):
 
 
 TUNE_GEMM_VARIANT = 0
+TUNE_GEMM_ABLATE = 1
+TUNE_GEMM_FAST = 6   # 0 = library default, 1 = exact dequant, G in {2, 4, 8} = one-VALU dequant re-centred every G K blocks
 
 
 def set_tuning(key: int, value: int):
-    """Kernel-selection knob (benchmarking only; every variant of an operator is bit-identical)."""
+    """Kernel-selection knob (include/turbodiffusion_amd.h TD_TUNE_*).  Every variant of an operator is bit-identical
+    except TUNE_GEMM_FAST >= 2 (one-VALU dequant: bounded difference, see csrc/gemm_w8a8_fi.hip)."""
     call("td_set_tuning", key, value)
 
 
