@@ -177,3 +177,119 @@ def reference_wan_from_sd(cfg: dict, sd: dict, act_dtype=None):
             if not any(isl in clean for isl in FP32_ISLANDS):
                 p.data = p.data.to(act_dtype)
     return net
+
+
+# --------------------------------------------------------------------------- #
+# the reference SLA / SageSLA modules on the CPU, with only their GPU leaves patched
+# --------------------------------------------------------------------------- #
+class _PatchedSLA:
+    """Context manager: the reference ``SLA`` package (SLA/core.py, SLA/utils.py) runnable on the CPU.
+
+    The module ``forward``s and ``get_block_map`` are pure torch except for leaf calls into Triton / SpargeAttn /
+    CUDA; exactly those leaves are replaced (nothing in /root/reference is edited):
+      * ``SLA.utils.mean_pool`` (Triton ``compress_kernel``, SLA/utils.py:21-52) -> a torch block mean with the same
+        arithmetic (fp32 sum over the valid rows / valid count, cast to the input dtype);
+      * ``SLA.core._attention.apply`` (Triton ``_attn_fwd``, SLA/kernel.py:21-82,240-274) -> ``sla_ref.sla_sparse_attn``;
+      * ``SLA.core.get_cuda_arch`` (``torch.cuda.get_device_capability``, SLA/utils.py:70-72) -> ``"sm80"`` (the
+        FP16-PV branch, SLA/core.py:211-216) or ``"sm89"`` (the FP8-PV branch, :217-239);
+      * the un-vendored SpargeAttn entry points the Sage module calls (SLA/core.py:22-24,201-204,214,221-237):
+        ``get_vanilla_qk_quant``, ``block_map_lut_triton``, ``qattn.qk_int8_sv_f16_*``, ``fused.*`` and the FP8 kernels
+        -> the oracle's statement of that arithmetic (``sla_ref``; PARITY UNPINNED for these leaves, oracle/__init__.py);
+      * ``torch.amp.autocast('cuda', ...)`` (SLA/core.py:116,255) -> the same autocast on ``'cpu'`` (the tensors live
+        there), so ``proj_l`` (fp32 nn.Linear) runs in the module dtype exactly as under CUDA autocast.
+    Everything else — the [B,L,H,D] transposes, dtype casts, block-map call, smooth-K mean, linear branch, the 16-bit
+    ``o_s + o_l`` and ``return_sparsity`` — is the reference's own code."""
+
+    def __init__(self, arch: str = "sm80"):
+        self.arch = arch
+        self._saved = []
+
+    def _set(self, obj, name, val):
+        self._saved.append((obj, name, getattr(obj, name, _MISSING)))
+        setattr(obj, name, val)
+
+    def __enter__(self):
+        import torch
+        from . import sla_ref as S
+
+        sla = load_sla()
+        core = importlib.import_module("SLA.core")
+        utils = importlib.import_module("SLA.utils")
+        arch = self.arch
+
+        self._set(utils, "mean_pool", lambda x, BLK: S.mean_pool(x, BLK))
+
+        class _Attn:
+            @staticmethod
+            def apply(q, k, v, sparse_map, lut, real_topk, BLKQ, BLKK, qk_scale=None):
+                return S.sla_sparse_attn(q, k, v, lut, BLKQ, BLKK, qk_scale)
+
+        self._set(core, "_attention", _Attn)
+        self._set(core, "get_cuda_arch", lambda idx: arch)
+        self._set(core, "SAGESLA_ENABLED", True)
+        self._set(core, "SAGE2PP_ENABLED", False)
+
+        def get_vanilla_qk_quant(q, k, km, blkq, blkk):
+            q8, qs = S.quant_per_block_int8(q, blkq)
+            k8, ks = S.quant_per_block_int8(k, blkk, km)
+            return q8, qs, k8, ks
+
+        def block_map_lut_triton(sparse_map):
+            return S.block_map_lut(sparse_map)
+
+        class _QAttn:
+            @staticmethod
+            def qk_int8_sv_f16_accum_f16_block_sparse_attn_inst_buf_with_pv_threshold(
+                    q8, k8, v16, o, lut, nvalid, pvthr, qs, ks, layout, causal, gran, scale, ret_lse):
+                assert layout == 1 and not causal and gran == 1 and ret_lse == 0 and float(pvthr.min()) >= 1e6
+                o.copy_(S.sage_sparse_attn(q8, qs, k8, ks, v16, S.lut_from_delta(lut), 128, 64, sm_scale=scale,
+                                           out_dtype=o.dtype, pv_dtype=torch.float16, nvalid=nvalid))
+
+            @staticmethod
+            def qk_int8_sv_f8_accum_f32_block_sparse_attn_inst_buf_fuse_v_scale_with_pv_threshold(
+                    q8, k8, v8, o, lut, nvalid, pvthr, qs, ks, vs, layout, causal, gran, scale, ret_lse):
+                assert layout == 1 and not causal and gran == 1 and ret_lse == 0 and float(pvthr.min()) >= 1e6
+                o.copy_(S.sage_sparse_attn_fp8(q8, qs, k8, ks, v8, vs, S.lut_from_delta(lut), 128, 64, sm_scale=scale,
+                                               out_dtype=o.dtype, nvalid=nvalid))
+
+        class _Fused:
+            @staticmethod
+            def transpose_pad_permute_cuda(v, vt, layout):
+                assert layout == 1
+                S.transpose_pad_permute(v, vt)
+
+            @staticmethod
+            def scale_fuse_quant_cuda(vt, v8, vs, kv_len, scale_max, layout):
+                assert layout == 1
+                q, s = S.v_fp8_quant(vt, kv_len, scale_max)
+                v8.copy_(q)
+                vs.copy_(s)
+
+        self._set(core, "get_vanilla_qk_quant", get_vanilla_qk_quant)
+        self._set(core, "block_map_lut_triton", block_map_lut_triton)
+        self._set(core, "qattn", _QAttn)
+        self._set(core, "fused", _Fused)
+
+        real_autocast = torch.amp.autocast
+
+        def cpu_autocast(device_type, *a, **k):
+            return real_autocast("cpu" if device_type == "cuda" else device_type, *a, **k)
+
+        self._set(torch.amp, "autocast", cpu_autocast)
+        return sla
+
+    def __exit__(self, *exc):
+        for obj, name, old in reversed(self._saved):
+            if old is _MISSING:
+                delattr(obj, name)
+            else:
+                setattr(obj, name, old)
+        self._saved.clear()
+        return False
+
+
+_MISSING = object()
+
+
+def patched_sla(arch: str = "sm80"):
+    return _PatchedSLA(arch)

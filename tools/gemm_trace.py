@@ -11,7 +11,7 @@ wq, ws = K.quant_i8_block128((torch.randn(n, k, device=dev) / math.sqrt(k)).bflo
 b = torch.zeros(n, device=dev).bfloat16()
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 K.set_tuning(0, variant)
-modes = ((9, "full"),) if variant == 5 else ((9, "full"), (7, "full, L2 prefetch")) if variant == 4 else ((9, "full"), (10, "no DMA in loop"), (11, "no ds_read in loop"), (12, "no MFMA"))
+modes = ((9, "exact"), (19, "fast G=4")) if variant == 5 else ((9, "full"), (7, "full, L2 prefetch")) if variant == 4 else ((9, "full"), (10, "no DMA in loop"), (11, "no ds_read in loop"), (12, "no MFMA"))
 for mode, nm in modes:
     K.set_tuning(1, mode)
     for _ in range(3):

@@ -59,7 +59,14 @@ __device__ __forceinline__ uint32_t g_swz(uint32_t row, uint32_t chunk) {
 // [0.125, 0.25) (ulp 2^-26), i.e. the int32 result read as fp32 is M' + isum * 2^-26 with M' = 10680707 * 2^-26, and
 // `acc = fma(raw, s * 2^26, acc)` adds isum*s + 10680707*s.  The two v_cvt blocks of a chain disappear; their slots
 // carry the recentring adds when one is due.  |fast - exact| <= 2^-24 * (G+1) * 10680707 * sum_k s_k = 0.64 (G+1) sum_k s_k.
-template <int ODT, int EPI, bool HAS_BIAS, bool QOUT = false, bool RES = false, int DBG = 0, int FAST = 0>
+// SCHED bit 0: the K block's barrier sits in chain 6 (right after its first MFMA) instead of at its end, the weight
+//   fragments wf[0][*] of the next stage are reloaded behind chain 6's own MFMAs (wf[1][*] and the activation row behind
+//   chain 7's), and the LDS-DMA of stage kb+2 is issued in chains 6, 7, 0, 1, 2: the fragment refill is spread over two
+//   chains instead of one burst of 12 reads per wave right after the barrier (tools/gemm_trace.py: chains 6 + 7 took
+//   2400-3000 cycles against 350 for each of chains 0-5).
+// SCHED bit 1: s_setprio 1 for the younger half of the workgroup (waves 4-7 lose the issue arbitration otherwise and
+//   reach the barrier ~800 cycles after their partners).
+template <int ODT, int EPI, bool HAS_BIAS, bool QOUT = false, bool RES = false, int DBG = 0, int FAST = 0, int SCHED = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
   // fp64, fed from the VECTOR copy of each scale so that the SGPR copies only have the fmacs as users
   double c_sum = FAST > 0 ? (double)sv0 * (10680707.0 / 67108864.0) : 0.0;
 
+  if constexpr (SCHED & 2) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
   constexpr int UNR = FAST > 0 ? FAST : 1;   // FAST: the K loop is unrolled by the recentring period
   float c_neg = 0.f;
   for (int kb0 = 0; kb0 < nk; kb0 += UNR) {
@@ -233,6 +241,22 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
       G_FMAC8(acc[i2][jj], t[jj], 1, sc2)
       if constexpr (FAST > 0) { G_MFMA0M(t[jj], wf[jj][0], xf[0]) } else { G_MFMA0(t[jj], wf[jj][0], xf[0]) }
       G_FENCE()
+      if constexpr (SCHED & 1) {
+        if (ch == 6) {
+          // every LDS read of stage kb has returned (block row 3's fragments were read during chain 5), this wave's
+          // pieces of stage kb+1 (issued up to chain 2) have landed; after the barrier: everyone's
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          G_BARRIER()
+        }
+        if (ch == 6 && more) { G_LOAD_W(stn, 0, 0) }
+        if (jj == 1) { if (i < 3) { G_LOAD_X(st, i + 1, 0) } else if (more) { G_LOAD_X(stn, 0, 0) } }
+        if (ch == 7 && more) { G_LOAD_W(stn, 1, 0) }
+        if (ch == 6) { if (dma_head) { G_PIECE(kb + 2, 0) G_PIECE(kb + 2, 4) } }
+        else if (ch == 7) { if (dma_head) { G_PIECE(kb + 2, 1) G_PIECE(kb + 2, 5) } }
+        else if (ch == 0) { if (dma_tail) { G_PIECE(kb + 1, 2) G_PIECE(kb + 1, 6) } }
+        else if (ch == 1) { if (dma_tail) { G_PIECE(kb + 1, 3) } }
+        else if (ch == 2) { if (dma_tail) { G_PIECE(kb + 1, 7) } }
+      } else {
       if (ch == 7 && more) { G_LOAD_W(stn, 0, 0) }
       if (jj == 1) { if (i < 3) { G_LOAD_X(st, i + 1, 0) } else if (more) { G_LOAD_X(stn, 0, 0) } }
       if (ch == 7 && more) { G_LOAD_W(stn, 1, 0) }
@@ -243,13 +267,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
       else if (ch == 2) { if (dma_tail) { G_PIECE(kb + 1, 6) } }
       else if (ch == 3) { if (dma_tail) { G_PIECE(kb + 1, 3) } }
       else if (ch == 4) { if (dma_tail) { G_PIECE(kb + 1, 7) } }
+      }
       if (ch == 5) { if (more) { sa_n = as_row[kb + 1]; sb_n = bs_row[kb + 1]; } }  // scalar loads
       G_FENCE()
       // -- slot 1
       G_MFMA1(t[jj], wf[jj][1], xf[1])
       if constexpr (FAST == 0) { G_CVT8(t[jj ^ 1], 0) } else if (recentre) { G_ADDC8(acc[i][jj], 0, c_neg) }
       G_FENCE()
-      if (ch == 7 && more) { G_LOAD_W(stn, 0, 1) }
+      if (ch == ((SCHED & 1) ? 6 : 7) && more) { G_LOAD_W(stn, 0, 1) }
       if (jj == 1) { if (i < 3) { G_LOAD_X(st, i + 1, 1) } else if (more) { G_LOAD_X(stn, 0, 1) } }
       if (ch == 7 && more) { G_LOAD_W(stn, 1, 1) }
       G_FENCE()
@@ -257,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
       G_MFMA1(t[jj], wf[jj][2], xf[2])
       if constexpr (FAST == 0) { G_CVT8(t[jj ^ 1], 1) } else if (recentre) { G_ADDC8(acc[i][jj], 1, c_neg) }
       G_FENCE()
-      if (ch == 7 && more) { G_LOAD_W(stn, 0, 2) }
+      if (ch == ((SCHED & 1) ? 6 : 7) && more) { G_LOAD_W(stn, 0, 2) }
       if (jj == 1) { if (i < 3) { G_LOAD_X(st, i + 1, 2) } else if (more) { G_LOAD_X(stn, 0, 2) } }
       if (ch == 7 && more) { G_LOAD_W(stn, 1, 2) }
       G_FENCE()
@@ -265,10 +290,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
       G_MFMA1(t[jj], wf[jj][3], xf[3])
       G_FMAC8(acc[i1][jj ^ 1], t[jj ^ 1], 0, sc1)
       G_FENCE()
-      if (ch == 7 && more) { G_LOAD_W(stn, 0, 3) }
+      if (ch == ((SCHED & 1) ? 6 : 7) && more) { G_LOAD_W(stn, 0, 3) }
       if (jj == 1) { if (i < 3) { G_LOAD_X(st, i + 1, 3) } else if (more) { G_LOAD_X(stn, 0, 3) } }
       if (ch == 7 && more) { G_LOAD_W(stn, 1, 3) }
-      if (ch == 6) {
+      if (ch == 6 && !(SCHED & 1)) {
         // every LDS read of stage kb has returned (block row 3's fragments were read during chain 5),
         // this wave's pieces of stage kb+1 have landed; after the barrier: everyone's
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -475,11 +500,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_m32_kernel(
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS, bool QOUT = false, bool RES = false, int DBG = 0, int FAST = 0>
+template <int ODT, int EPI, bool HAS_BIAS, bool QOUT = false, bool RES = false, int DBG = 0, int FAST = 0, int SCHED = 0>
 static int launch_gemm_m32(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                            const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                            hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
-  auto kern = gemm_w8a8_m32_kernel<ODT, EPI, HAS_BIAS, QOUT, RES, DBG, FAST>;
+  auto kern = gemm_w8a8_m32_kernel<ODT, EPI, HAS_BIAS, QOUT, RES, DBG, FAST, SCHED>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
@@ -500,6 +525,20 @@ int td_gemm_w8a8_m32(const int8_t* a, const float* a_s, const int8_t* b, const f
                      int64_t k, int64_t ldd, hipStream_t st) {
   if (td_tuning(TD_TUNE_GEMM_ABLATE) == 6)  // phase stamps (prologue / main loop / epilogue)
     return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
+  if (out_dtype == TD_BF16 && bias && epilogue == TD_EPI_NONE && td_tuning(TD_TUNE_GEMM_SCHED) > 0) {  // schedule experiments
+    const int abl = td_tuning(TD_TUNE_GEMM_ABLATE), fg = td_gemm_fast_g();
+#define TD_M32_SCHED(S_)                                                                                            \
+    if (td_tuning(TD_TUNE_GEMM_SCHED) == S_) {                                                                      \
+      if (abl == 9) return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 1, 0, S_>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st); \
+      if (abl == 6) return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 2, 0, S_>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st); \
+      if (fg == 4) return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 0, 4, S_>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);  \
+      return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 0, 0, S_>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);               \
+    }
+    TD_M32_SCHED(1) TD_M32_SCHED(2) TD_M32_SCHED(3)
+#undef TD_M32_SCHED
+  }
+  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 19)  // the same trace of the one-VALU (FAST = 4) instantiation
+    return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 1, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
   if (td_tuning(TD_TUNE_GEMM_ABLATE) == 9)  // s_memtime at every chain start of K blocks 8 and 9 (tools/gemm_trace.py)
     return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, false, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
   if (out_dtype == TD_BF16 && bias && epilogue == TD_EPI_NONE) {
@@ -529,13 +568,13 @@ int td_gemm_w8a8_m32_q(const int8_t* a, const float* a_s, const int8_t* b, const
                        int8_t* d_q, float* d_s, int act_dtype, int epilogue, int64_t m, int64_t n, int64_t k,
                        hipStream_t st) {
   const int64_t ldqs = td_cdiv(n, 128);
-  if (act_dtype == TD_BF16 && bias && epilogue == TD_EPI_GELU_TANH) {
-    switch (td_gemm_fast_g()) {
-      case 2: return launch_gemm_m32<TD_BF16, TD_EPI_GELU_TANH, true, true, false, 0, 2>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
-      case 4: return launch_gemm_m32<TD_BF16, TD_EPI_GELU_TANH, true, true, false, 0, 4>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
-      case 8: return launch_gemm_m32<TD_BF16, TD_EPI_GELU_TANH, true, true, false, 0, 8>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
-      default: break;
-    }
+  if (act_dtype == TD_BF16 && bias && epilogue == TD_EPI_GELU_TANH) {  // the model's instantiation: dequant mode x schedule
+    const int fg = td_gemm_fast_g() ? 4 : 0, sch = td_tuning(TD_TUNE_GEMM_SCHED);
+#define TD_M32_Q(F_, S_)                                                                                      \
+    if (fg == F_ && sch == S_)                                                                                \
+      return launch_gemm_m32<TD_BF16, TD_EPI_GELU_TANH, true, true, false, 0, F_, S_>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, d_s, ldqs);
+    TD_M32_Q(4, 0) TD_M32_Q(4, 1) TD_M32_Q(4, 3) TD_M32_Q(0, 1) TD_M32_Q(0, 3)
+#undef TD_M32_Q
   }
 #define TD_GEMM_CASE(ODT)                                                                                   \
   if (epilogue == TD_EPI_GELU_TANH) {                                                                       \
@@ -553,13 +592,13 @@ int td_gemm_w8a8_m32_q(const int8_t* a, const float* a_s, const int8_t* b, const
 int td_gemm_w8a8_m32_res(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
                          void* x, const float* gate, int dtype, int64_t m, int64_t n, int64_t k, int64_t ldx,
                          hipStream_t st) {
-  if (dtype == TD_BF16 && bias) {
-    switch (td_gemm_fast_g()) {
-      case 2: return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true, 0, 2>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
-      case 4: return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true, 0, 4>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
-      case 8: return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true, 0, 8>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
-      default: break;
-    }
+  if (dtype == TD_BF16 && bias) {  // the model's instantiation: dequant mode x schedule
+    const int fg = td_gemm_fast_g() ? 4 : 0, sch = td_tuning(TD_TUNE_GEMM_SCHED);
+#define TD_M32_R(F_, S_)                                                                                      \
+    if (fg == F_ && sch == S_)                                                                                \
+      return launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true, 0, F_, S_>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+    TD_M32_R(4, 0) TD_M32_R(4, 1) TD_M32_R(4, 3) TD_M32_R(0, 1) TD_M32_R(0, 3)
+#undef TD_M32_R
   }
   if (dtype == TD_BF16)
     return bias ? launch_gemm_m32<TD_BF16, TD_EPI_NONE, true, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate)
