@@ -11,10 +11,16 @@ integer arithmetic), one operator of the reference hot path and cites the
 reference ``file:line`` it follows (paths relative to ``/root/reference``).
 
 Parity pinning status:
-  * Wan DiT eager path, norms, AdaLN glue, RoPE, SLA block map, SLA linear
-    branch, SLA block-sparse softmax: pinned against the reference itself,
-    imported on CPU by ``oracle/ref_harness.py`` (fixtures in ``tests/golden``
-    generated by ``oracle/make_golden.py``).
+  * Wan DiT eager path, norms, AdaLN glue, RoPE: pinned bit-exactly against
+    the reference itself, imported on CPU by ``oracle/ref_harness.py``
+    (``tests/test_oracle_cpu.py``; fixtures ``tests/golden/wan_tiny.pt``).
+  * SLA / SageSLA module compositions (``SparseLinearAttention.forward``,
+    ``SageSparseLinearAttention.forward`` FP16-PV and FP8-PV branches,
+    ``get_block_map``, the linear branch, ``proj_l`` under autocast): pinned
+    bit-exactly against the reference's own module code run on the CPU with
+    only its Triton / SpargeAttn / CUDA leaves replaced
+    (``ref_harness.patched_sla``; ``tests/golden/sla_tiny.pt`` carries the
+    reference-produced tensors to the GPU box).
   * Block-128 INT8 quantiser and W8A8 GEMM (CUDA sources, not buildable here —
     need nvcc + the un-vendored CUTLASS submodule): restated from the source
     lines cited; the reference ships no test vectors for them.

@@ -203,6 +203,7 @@ class _PatchedSLA:
     def __init__(self, arch: str = "sm80"):
         self.arch = arch
         self._saved = []
+        self.recorded = {}   # what the reference module handed its sparse-attention leaf on the last call
 
     def _set(self, obj, name, val):
         self._saved.append((obj, name, getattr(obj, name, _MISSING)))
@@ -219,9 +220,12 @@ class _PatchedSLA:
 
         self._set(utils, "mean_pool", lambda x, BLK: S.mean_pool(x, BLK))
 
+        rec = self.recorded
+
         class _Attn:
             @staticmethod
             def apply(q, k, v, sparse_map, lut, real_topk, BLKQ, BLKK, qk_scale=None):
+                rec.update(sparse_map=sparse_map.clone(), lut=lut.clone(), real_topk=real_topk)
                 return S.sla_sparse_attn(q, k, v, lut, BLKQ, BLKK, qk_scale)
 
         self._set(core, "_attention", _Attn)
@@ -276,6 +280,7 @@ class _PatchedSLA:
             return real_autocast("cpu" if device_type == "cuda" else device_type, *a, **k)
 
         self._set(torch.amp, "autocast", cpu_autocast)
+        sla._td_recorded = self.recorded
         return sla
 
     def __exit__(self, *exc):

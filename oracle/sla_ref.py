@@ -231,13 +231,16 @@ def linear_branch_exact_autocast(q, k, v, proj_w, proj_b, dtype=torch.bfloat16):
 # --------------------------------------------------------------------------- #
 # module-level compositions (inputs/outputs [B, L, H, D] like the reference modules)
 # --------------------------------------------------------------------------- #
-def sla_forward(q, k, v, proj_w, proj_b, topk, blkq=128, blkk=64, dtype=torch.bfloat16):
-    """SparseLinearAttention.forward (SLA/core.py:83-119)."""
+def sla_forward(q, k, v, proj_w, proj_b, topk, blkq=128, blkk=64, dtype=torch.bfloat16, lut=None):
+    """SparseLinearAttention.forward (SLA/core.py:83-119).  ``lut``: visit the selected blocks in this order instead of
+    ascending (the reference hands the Triton kernel torch.topk's unsorted order, SLA/utils.py:63; the online softmax
+    is order-dependent at rounding level — SURVEY §8c caveat iv)."""
     in_dtype = q.dtype
     q = q.transpose(1, 2).contiguous()
     k = k.transpose(1, 2).contiguous()
     v = v.transpose(1, 2).contiguous()
-    _, lut, _ = get_block_map(q, k, topk, blkq, blkk)
+    if lut is None:
+        _, lut, _ = get_block_map(q, k, topk, blkq, blkk)
     q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
     o_s = sla_sparse_attn(q, k, v, lut, blkq, blkk)
     o_l = linear_branch_exact_autocast(q, k, v, proj_w, proj_b, dtype)
@@ -267,3 +270,126 @@ def sdpa_ref(q, k, v, scale=None):
     d = q.shape[-1]
     s = (qf @ kf.transpose(-1, -2)) * (scale if scale is not None else d ** -0.5)
     return torch.softmax(s, dim=-1) @ vf
+
+
+# --------------------------------------------------------------------------- #
+# SpargeAttn host-side helpers as called by SageSparseLinearAttention.forward (PARITY UNPINNED: the package is not in
+# the tree; stated from its call sites SLA/core.py:201-204,221-227)
+# --------------------------------------------------------------------------- #
+def block_map_lut(sparse_map):
+    """block_map_lut_triton(sparse_map) (SLA/core.py:204): per Q block the selected K-block ids in ascending order,
+    stored as DELTAS (lut[0] = first id, lut[i] = id_i - id_{i-1}; the kernel walks ``blk += lut[i]``), padded with
+    zeros, plus the number of valid entries.  sparse_map [B,H,Qb,Kb] int8 -> (lut int32 [B,H,Qb,Kb], valid int32 [B,H,Qb])."""
+    b, h, qb, kb = sparse_map.shape
+    valid = sparse_map.to(torch.int32).sum(-1)
+    # ascending ids of the selected blocks, unselected ones pushed to the end
+    key = torch.where(sparse_map > 0, torch.arange(kb).expand_as(sparse_map), torch.full_like(sparse_map, kb, dtype=torch.long))
+    ids = torch.sort(key, dim=-1).values
+    prev = torch.cat([torch.zeros_like(ids[..., :1]), ids[..., :-1]], -1)
+    delta = ids - prev
+    pos = torch.arange(kb).expand_as(ids)
+    delta = torch.where(pos < valid[..., None], delta, torch.zeros_like(delta))
+    return delta.to(torch.int32), valid
+
+
+def lut_from_delta(lut_delta):
+    """Inverse of the delta encoding: absolute ascending block ids (entries past ``valid`` repeat the last id)."""
+    return torch.cumsum(lut_delta.to(torch.int64), dim=-1)
+
+
+# --------------------------------------------------------------------------- #
+# a13, FP8-PV variant (the reference's sm89+ path, SLA/core.py:217-239; SpargeAttn kernels — PARITY UNPINNED)
+# --------------------------------------------------------------------------- #
+FP8_MAX = 448.0           # largest finite e4m3fn
+P_FP8_OFFSET = 448.0      # P in [0,1] is scaled by 448 before the e4m3 conversion (SageAttention2's exp2 offset log2(448))
+
+
+def fp8_e4m3(x):
+    """fp32 -> OCP e4m3fn (round to nearest even, saturate to +-448) -> fp32 value."""
+    return x.clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).float()
+
+
+def transpose_pad_permute(v, vt):
+    """fused.transpose_pad_permute_cuda(v, vt, 1) (SLA/core.py:221): vt[b,h,d,:kv_len] = v[b,h,:,d]^T, zero padded to a
+    multiple of 128 keys.  (The CUDA routine also permutes keys inside 16-groups for its MMA operand layout; that is a
+    storage detail of that kernel, not arithmetic, and is not modelled.)"""
+    kv = v.shape[2]
+    vt.zero_()
+    vt[..., :kv] = v.transpose(-1, -2)
+
+
+def v_fp8_quant(vt, kv_len, scale_max=2.25):
+    """fused.scale_fuse_quant_cuda(vt, v_fp8, v_scale, kv_len, 2.25, 1) (SLA/core.py:224): per (b,h,d) channel
+    scale = max_{keys < kv_len} |v| / scale_max (fp32), v_fp8 = e4m3(v / scale).  scale_max = 2.25 keeps
+    448 (P) * 2.25 (V) * 64 keys = 64512 inside an fp16 accumulator.  Returns (v_fp8 [b,h,d,Lpad] float8_e4m3fn,
+    v_scale fp32 [b,h,d])."""
+    vf = vt.float()
+    amax = vf[..., :kv_len].abs().amax(dim=-1)
+    scale = amax / torch.tensor(scale_max)
+    q = (vf / scale.clamp_min(1e-30)[..., None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn)
+    return q, scale
+
+
+def sage_sparse_attn_fp8(q_i8, q_s, k_i8, k_s, v_fp8_t, v_scale, lut, blkq=128, blkk=64, sm_scale=None,
+                         out_dtype=torch.bfloat16, nvalid=None):
+    """INT8-QK / FP8-PV block-sparse attention as invoked at SLA/core.py:227-239
+    (qk_int8_sv_f8_accum_f32|f16_block_sparse_attn_inst_buf_fuse_v_scale_with_pv_threshold).  Rule stated by this oracle:
+
+        s   as in ``sage_sparse_attn``; online softmax in the exp2 domain, ascending selected blocks, tail keys masked;
+        P8  = e4m3(448 * exp2(s - m))          (the row sum l accumulates the un-rounded fp32 P)
+        O  += P8 @ V8^T                        (fp32 accumulate; V8 = the per-channel-scaled e4m3 values)
+        out = O * v_scale[d] / (448 * l)       (v scale fused in the epilogue), cast to out_dtype
+
+    v_fp8_t: [B,H,D,Lpad] float8_e4m3fn, v_scale fp32 [B,H,D]."""
+    b, h, l, d = q_i8.shape
+    lk = k_i8.shape[2]
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(d)
+    qb_n = _cdiv(l, blkq)
+    out = torch.empty(b, h, l, d, dtype=out_dtype)
+    vf = v_fp8_t.float().transpose(-1, -2)  # [B,H,Lpad,D]
+    qf, kf = q_i8.float(), k_i8.float()
+    c = torch.tensor(sm_scale * LOG2E, dtype=torch.float32)
+    for bi in range(b):
+        for hi in range(h):
+            for qb in range(qb_n):
+                q0, q1 = qb * blkq, min(l, (qb + 1) * blkq)
+                m_i = torch.full((q1 - q0,), -float("inf"))
+                l_i = torch.zeros(q1 - q0)
+                o = torch.zeros(q1 - q0, d)
+                sel = lut[bi, hi, qb].tolist()
+                if nvalid is not None:
+                    sel = sel[: int(nvalid[bi, hi, qb])]
+                for kb in sel:
+                    k0, k1 = kb * blkk, min(lk, (kb + 1) * blkk)
+                    mult = (q_s[bi, hi, qb] * k_s[bi, hi, kb]) * c
+                    s = (qf[bi, hi, q0:q1] @ kf[bi, hi, k0:k1].t()) * mult
+                    new_m = torch.maximum(m_i, s.max(dim=1).values)
+                    p = torch.exp2(s - new_m[:, None])
+                    alpha = torch.exp2(m_i - new_m)
+                    o = o * alpha[:, None] + fp8_e4m3(p * P_FP8_OFFSET) @ vf[bi, hi, k0:k1]
+                    l_i = l_i * alpha + p.sum(dim=1)
+                    m_i = new_m
+                out[bi, hi, q0:q1] = (o * v_scale[bi, hi][None, :] / (P_FP8_OFFSET * l_i[:, None])).to(out_dtype)
+    return out
+
+
+def sagesla_forward_fp8(q, k, v, proj_w, proj_b, topk, dtype=torch.bfloat16, blkq=128, blkk=64):
+    """SageSparseLinearAttention.forward (SLA/core.py:168-258), sm89+ (FP8-PV) branch."""
+    in_dtype = q.dtype
+    q = q.transpose(1, 2).contiguous()
+    k = k.transpose(1, 2).contiguous()
+    v = v.transpose(1, 2).contiguous()
+    _, lut, _ = get_block_map(q, k, topk, blkq, blkk)
+    q, k, v = q.to(dtype), k.to(dtype), v.to(dtype)
+    km = seq_mean(k)
+    q_i8, q_s = quant_per_block_int8(q, blkq)
+    k_i8, k_s = quant_per_block_int8(k, blkk, km)
+    b, h, l, d = v.shape
+    lpad = _cdiv(l, 128) * 128
+    vt = torch.empty(b, h, d, lpad, dtype=v.dtype)
+    transpose_pad_permute(v, vt)
+    v8, vs = v_fp8_quant(vt, l, 2.25)
+    o_s = sage_sparse_attn_fp8(q_i8, q_s, k_i8, k_s, v8, vs, lut, blkq, blkk, out_dtype=dtype)
+    o_l = linear_branch_exact_autocast(q, k, v, proj_w, proj_b, dtype)
+    return (o_s + o_l).to(in_dtype).transpose(1, 2)

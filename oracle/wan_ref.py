@@ -74,7 +74,8 @@ def _attention(q, k, v, kind, sd, prefix, topk, dt):
 
 def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=None, mode="eager",
                 attention="original", quant=False, topk=0.1, act_dtype=torch.bfloat16, num_layers=None,
-                return_tokens=False):
+                return_tokens=False, tap=None):
+    """``tap``: optional dict that receives the intermediates of block 0 (fixture generation only)."""
     dt = act_dtype
     dim, H = cfg["dim"], cfg["num_heads"]
     D = dim // H
@@ -120,9 +121,13 @@ def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=
         q = rms(lin(sa + ".q", h), sd[sa + ".norm_q.weight"]).view(B, L, H, D)
         k = rms(lin(sa + ".k", h), sd[sa + ".norm_k.weight"]).view(B, L, H, D)
         v = lin(sa + ".v", h).view(B, L, H, D)
-        a = _attention(O.rope_apply(q, freqs), O.rope_apply(k, freqs), v, attention if turbo else "original",
-                       sd, sa, topk, dt)
+        qr, kr = O.rope_apply(q, freqs), O.rope_apply(k, freqs)
+        a = _attention(qr, kr, v, attention if turbo else "original", sd, sa, topk, dt)
+        if tap is not None and i == 0:
+            tap.update(h1=h, q_rope=qr, k_rope=kr, v=v, attn=a)
         x = O.gated_residual(x, lin(sa + ".o", a), em[2])
+        if tap is not None and i == 0:
+            tap["x_after_sa"] = x
         # cross attention
         ca = p + ".cross_attn"
         xn = ln(x, sd.get(p + ".norm3.weight"), sd.get(p + ".norm3.bias")) if (p + ".norm3.weight") in sd else x
@@ -131,6 +136,8 @@ def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=
         v = lin(ca + ".v", ctx).view(B, -1, H, D)
         a = _attention(q, k, v, "original", sd, ca, topk, dt)
         x = x + lin(ca + ".o", a)
+        if tap is not None and i == 0:
+            tap["x_after_ca"] = x
         # ffn
         h = O.modulate(ln(x), em[4], em[3])
         f = lin(p + ".ffn.2", lin(p + ".ffn.0", h, gelu=True))

@@ -265,3 +265,42 @@ def test_qk_norm_rope(K, L, H):
     # plain relayout of the V columns
     v = K.qk_norm_rope(src.to(DEV), 2 * H * D, H, D, None, None, None, 1e-6)
     assert torch.equal(v.cpu(), src[:, 2 * H * D:].view(L, H, D).transpose(0, 1))
+
+
+# ---------------------------------------------------------------- seam 1: the pybind-signature stand-in
+def test_turbo_diffusion_ops_compat_drives_the_reference_call_sequence(K):
+    """turbodiffusion_amd.compat.turbo_diffusion_ops exports quant_cuda / gemm_cuda / rms_norm_cuda / layer_norm_cuda with
+    the pybind signatures (ops/bindings.cpp:6-16).  The reference's int8_linear call sequence (ops/core.py:49-57:
+    torch.zeros y, quant_cuda(x, None, None), gemm_cuda(x_q, x_s, w_q, w_s, y)) through it == the oracle, as are the
+    norms' optional-output conventions."""
+    import sys
+    from turbodiffusion_amd.compat import turbo_diffusion_ops as T
+    sys.modules.setdefault("turbo_diffusion_ops", T)
+    from turbo_diffusion_ops import gemm_cuda, layer_norm_cuda, quant_cuda, rms_norm_cuda   # as ops/core.py:9 does
+    x = act_like(300, 512, torch.bfloat16, seed=1).to(DEV)
+    w = (torch.randn(264, 512, generator=torch.Generator().manual_seed(2)) / 22).bfloat16()
+    w_q, w_s = O.quant_block128(w)
+    y = torch.zeros(300, 264, dtype=x.dtype, device=DEV)
+    x_q, x_s = quant_cuda(x, None, None)
+    assert gemm_cuda(x_q, x_s, w_q.to(DEV), w_s.to(DEV), y) is None
+    xq_ref, xs_ref = O.quant_block128(x.cpu())
+    assert torch.equal(x_q.cpu(), xq_ref) and torch.equal(x_s.cpu(), xs_ref)
+    assert ulp_diff_bf16(y, O.gemm_w8a8(xq_ref, xs_ref, w_q, w_s)).max().item() <= 1
+    # caller-provided outputs are written in place and returned
+    oq, os_ = torch.empty_like(x_q), torch.empty_like(x_s)
+    r = quant_cuda(x, oq, os_)
+    assert r[0] is oq and r[1] is os_ and torch.equal(oq, x_q) and torch.equal(os_, x_s)
+    with pytest.raises(RuntimeError):
+        quant_cuda(x.float(), None, None)
+    with pytest.raises(RuntimeError):
+        gemm_cuda(x_q, x_s, w_q.to(DEV), w_s.to(DEV), y.float())
+    # norms: fp32 in / fp32 out, optional weight / bias / output
+    xf = torch.randn(33, 1536, generator=torch.Generator().manual_seed(3)).to(DEV)
+    wn = (torch.rand(1536, generator=torch.Generator().manual_seed(4)) + 0.5).to(DEV)
+    bn = (torch.randn(1536, generator=torch.Generator().manual_seed(5)) * 0.1).to(DEV)
+    torch.testing.assert_close(rms_norm_cuda(xf, 1e-6, wn, None).cpu(), O.rmsnorm_fast(xf.cpu(), wn.cpu(), 1e-6), rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(rms_norm_cuda(xf, 1e-6, None, None).cpu(), O.rmsnorm_fast(xf.cpu(), torch.ones(1536), 1e-6), rtol=2e-6, atol=1e-6)
+    out = torch.empty_like(xf)
+    assert layer_norm_cuda(xf, 1e-6, wn, bn, out) is out
+    torch.testing.assert_close(out.cpu(), O.layernorm_fast(xf.cpu(), wn.cpu(), bn.cpu(), 1e-6), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(layer_norm_cuda(xf, 1e-6, None, None, None).cpu(), O.layernorm_fast(xf.cpu(), None, None, 1e-6), rtol=2e-5, atol=2e-6)

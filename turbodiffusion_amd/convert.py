@@ -80,8 +80,7 @@ def load_checkpoint(net: WanModel, ckpt: Dict) -> WanModel:
         if unexpected or missing:
             raise KeyError(f"checkpoint/model mismatch: unexpected {unexpected[:4]}, missing {missing[:4]}")
         net.load_state_dict({k: v.to(own[k].device) for k, v in sd.items()}, assign=False)
-        net._fused.clear()
-        net._ckv_all = None
+        net.invalidate_caches()
     else:
         dev = next(net.parameters()).device
         net.load_from_float_state_dict({k: (v.to(dev).to(own[k].dtype) if k in own else v.to(dev)) for k, v in sd.items()})
@@ -100,7 +99,7 @@ def main():
     with torch.device("meta"):
         net = select_model(args.model, attention_type=args.attention_type, sla_topk=args.sla_topk,
                            quant_linear=args.quant_linear)
-    ckpt = torch.load(args.input_path, map_location="cpu", weights_only=False)
+    ckpt = torch.load(args.input_path, map_location="cpu", weights_only=True)
     sd = normalize_checkpoint(ckpt, net.patch_embedding.weight.shape, net.patch_embedding.bias.shape)
     if args.quant_linear:
         sd = quantize_state_dict(sd)

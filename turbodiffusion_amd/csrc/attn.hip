@@ -412,12 +412,8 @@ template <bool QK_I8, int PDT, int ODT>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
   auto kern = attn_kernel<QK_I8, PDT, ODT>;
   constexpr int lds = 2 * (KTile<QK_I8>::BYTES + VT_BYTES);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};
+  td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, attr_mask);
   const unsigned nwg = (unsigned)p.H * (unsigned)p.Qb;
   kern<<<nwg, 256, lds, st>>>(p, p.lut, p.k_s, p.q_s);
   TD_CHECK_LAUNCH();

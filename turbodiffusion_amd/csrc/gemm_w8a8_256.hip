@@ -195,12 +195,8 @@ static int launch_gemm256(const int8_t* a, const float* a_s, const int8_t* b, co
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st) {
   auto kern = gemm_w8a8_256_kernel<ODT, EPI, HAS_BIAS, ABL>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};
+  td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), H_LDS, attr_mask);
   const int tiles_m = (int)td_cdiv(m, H_BM), tiles_n = (int)td_cdiv(n, H_BN);
   const int group_m = 4;
   const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;

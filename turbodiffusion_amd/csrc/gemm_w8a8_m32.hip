@@ -505,11 +505,8 @@ static int launch_gemm_m32(const int8_t* a, const float* a_s, const int8_t* b, c
                            const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                            hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
   auto kern = gemm_w8a8_m32_kernel<ODT, EPI, HAS_BIAS, QOUT, RES, DBG, FAST, SCHED>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};
+  td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), G_LDS, attr_mask);
   const int tiles_m = (int)td_cdiv(m, G_BM), tiles_n = (int)td_cdiv(n, G_BN);
   const int group_m = td_tuning(TD_TUNE_GEMM_GROUP_M) > 0 ? td_tuning(TD_TUNE_GEMM_GROUP_M) : 4;
   const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;

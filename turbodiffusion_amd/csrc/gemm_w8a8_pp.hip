@@ -297,12 +297,8 @@ static int launch_gemm_pp(const int8_t* a, const float* a_s, const int8_t* b, co
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st) {
   auto kern = gemm_w8a8_pp_kernel<ODT, EPI, HAS_BIAS, DBG>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_mask{0};
+  td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), P_LDS, attr_mask);
   const int tiles_m = (int)td_cdiv(m, P_BM), tiles_n = (int)td_cdiv(n, P_BN);
   const int group_m = 4;
   const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;

@@ -527,15 +527,13 @@ static int sla_linear_out_impl(const void* q, int dtype, const void* kvsum_t, co
   dim3 grid((unsigned)td_cdiv(Qb, LO_QB_PER_WG), H);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16) {
-    static bool a = false;
-    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_out_kernel<TD_BF16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
+    static std::atomic<uint64_t> a{0};
+    td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<TD_BF16>), lds, a);
     linear_out_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
         (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out);
   } else {
-    static bool a = false;
-    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_out_kernel<TD_F16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds); a = true; }
+    static std::atomic<uint64_t> a{0};
+    td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<TD_F16>), lds, a);
     linear_out_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
         (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out);
   }

@@ -438,9 +438,8 @@ extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* l
   const int nper = (Kb + 63) / 64;
 #define TD_TK(DT_, NP_)                                                                                            \
   {                                                                                                                \
-    static bool a = false;                                                                                         \
-    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sla_topk_kernel<DT_, NP_>),                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, TK_ROWS * TK_MAXKB * 2 + 16 + 64 * 17 * 16); a = true; } \
+    static std::atomic<uint64_t> a{0};                                                                             \
+    td_ensure_dyn_lds(reinterpret_cast<const void*>(sla_topk_kernel<DT_, NP_>), TK_ROWS * TK_MAXKB * 2 + 16 + 64 * 17 * 16, a); \
     sla_topk_kernel<DT_, NP_><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk); \
   }
 #define TD_TK_DT(DT_)                                                                                              \

@@ -67,6 +67,19 @@ int td_gemm_w8a8_256(const int8_t* a, const float* a_s, const int8_t* b, const f
 
 __host__ __device__ static inline int64_t td_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: one process driving several GPUs (or
+// several host threads) must set it once per device, not once per process.  `mask` = one static atomic per kernel
+// instantiation, bit d = "set on device d" (devices >= 64 simply set it on every launch).
+#include <atomic>
+static inline void td_ensure_dyn_lds(const void* kern, int bytes, std::atomic<uint64_t>& mask) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+  if (bit && (mask.load(std::memory_order_acquire) & bit)) return;
+  (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (bit) mask.fetch_or(bit, std::memory_order_release);
+}
+
 // ---- scalar conversions (device) ------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(uint32_t b) { return __uint_as_float(b << 16); }
 

@@ -23,6 +23,7 @@ class GraphedModel(torch.nn.Module):
         super().__init__()
         self.net = net
         self._graphs = {}
+        self._epoch = getattr(net, "_weights_epoch", 0)
 
     def _key(self, x, t, ctx, y):
         return (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype,
@@ -35,6 +36,10 @@ class GraphedModel(torch.nn.Module):
             return self.net(x_B_C_T_H_W, timesteps_B_T, crossattn_emb,
                             frame_cond_crossattn_emb_B_L_D=frame_cond_crossattn_emb_B_L_D,
                             y_B_C_T_H_W=y_B_C_T_H_W, **kwargs)
+        epoch = getattr(self.net, "_weights_epoch", 0)
+        if epoch != self._epoch:   # derived weight copies were dropped: captured graphs hold pointers into freed tensors
+            self._graphs.clear()
+            self._epoch = epoch
         key = self._key(x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W)
         ent = self._graphs.get(key)
         if ent is None:

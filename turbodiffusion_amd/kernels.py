@@ -20,6 +20,14 @@ def cdiv(a: int, b: int) -> int:
     return (a + b - 1) // b
 
 
+def _f32c(t, what):
+    """The kernels read these as contiguous fp32 (norm weights, RoPE tables, block scales): a buffer that a stray
+    ``net.to(torch.bfloat16)`` converted would be read as garbage past its end — refuse instead."""
+    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+        raise TypeError(f"{what} must be a contiguous float32 tensor (got {t.dtype}, contiguous={t.is_contiguous()})")
+    return t
+
+
 class KernelTimer:
     """Times selected entry points with HIP events recorded on the stream the kernel is launched on
     (torch's current stream).  Used by bench.py for the roofline numbers; off by default."""
@@ -89,6 +97,7 @@ def gemm_w8a8(a_q, a_s, b_q, b_s, out_dtype=torch.bfloat16, bias=None, gelu_tanh
     n, k2 = b_q.shape
     assert k == k2, "gemm_w8a8: K mismatch"
     assert a_s.shape == (cdiv(m, 128), k // 128) and b_s.shape == (cdiv(n, 128), k // 128), "scale shapes"
+    _f32c(a_s, "a_s"), _f32c(b_s, "b_s")
     if out is None:
         out = torch.empty((m, n), dtype=out_dtype, device=a_q.device)
     else:
@@ -111,6 +120,7 @@ def gemm_w8a8_quant(a_q, a_s, b_q, b_s, act_dtype=torch.bfloat16, bias=None, gel
     n, k2 = b_q.shape
     assert k == k2, "gemm_w8a8_quant: K mismatch"
     assert a_s.shape == (cdiv(m, 128), k // 128) and b_s.shape == (cdiv(n, 128), k // 128), "scale shapes"
+    _f32c(a_s, "a_s"), _f32c(b_s, "b_s")
     if bias is not None:
         assert bias.dtype == act_dtype and bias.shape == (n,) and bias.is_contiguous()
     q = torch.empty((m, n), dtype=torch.int8, device=a_q.device)
@@ -167,6 +177,7 @@ def gemm_w8a8_residual_(x, a_q, a_s, b_q, b_s, bias=None, gate=None):
     n, k2 = b_q.shape
     assert k == k2 and x.shape == (m, n), "gemm_w8a8_residual_: shape mismatch"
     assert a_s.shape == (cdiv(m, 128), k // 128) and b_s.shape == (cdiv(n, 128), k // 128), "scale shapes"
+    _f32c(a_s, "a_s"), _f32c(b_s, "b_s")
     if bias is not None:
         assert bias.dtype == x.dtype and bias.shape == (n,) and bias.is_contiguous()
     if gate is not None:
@@ -228,6 +239,7 @@ def qk_norm_rope(src, col0, H, D, w, cos, sin, eps):
     H*D columns (w f32 [H*D] or None) and interleaved RoPE (cos/sin f32 [L, D/2] or None)."""
     require_gpu(src, w, cos, sin)
     assert src.dim() == 2 and src.stride(1) == 1
+    _f32c(w, "norm weight"), _f32c(cos, "cos"), _f32c(sin, "sin")
     Lr = src.shape[0]
     dst = torch.empty((H, Lr, D), dtype=src.dtype, device=src.device)
     view = src[:, col0:col0 + H * D]
@@ -298,6 +310,7 @@ def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale
     [L, H*128] output block-quantised for the o projection: (int8 [L, H*128], f32 [ceil(L/128), H]); ``out`` then
     only supplies the 16-bit dtype (a tensor or a torch.dtype)."""
     require_gpu(q_i8, k_i8, vt, lut, add_t)
+    _f32c(q_s, "q_s"), _f32c(k_s, "k_s")
     H, L_, D = q_i8.shape
     lk_alloc = k_i8.shape[1]
     Lk = lk_alloc if lk is None else lk  # lk < allocation: rank-padded gathered layout
@@ -345,7 +358,8 @@ def attn_16_qnorm(q_src, rstd, w, k, vt, lut, out, o_stride_h, o_stride_l, sm_sc
     H, lk_alloc, D = k.shape
     L_ = q_src.shape[0]
     Lk = lk_alloc if lk is None else lk
-    assert D == 128 and vt.dtype == q_src.dtype and q_src.stride(1) == 1 and w.dtype == torch.float32
+    assert D == 128 and vt.dtype == q_src.dtype and q_src.stride(1) == 1
+    _f32c(w, "norm weight"), _f32c(rstd, "rstd")
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]

@@ -49,11 +49,13 @@ class SeqParallel:
     def plan(self, L: int):
         qb = _cdiv(L, 128)
         self.per = _cdiv(qb, self.world) * 128          # padded tokens per rank
+        # evaluated identically on EVERY rank (a rank-local failure would leave the others inside an all-gather)
+        if (self.world - 1) * self.per >= L:
+            raise ValueError(f"sequence parallelism over {self.world} ranks needs more than {(self.world - 1) * self.per} "
+                             f"tokens (128-token-aligned shards of {self.per}); L = {L}: the last rank would own none — use fewer ranks")
         self.start = min(L, self.rank * self.per)
         self.stop = min(L, self.start + self.per)
         self.L = L
-        assert self.stop > self.start, (
-            f"rank {self.rank} owns no tokens (L={L}, world={self.world}); use fewer ranks")
         return self.start, self.stop
 
     def shard_tokens(self, x, cos, sin):

@@ -17,11 +17,27 @@ from . import kernels as K
 __all__ = ["SparseLinearAttention", "SageSparseLinearAttention", "sparse_linear_attention_hld"]
 
 
+SUPPORTED = "head_dim = 128, BLKQ = 128, BLKK = 64, feature_map = 'softmax'"
+
+
 def _check_feature_map(feature_map):
-    if feature_map != "softmax":
+    if feature_map in ("elu", "relu"):
         # the published TurboDiffusion checkpoints use the default softmax map; elu/relu exist in
-        # the reference (SLA/core.py:59-75) for SLA fine-tuning only
-        raise NotImplementedError(f"Not supported feature map {feature_map}.")
+        # the reference (SLA/core.py:57-64) for SLA fine-tuning only
+        raise NotImplementedError(f"feature_map={feature_map!r} is not built for the MI355X kernels (supported: {SUPPORTED})")
+    if feature_map != "softmax":
+        raise NotImplementedError(f"Not supported feature map {feature_map}.")   # the reference's own error, SLA/core.py:75
+
+
+def _check_geometry(head_dim, blkq, blkk):
+    """What the HIP attention / block-map kernels are instantiated for.  The reference additionally allows head_dim 64
+    (SLA/core.py:207) and defaults SparseLinearAttention to BLKQ = 64 (:39); its inference scripts construct
+    BLKQ = 128 / BLKK = 64 (inference/modify_model.py:50), which is the configuration built here."""
+    if head_dim != 128:
+        raise ValueError(f"head_dim={head_dim}: the MI355X attention kernels are built for {SUPPORTED}")
+    if blkq != 128 or blkk != 64:
+        raise ValueError(f"BLKQ={blkq}, BLKK={blkk}: the MI355X attention kernels are built for {SUPPORTED} "
+                         f"(pass BLKQ=128, BLKK=64 as inference/modify_model.py:50 does)")
 
 
 def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
@@ -39,8 +55,7 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     it in its epilogue (o = o_s + o_l, the 16-bit add of SLA/core.py:253) — no read-modify-write pass over the output.
     """
     H, L_, D = q.shape
-    assert D == 128, "head_dim must be 128 on this build (SLA/core.py:207 allows 64|128)"
-    assert blkq == 128 and blkk == 64, "MI355X kernels are built for BLKQ=128, BLKK=64"
+    _check_geometry(D, blkq, blkk)
     kb = K.cdiv(L_, blkk)
     topk = min(kb, int(topk_ratio * kb))
     if not dense and topk < 1:
@@ -81,6 +96,7 @@ class _SLABase(nn.Module):
     def __init__(self, head_dim, topk, feature_map, use_bf16, tie_feature_map_qk):
         super().__init__()
         _check_feature_map(feature_map)
+        _check_geometry(head_dim, 128, 64)
         self.dtype = torch.bfloat16 if use_bf16 else torch.float16
         self.topk = topk
         self.head_dim = head_dim
@@ -118,6 +134,7 @@ class SparseLinearAttention(_SLABase):
     def __init__(self, head_dim, topk, feature_map="softmax", BLKQ=64, BLKK=64, use_bf16=True,
                  tie_feature_map_qk=True):
         super().__init__(head_dim, topk, feature_map, use_bf16, tie_feature_map_qk)
+        _check_geometry(head_dim, BLKQ, BLKK)   # incl. the reference's default BLKQ = 64: refused at construction
         self.BLKQ = BLKQ
         self.BLKK = BLKK
 

@@ -124,7 +124,8 @@ class WanModel(nn.Module):
         super().__init__()
         assert model_type in ("t2v", "i2v") and qk_norm
         assert attention_type in ATTENTION_TYPES
-        assert (dim // num_heads) == 128, "the MI355X attention kernels are built for head_dim 128"
+        if dim // num_heads != 128 or dim % num_heads:
+            raise ValueError(f"dim={dim}, num_heads={num_heads}: the MI355X attention kernels are built for head_dim 128")
         self.model_type, self.patch_size, self.text_len = model_type, patch_size, text_len
         self.in_dim, self.dim, self.ffn_dim, self.freq_dim = in_dim, dim, ffn_dim, freq_dim
         self.text_dim, self.out_dim, self.num_heads, self.num_layers = text_dim, out_dim, num_heads, num_layers
@@ -147,6 +148,39 @@ class WanModel(nn.Module):
         self.fuse_cross_q_norm = True
         self.batch_text_kv = True
         self._ckv_all = None
+        self._weights_epoch = 0   # bumped whenever derived weight copies are dropped (GraphedModel re-captures on a change)
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_caches())
+
+    # ------------------------------------------------------------------ derived weight copies
+    def invalidate_caches(self):
+        """Forget every tensor derived from the weights (the q|k|v / cross k|v concatenations, the all-blocks text K|V
+        weight, proj_l copies) and make ``GraphedModel`` re-capture.  Called automatically after ``load_state_dict`` and
+        after ``.to()`` / ``.cuda()`` / ``.half()`` ...; call it yourself after replacing a weight tensor by assignment.
+        (In-place updates need nothing: the per-module weights are VIEWS of the concatenations, see ``_fused_weights``.)"""
+        self._fused.clear()
+        self._ckv_all = None
+        self._weights_epoch += 1
+
+    _FP32_BUFFERS = ("weight", "bias", "scale")
+
+    def _apply(self, fn, recurse=True):
+        """``net.to(torch.bfloat16)`` / ``.half()`` would also convert the fp32 buffers the HIP kernels read as fp32
+        (FastRMSNorm / FastLayerNorm weights, Int8Linear scales — the hazard wan2pt1.py warns about): keep those fp32
+        (device moves still apply), and drop the derived copies."""
+        keep = []
+        for m in self.modules():
+            if isinstance(m, (FastRMSNorm, FastLayerNorm, Int8Linear)):
+                for name in self._FP32_BUFFERS:
+                    t = m._buffers.get(name)
+                    if t is not None and t.dtype == torch.float32:
+                        keep.append((m, name, t))
+        out = super()._apply(fn, recurse)
+        for m, name, t in keep:
+            new = m._buffers.get(name)
+            if new is not None and new.dtype != torch.float32:
+                m._buffers[name] = t.to(device=new.device)
+        self.invalidate_caches()
+        return out
 
     # ------------------------------------------------------------------ weights
     @torch.no_grad()
@@ -173,9 +207,7 @@ class WanModel(nn.Module):
         missing = [k for k in own if k not in new]
         if missing:
             raise KeyError(f"missing keys {missing[:5]} ...")
-        self.load_state_dict(new, assign=False)
-        self._fused.clear()
-        self._ckv_all = None
+        self.load_state_dict(new, assign=False)   # (the post-hook drops the derived copies)
 
     def _lin(self, mod, x, gelu=False):
         """One Linear of a block on a [M, K] activation: W8A8 (HIP) or the plain bf16 library GEMM."""
@@ -221,7 +253,9 @@ class WanModel(nn.Module):
     def _fused_weights(self, i, blk):
         """q|k|v of self-attention and k|v of cross-attention share their input: concatenate the
         weights (and block scales — 128-row aligned, so the concatenation keeps the block structure)
-        once, so each input is quantised once and multiplied once."""
+        once, so each input is quantised once and multiplied once.  The per-module tensors are then RE-POINTED to
+        views of the concatenation: one copy in memory, ``state_dict()`` unchanged, and an in-place update of a module's
+        weight (``load_state_dict`` without ``assign``, ``copy_``) is an update of the fused tensor."""
         f = self._fused.get(i)
         if f is not None:
             return f
@@ -229,19 +263,29 @@ class WanModel(nn.Module):
         f = {}
         if isinstance(sa.q, Int8Linear):
             assert self.dim % 128 == 0
-            f["qkv_w"] = torch.cat([sa.q.int8_weight, sa.k.int8_weight, sa.v.int8_weight], 0).contiguous()
-            f["qkv_s"] = torch.cat([sa.q.scale, sa.k.scale, sa.v.scale], 0).contiguous()
-            f["qkv_b"] = torch.cat([sa.q.bias, sa.k.bias, sa.v.bias], 0).contiguous()
-            f["ckv_w"] = torch.cat([ca.k.int8_weight, ca.v.int8_weight], 0).contiguous()
-            f["ckv_s"] = torch.cat([ca.k.scale, ca.v.scale], 0).contiguous()
-            f["ckv_b"] = torch.cat([ca.k.bias, ca.v.bias], 0).contiguous()
+            for key, mods in (("qkv", (sa.q, sa.k, sa.v)), ("ckv", (ca.k, ca.v))):
+                for suf, attr in (("_w", "int8_weight"), ("_s", "scale"), ("_b", "bias")):
+                    parts = [getattr(m, attr) for m in mods]
+                    cat = torch.cat(parts, 0).contiguous()
+                    f[key + suf] = cat
+                    o = 0
+                    for m, p_ in zip(mods, parts):
+                        setattr(m, attr, cat[o:o + p_.shape[0]])
+                        o += p_.shape[0]
         else:
-            f["qkv_w"] = torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], 0).contiguous()
-            f["qkv_b"] = torch.cat([sa.q.bias, sa.k.bias, sa.v.bias], 0).contiguous()
-            f["ckv_w"] = torch.cat([ca.k.weight, ca.v.weight], 0).contiguous()
-            f["ckv_b"] = torch.cat([ca.k.bias, ca.v.bias], 0).contiguous()
+            for key, mods in (("qkv", (sa.q, sa.k, sa.v)), ("ckv", (ca.k, ca.v))):
+                for suf, attr in (("_w", "weight"), ("_b", "bias")):
+                    parts = [getattr(m, attr) for m in mods]
+                    cat = torch.cat([p_.detach() for p_ in parts], 0).contiguous()
+                    f[key + suf] = cat
+                    o = 0
+                    for p_ in parts:
+                        p_.data = cat[o:o + p_.shape[0]]
+                        o += p_.shape[0]
         la = getattr(sa.attn_op, "local_attn", None)
         if la is not None:
+            # fp32, contiguous nn.Linear parameters: these are the parameters' own storage (no copy), so fine-tuning
+            # updates are seen; after a dtype conversion of proj_l they would be copies -> _apply drops them
             f["proj_w"] = la.proj_l.weight.detach().float().contiguous()
             f["proj_b"] = la.proj_l.bias.detach().float().contiguous()
         self._fused[i] = f
@@ -250,18 +294,31 @@ class WanModel(nn.Module):
     def _text_kv_all(self, context):
         """[Lc, dim] text tokens -> [Lc, nblk * 2 * dim]: cross-attention k|v projections of every block, block i in columns
         [i*2*dim, (i+1)*2*dim).  The concatenated weights replace the per-block copies (views), so nothing is duplicated."""
+        a = self._text_kv_weights()
+        return self._fused_lin(context, a["ckv_w"], a.get("ckv_s"), a["ckv_b"])
+
+    def _text_kv_weights(self):
         if self._ckv_all is None:
             fs = [self._fused_weights(i, blk) for i, blk in enumerate(self.blocks)]
             n2 = 2 * self.dim
             allw = {k: torch.cat([f[k] for f in fs], 0).contiguous() for k in ("ckv_w", "ckv_s", "ckv_b") if k in fs[0]}
-            for i, f in enumerate(fs):   # per-block entries become views of the concatenation
+            quant = "ckv_s" in allw
+            for i, (f, blk) in enumerate(zip(fs, self.blocks)):   # per-block entries (and the modules' own tensors) become views
                 f["ckv_w"] = allw["ckv_w"][i * n2:(i + 1) * n2]
                 f["ckv_b"] = allw["ckv_b"][i * n2:(i + 1) * n2]
-                if "ckv_s" in allw:
+                if quant:
                     f["ckv_s"] = allw["ckv_s"][i * (n2 // 128):(i + 1) * (n2 // 128)]
+                ca, d = blk.cross_attn, self.dim
+                for j, m in enumerate((ca.k, ca.v)):
+                    if quant:
+                        m.int8_weight = f["ckv_w"][j * d:(j + 1) * d]
+                        m.scale = f["ckv_s"][j * (d // 128):(j + 1) * (d // 128)]
+                        m.bias = f["ckv_b"][j * d:(j + 1) * d]
+                    else:
+                        m.weight.data = f["ckv_w"][j * d:(j + 1) * d]
+                        m.bias.data = f["ckv_b"][j * d:(j + 1) * d]
             self._ckv_all = allw
-        a = self._ckv_all
-        return self._fused_lin(context, a["ckv_w"], a.get("ckv_s"), a["ckv_b"])
+        return self._ckv_all
 
     def _fused_lin(self, x, w, s, b):
         if s is not None:
@@ -374,6 +431,7 @@ class WanModel(nn.Module):
     @torch.no_grad()
     def forward(self, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, frame_cond_crossattn_emb_B_L_D=None,
                 y_B_C_T_H_W=None, **kwargs):
+        return_tokens = bool(kwargs.pop("_return_tokens", False))   # parity tests: the [B, L, dim] tokens after the blocks
         del kwargs
         K.require_gpu(x_B_C_T_H_W)
         if frame_cond_crossattn_emb_B_L_D is not None:
@@ -411,6 +469,8 @@ class WanModel(nn.Module):
             tkv = [self._text_kv_all(context[b]) for b in range(B)]
         for i, blk in enumerate(self.blocks):
             x = self._block(i, blk, x, e0, cos, sin, context, tkv)
+        if return_tokens:
+            return x if sp is None else sp.gather_tokens(x, L_)
         # head (wan2pt1.py:444-454): fp32 modulate of the (bf16) norm, fp32 Linear
         em = (self.head.modulation.float() + e_B_D.unsqueeze(1))  # [B, 2, dim]
         L_loc = x.shape[1]
