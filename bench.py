@@ -8,18 +8,18 @@ A "step" is one whole video: the 4 DiT forwards + sampler updates on latents alr
 HBM (text encoding / VAE are outside the metric, reference README.md:207).  For N > 1 launch with
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
 
-Multi-GPU (one process per GPU, RCCL).  The unit of work is a video and videos are independent, so the headline
-number shards VIDEOS: every rank runs the single-GPU path (hipGraph replay) on its own seeded video, no data-path
-collective, per-GPU work fixed as N grows ("weak" scaling), ``value`` = N videos / max-over-ranks time.  Sharding
-ONE video by sequence (turbodiffusion_amd.seqpar: one packed RCCL all-gather of the quantised K/V state per
-self-attention layer) is the LATENCY mode: per layer every rank must receive 3 B per token-channel of the other
-ranks' K/V over xGMI (C1: 151 MB/layer in total = 1.0 ms at sp=2 over one link, 0.25 ms at sp=8 over seven) beside
-3.3 ms / sp of compute, so it can never reach the videos/s of N independent replicas.  After the timed region the
-same run therefore measures that mode once over all N ranks and reports it in ``sequence_parallel`` (ms per video,
-DiT-step ms, speed-up over one GPU); ``--sp S`` instead makes the timed region itself run N/S sequence-parallel
-groups of S GPUs.  At N = 1 the line also carries ``two_videos_in_flight_videos_per_s``: the same GPU with two
-independent videos in flight on two streams (a serving-style extra, +3-6 %; never the headline ``value``).  Rank 0
-prints ONE JSON line.
+Multi-GPU (one process per GPU, RCCL over xGMI).  BASELINE.json's configs are ONE sample and its north star shards
+the DiT forward by SEQUENCE, so for N > 1 the timed region is one video sharded over all N ranks
+(turbodiffusion_amd.seqpar: every rank owns a 128-token-aligned slice of the tokens; per self-attention layer one
+packed RCCL all-gather of the quantised K / V^T / pooled-K / linear-branch partials, pipelined over head groups; one
+all-gather of the head output per step): ``value`` = videos/s of that single video, ``"scaling": "strong"``.  Per layer
+every rank must receive 3 B per token-channel of the other ranks' K/V (C1: 151 MB/layer in total = 1.0 ms at N = 2 over
+one link, 0.25 ms at N = 8 over seven) beside 3.3 ms / N of compute, so this is the LATENCY mode; the THROUGHPUT mode —
+N independent videos, no data-path collective — is measured after the timed region and reported beside it in
+``replicas`` (never as ``value``).  ``--sp S`` (S < N) makes the timed region run N/S sequence-parallel groups of S
+GPUs; ``--sp 1`` N independent videos.  A collective that fails or never returns fails the run (no masking).  At N = 1
+the line also carries ``two_videos_in_flight_videos_per_s``: the same GPU with two independent videos in flight on two
+streams (a serving-style extra, +3-6 %; never the headline ``value``).  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
   turbo    TurboWan2.1-T2V-1.3B-480P as published: SageSLA top-k 0.1 + W8A8 linears + fused norms
@@ -144,15 +144,18 @@ def main():
     ap.add_argument("--res", default="480p", choices=sorted(RES))
     ap.add_argument("--num-steps", type=int, default=4, help="sampler steps per video")
     ap.add_argument("--topk", type=float, default=0.1)
+    ap.add_argument("--two-experts", action="store_true", help="Wan2.2-A14B as the reference runs it (wan2.2_i2v_infer.py:"
+                    "186-197): high- and low-noise experts, switched at t < 0.9 — BOTH resident in HBM (2 x 14 GB int8), "
+                    "the switch inside the timed region; sigma_max = 200")
+    ap.add_argument("--sigma-max", type=float, default=0.0, help="0: 80 for T2V, 200 for I2V (the scripts' defaults)")
     ap.add_argument("--layers", type=int, default=0, help="debug: override num_layers (INVALID as a bench number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel eagerly instead of replaying "
                     "one captured hipGraph per DiT forward (sequence-parallel runs are always eager)")
-    ap.add_argument("--sp", type=int, default=1, help="sequence-parallel group size of the TIMED region (GPUs sharing "
-                    "one video); N/sp groups run independent videos.  Default 1: N independent videos")
-    ap.add_argument("--no-sp-leg", action="store_true", help="N > 1: skip the sequence-parallel latency measurement "
-                    "that follows the timed region")
-    ap.add_argument("--sp-leg-timeout", type=float, default=240.0)
+    ap.add_argument("--sp", type=int, default=0, help="sequence-parallel group size of the TIMED region (GPUs sharing "
+                    "one video); N/sp groups run independent videos.  Default 0 = N: ONE video sharded over all GPUs")
+    ap.add_argument("--no-replica-leg", action="store_true", help="N > 1: skip the throughput-mode measurement (N "
+                    "independent videos) that follows the timed region")
     ap.add_argument("--no-two-in-flight", action="store_true", help="N = 1: skip the extra measurement with two "
                     "independent videos in flight on two streams (reported beside the headline, never as `value`)")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("TD_GEMM_VARIANT", "0")),
@@ -173,7 +176,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    sp = max(1, args.sp)
+    sp = args.sp if args.sp > 0 else world
     assert world % sp == 0, f"--sp {sp} must divide the number of GPUs ({world})"
     dp = world // sp
     sp_group, my_group = None, rank // sp
@@ -197,9 +200,16 @@ def main():
 
     wl = WORKLOADS[args.workload]
     net, cfg = build_model(args.model, wl, dev, args.topk, args.layers or None)
+    net_low = None
+    if args.two_experts:
+        assert cfg["model_type"] == "i2v", "--two-experts is the Wan2.2-A14B configuration"
+        net_low, _ = build_model(args.model, wl, dev, args.topk, args.layers or None)   # second weight set, resident
+    sigma_max = args.sigma_max or (200.0 if cfg["model_type"] == "i2v" else 80.0)
     if sp > 1:
         from turbodiffusion_amd import seqpar
         seqpar.enable(net, sp_group)
+        if net_low is not None:
+            seqpar.enable(net_low, sp_group)
 
     w, h = RES[args.res]
     lat_shape = (1, 16, 21, h // 8, w // 8)  # 81 frames -> 21 latent frames, VAE 8x spatial
@@ -224,13 +234,16 @@ def main():
         assert hasattr(net, key), key
         setattr(net, key, bool(int(val)))
     use_graph = (sp == 1) and not args.no_graph  # (the RCCL all-gathers of a sequence-parallel step stay eager)
-    run_net = net
+    run_net, run_low = net, net_low
     if use_graph:
         from turbodiffusion_amd.graph import GraphedModel
         run_net = GraphedModel(net)
+        run_low = None if net_low is None else GraphedModel(net_low)
 
     def one_video(model=None):
-        return rcm_sample(model or run_net, init_noise, text, num_steps=args.num_steps, generator=g, y=y)
+        eager = model is not None
+        return rcm_sample(model or run_net, init_noise, text, num_steps=args.num_steps, generator=g, y=y,
+                          sigma_max=sigma_max, net_low=(net_low if eager else run_low), boundary=0.9)
 
     def sync():
         torch.cuda.synchronize()
@@ -299,54 +312,35 @@ def main():
         elapsed = tt.item()
     assert torch.isfinite(out).all(), "non-finite latents"
 
-    # ---- latency mode: ONE video sharded by sequence over all N ranks (RCCL all-gathers over xGMI), measured after
-    #      the timed region; a watchdog bounds it so that a collective that never returns cannot cost the headline line
-    sp_leg, sp_hung = None, False
-    if world > 1 and sp == 1 and not args.no_sp_leg:
-        import threading
-        sp_leg = {}
+    # ---- throughput mode beside it (N > 1, sequence-parallel timed region): N independent videos, one per rank, the
+    #      single-GPU path (hipGraph replay), no data-path collective; reported in `replicas`, never as `value`
+    replicas = None
+    if world > 1 and sp > 1 and not args.no_replica_leg:
+        from turbodiffusion_amd import seqpar
+        from turbodiffusion_amd.graph import GraphedModel
+        seqpar.disable(net)
+        if net_low is not None:
+            seqpar.disable(net_low)
+        g_own = torch.Generator(device=dev).manual_seed(1000 + rank)
+        noise_own = torch.randn(lat_shape, dtype=torch.float32, device=dev, generator=g_own)
+        gm = GraphedModel(net)
+        gm_low = None if net_low is None else GraphedModel(net_low)
 
-        def run_leg():
-            try:
-                torch.cuda.set_device(local)
-                from turbodiffusion_amd import seqpar
-                g2 = torch.Generator(device=dev).manual_seed(0)   # identical latents on every rank
-                noise2 = torch.randn(lat_shape, dtype=torch.float32, device=dev, generator=g2)
-                text2 = torch.randn(1, 512, cfg.get("text_dim", 4096), device=dev, generator=g2).bfloat16()
-                y2 = None
-                if y is not None:
-                    y2 = y.clone()
-                    y2[:, 4:] = torch.randn(1, 16, *lat_shape[2:], device=dev, generator=g2)
-                seqpar.enable(net, dist.group.WORLD)
-                try:
-                    def video():
-                        return rcm_sample(net, noise2, text2, num_steps=args.num_steps, generator=g2, y=y2)
-                    video()                       # warm-up: RCCL channels for the all-gather sizes, allocator
-                    sync()
-                    n_v = 2
-                    t2 = time.perf_counter()
-                    for _ in range(n_v):
-                        o2 = video()
-                    sync()
-                    dt2 = (time.perf_counter() - t2) / n_v
-                    assert torch.isfinite(o2).all(), "non-finite latents (sequence parallel)"
-                finally:
-                    seqpar.disable(net)
-                sp_leg.update({"ranks": world, "ms_per_video": dt2 * 1e3, "dit_step_ms": dt2 * 1e3 / args.num_steps,
-                               "videos_per_s": 1.0 / dt2, "speedup_vs_one_gpu": (elapsed / args.steps) / dt2,
-                               "videos_timed": n_v, "launch_mode": "eager enqueue",
-                               "collective": "packed all-gather of int8 K | fp16 V^T | scales | pooled K | linear-branch partials per "
-                                             "self-attention layer (4 head-group pieces, attention pipelined behind them) + one "
-                                             "of the head output per step"})
-            except Exception as e:  # reported, never fatal for the headline number
-                sp_leg["error"] = repr(e)
-
-        th = threading.Thread(target=run_leg, daemon=True)
-        th.start()
-        th.join(args.sp_leg_timeout)
-        if th.is_alive():
-            sp_hung = True
-            sp_leg = {"error": f"no completion within {args.sp_leg_timeout:.0f} s"}
+        def own_video():
+            return rcm_sample(gm, noise_own, text, num_steps=args.num_steps, generator=g_own, y=y, sigma_max=sigma_max,
+                              net_low=gm_low, boundary=0.9)
+        own_video()                       # capture + warm-up
+        sync()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            o3 = own_video()
+        sync()
+        dt3 = time.perf_counter() - t3
+        tt3 = torch.tensor([dt3], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt3, op=dist.ReduceOp.MAX)
+        assert torch.isfinite(o3).all(), "non-finite latents (replica leg)"
+        replicas = {"videos_per_s": world * args.steps / tt3.item(), "ms_per_video_per_gpu": tt3.item() / args.steps * 1e3,
+                    "mode": f"{world} independent videos, one per GPU, hipGraph replay, no data-path collective"}
 
     if rank == 0:
         per_video = elapsed / args.steps   # per sequence-parallel group
@@ -393,7 +387,10 @@ def main():
             "data": "synthetic (seeded N(0,1) latents/text embedding, random-init weights of the named architecture)",
             "config": {"workload": wl["desc"].replace("Wan2.1-T2V-1.3B 480p", f"{args.model} {args.res}").replace(
                            "TurboWan2.1-T2V-1.3B-480P", f"Turbo{args.model}-{args.res.upper()}"), "model": args.model, "resolution": args.res, "tokens": L_tok,
-                       "sampler_steps": args.num_steps, "sla_topk": args.topk,
+                       "sampler_steps": args.num_steps, "sla_topk": args.topk, "sigma_max": sigma_max,
+                       "experts": ("high-noise + low-noise, both resident in HBM, switch at t < 0.9 inside the timed region "
+                                   "(steps: " + "/".join(__import__("turbodiffusion_amd.sampler", fromlist=["x"]).expert_schedule(
+                                       args.num_steps, sigma_max, 0.9)) + ")") if net_low is not None else 1,
                        "global_batch": dp,
                        "parallelism": "single GPU" if world == 1 else (
                            f"dp{dp} x sp{sp}: {dp} independent videos, each sharded by sequence over {sp} GPUs "
@@ -404,8 +401,8 @@ def main():
         }
         if eager_elapsed is not None:
             res["eager_videos_per_s"] = 1.0 / eager_elapsed
-        if sp_leg is not None:
-            res["sequence_parallel"] = sp_leg
+        if replicas is not None:
+            res["replicas"] = replicas
         if two_in_flight is not None:
             res["two_videos_in_flight_videos_per_s"] = two_in_flight
         if args.layers:
@@ -417,9 +414,6 @@ def main():
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
     if world > 1:
-        if sp_hung or (sp_leg is not None and "error" in sp_leg):
-            sys.stdout.flush()
-            os._exit(0)   # ranks may be stuck inside a collective: leave without a teardown handshake
         dist.destroy_process_group()
 
 

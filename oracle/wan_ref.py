@@ -162,15 +162,25 @@ def rcm_timesteps(num_steps=4, sigma_max=80.0):
     return torch.sin(t) / (torch.cos(t) + torch.sin(t))
 
 
-def rcm_sample(net_fn, init_noise, noises, num_steps=4, sigma_max=80.0, act_dtype=torch.bfloat16):
+def rcm_sample(net_fn, init_noise, noises, num_steps=4, sigma_max=80.0, act_dtype=torch.bfloat16, ode=False,
+               net_low_fn=None, boundary=0.9):
     """net_fn(x_bf16, t_bf16[B,1]) -> velocity; ``noises``: list of the per-step N(0,1) tensors (the
-    reference draws them from a seeded CUDA generator; passing them in makes CPU/GPU runs comparable)."""
+    reference draws them from a seeded CUDA generator; passing them in makes CPU/GPU runs comparable).
+    ``ode``: x - (t_cur - t_next) v instead of the SDE step (wan2.2_i2v_infer.py:202-203); ``net_low_fn`` / ``boundary``:
+    the Wan2.2 expert switch — the high-noise net until the first step with t_cur < boundary, the low-noise one from
+    there on (:190-197)."""
     t_steps = rcm_timesteps(num_steps, sigma_max)
     x = init_noise.to(torch.float64) * t_steps[0]
     ones = torch.ones(x.size(0), 1, dtype=torch.float64)
+    fn, switched = net_fn, False
     for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
-        v = net_fn(x.to(act_dtype), (t_cur.float() * ones * 1000).to(act_dtype)).to(torch.float64)
-        x = (1 - t_next) * (x - t_cur * v) + t_next * noises[i].to(torch.float64)
+        if net_low_fn is not None and t_cur.item() < boundary and not switched:
+            fn, switched = net_low_fn, True
+        v = fn(x.to(act_dtype), (t_cur.float() * ones * 1000).to(act_dtype)).to(torch.float64)
+        if ode:
+            x = x - (t_cur - t_next) * v
+        else:
+            x = (1 - t_next) * (x - t_cur * v) + t_next * noises[i].to(torch.float64)
     return x.float()
 
 

@@ -40,14 +40,14 @@ def _single_rank(q, k, v, at, ratio, wp, bp):
     return out
 
 
-def _worker(rank, world, port, at, L, ratio, ret):
+def _worker(rank, world, port, at, L, ratio, ret, H=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from turbodiffusion_amd.seqpar import SeqParallel
         torch.manual_seed(0)
-        H, D = 2, 128
+        D = 128
         q, k, v = (t[0].contiguous() for t in qkv(H, L, 21))  # [H, L, D], identical on every rank
         g = torch.Generator().manual_seed(3)
         wp, bp = torch.randn(D, D, generator=g) * 0.05, torch.randn(D, generator=g) * 0.05
@@ -82,6 +82,43 @@ def test_seqpar_world2_matches_single_rank(at, L, ratio):
     assert ret["exact_frac"] > 0.98, dict(ret)
     if at == "sagesla":
         assert ret["sp_vs_module_oracle"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
+
+
+@pytest.mark.parametrize("world,at,L,ratio,H", [(4, "sagesla", 900, 0.3, 2),      # 8 Q blocks: 256, 256, 256, 132 tokens
+                                                 (8, "sagesla", 1970, 0.25, 5),    # 16 Q blocks: 7 x 256 + a 178-token tail rank;
+                                                                                   # 5 heads over 4 head groups (uneven groups)
+                                                 (8, "sage", 1100, 1.0, 1)])       # 9 Q blocks, per = 256: ranks 5-7 would be empty
+def test_seqpar_world4_and_world8(world, at, L, ratio, H):
+    """The rank-padded gathered layout, the packed exchange and the head-group pipeline at world sizes 4 and 8 (gloo,
+    CPU, oracle compute backend), incl. a short tail rank; and a shape that leaves ranks without tokens is refused on
+    EVERY rank before any collective (no hang)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    if L == 1100:
+        with pytest.raises(Exception) as ei:
+            mp.spawn(_worker, args=(world, _free_port(), at, L, ratio, ret, H), nprocs=world, join=True)
+        assert "use fewer ranks" in str(ei.value)
+        return
+    mp.spawn(_worker, args=(world, _free_port(), at, L, ratio, ret, H), nprocs=world, join=True)
+    assert ret["sp_vs_single"] < 5e-3, dict(ret)
+    assert ret["exact_frac"] > 0.97, dict(ret)
+    assert ret["sp_vs_module_oracle"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
+
+
+def test_plan_c4_591_blocks_over_8_ranks():
+    """C4/C5 (720p): L = 75 600 = 590 full 128-token blocks + an 80-token tail = 591 Q blocks over 8 ranks -> 74 blocks
+    (9472 tokens) on ranks 0-6, 73 on rank 7 whose last block is the 80-token tail."""
+    from turbodiffusion_amd.seqpar import SeqParallel
+
+    class Fake(SeqParallel):
+        def __init__(self, rank, world):
+            self.rank, self.world, self.L = rank, world, None
+
+    spans = [Fake(r, 8).plan(75600) for r in range(8)]
+    assert [e - s for s, e in spans] == [9472] * 7 + [75600 - 7 * 9472]
+    assert (75600 - 7 * 9472) == 72 * 128 + 80
+    with pytest.raises(ValueError, match="use fewer ranks"):
+        Fake(0, 8).plan(128 * 7)          # evaluated identically on every rank, rank 0 included
 
 
 def test_plan_covers_all_tokens_block_aligned():

@@ -9,11 +9,24 @@ from typing import Callable, List, Optional
 import torch
 
 
-def rcm_timesteps(num_steps: int = 4, sigma_max: float = 80.0, device="cuda") -> torch.Tensor:
-    """TrigFlow times [atan(sigma_max), 1.5, 1.4, 1.0, 0] -> rectified-flow t = sin/(cos+sin)  (:111-122)."""
+def rcm_timesteps(num_steps: int = 4, sigma_max: float = 80.0, device="cpu") -> torch.Tensor:
+    """TrigFlow times [atan(sigma_max), 1.5, 1.4, 1.0, 0] -> rectified-flow t = sin/(cos+sin)  (:111-122).
+    Five fp64 numbers: computed on the HOST (the loop below needs them as host scalars — the expert switch compares
+    t_cur with ``boundary`` — and a device tensor would cost one synchronising ``.item()`` per step)."""
     mid_t = [1.5, 1.4, 1.0][: num_steps - 1]
-    t = torch.tensor([math.atan(sigma_max), *mid_t, 0], dtype=torch.float64, device=device)
-    return torch.sin(t) / (torch.cos(t) + torch.sin(t))
+    t = torch.tensor([math.atan(sigma_max), *mid_t, 0], dtype=torch.float64)
+    return (torch.sin(t) / (torch.cos(t) + torch.sin(t))).to(device)
+
+
+def expert_schedule(num_steps: int = 4, sigma_max: float = 200.0, boundary: float = 0.9):
+    """Which expert runs each step of the Wan2.2 loop (wan2.2_i2v_infer.py:190-197): 'high' while t_cur >= boundary,
+    'low' from the first step with t_cur < boundary on.  sigma_max = 200, boundary 0.9 -> ['high', 'high', 'low', 'low']."""
+    ts = rcm_timesteps(num_steps, sigma_max).tolist()
+    out, switched = [], False
+    for t_cur in ts[:-1]:
+        switched = switched or t_cur < boundary
+        out.append("low" if switched else "high")
+    return out
 
 
 @torch.no_grad()
@@ -28,14 +41,17 @@ def rcm_sample(net: Callable, init_noise: torch.Tensor, crossattn_emb: torch.Ten
     CPU oracle and GPU runs see identical noise.  ``net_low``/``boundary``: Wan2.2 expert switch
     (use ``net`` while t_cur >= boundary, ``net_low`` after: wan2.2_i2v_infer.py:191-197)."""
     dev = init_noise.device
-    t_steps = rcm_timesteps(num_steps, sigma_max, dev)
+    t_host = rcm_timesteps(num_steps, sigma_max)             # fp64, host: no device sync anywhere in the loop
+    t_steps = t_host.tolist()
     x = init_noise.to(torch.float64) * t_steps[0]
-    ones = torch.ones(x.size(0), 1, device=dev, dtype=x.dtype)
+    kw = {} if y is None else {"y_B_C_T_H_W": y.to(dtype)}
+    switched = False
     for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
-        model = net if (net_low is None or t_cur.item() >= boundary) else net_low
-        kw = {} if y is None else {"y_B_C_T_H_W": y.to(dtype)}
-        v = model(x_B_C_T_H_W=x.to(dtype), timesteps_B_T=(t_cur.float() * ones * 1000).to(dtype),
-                  crossattn_emb=crossattn_emb, **kw).to(torch.float64)
+        switched = switched or (net_low is not None and t_cur < boundary)   # once low, stays low (:191-197)
+        model = net_low if switched else net
+        # (t_cur.float() * ones * 1000).to(dtype): the fp32 rounding of t_cur, times 1000 in fp64, cast  (:199)
+        t_in = torch.full((x.size(0), 1), float(t_host[i].float()) * 1000.0, dtype=torch.float64, device=dev).to(dtype)
+        v = model(x_B_C_T_H_W=x.to(dtype), timesteps_B_T=t_in, crossattn_emb=crossattn_emb, **kw).to(torch.float64)
         if ode:
             x = x - (t_cur - t_next) * v
         else:
