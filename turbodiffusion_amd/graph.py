@@ -23,6 +23,7 @@ class GraphedModel(torch.nn.Module):
         super().__init__()
         self.net = net
         self._graphs = {}
+        self._text_src = {}   # per graph: identity/version of the text tensor last copied into its static buffer
         self._epoch = getattr(net, "_weights_epoch", 0)
 
     def _key(self, x, t, ctx, y):
@@ -39,11 +40,26 @@ class GraphedModel(torch.nn.Module):
         epoch = getattr(self.net, "_weights_epoch", 0)
         if epoch != self._epoch:   # derived weight copies were dropped: captured graphs hold pointers into freed tensors
             self._graphs.clear()
+            self._text_src.clear()
             self._epoch = epoch
         key = self._key(x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W)
         ent = self._graphs.get(key)
+        cache_text = getattr(self.net, "cache_text_kv", False)
+        if ent is not None and cache_text:
+            # the text-only work (text MLP, cross-attention K / V^T of every block) lives OUTSIDE the captured graph: done
+            # eagerly here when the text changed, a no-op (cache hit) for the other steps of a video.  The graph reads the
+            # model's persistent text buffers; should the model have re-allocated them (cache eviction), re-capture.
+            sc = ent[3]
+            src = (crossattn_emb.data_ptr(), crossattn_emb._version)
+            if self._text_src.get(key) != src:
+                sc.copy_(crossattn_emb)
+                self._text_src[key] = src
+            if self.net.prepare_text(sc)[2].data_ptr() != ent[6]:
+                del self._graphs[key]
+                ent = None
         if ent is None:
             sx, st, sc = x_B_C_T_H_W.clone(), timesteps_B_T.clone(), crossattn_emb.clone()
+            self._text_src[key] = (crossattn_emb.data_ptr(), crossattn_emb._version)
             sy = None if y_B_C_T_H_W is None else y_B_C_T_H_W.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -54,13 +70,16 @@ class GraphedModel(torch.nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 so = self.net(sx, st, sc, y_B_C_T_H_W=sy)
-            ent = (g, sx, st, sc, sy, so)
+            text_ptr = self.net.prepare_text(sc)[2].data_ptr() if cache_text else 0
+            ent = (g, sx, st, sc, sy, so, text_ptr)
             self._graphs[key] = ent
-        g, sx, st, sc, sy, so = ent
+        g, sx, st, sc, sy, so, _ = ent
         sx.copy_(x_B_C_T_H_W)
         st.copy_(timesteps_B_T)
-        if sc.data_ptr() != crossattn_emb.data_ptr():
+        src = (crossattn_emb.data_ptr(), crossattn_emb._version)
+        if self._text_src.get(key) != src:     # a new text (or the same tensor modified in place): refresh the static copy
             sc.copy_(crossattn_emb)
+            self._text_src[key] = src
         if sy is not None:
             sy.copy_(y_B_C_T_H_W)
         g.replay()

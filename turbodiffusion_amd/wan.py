@@ -148,6 +148,8 @@ class WanModel(nn.Module):
         self.fuse_cross_q_norm = True
         self.batch_text_kv = True
         self._ckv_all = None
+        self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
+        self._text_states = {}     # data_ptr -> (key, source tensor, context, [per batch entry: [per block: (k, vt)]])
         self._weights_epoch = 0   # bumped whenever derived weight copies are dropped (GraphedModel re-captures on a change)
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_caches())
 
@@ -159,6 +161,7 @@ class WanModel(nn.Module):
         (In-place updates need nothing: the per-module weights are VIEWS of the concatenations, see ``_fused_weights``.)"""
         self._fused.clear()
         self._ckv_all = None
+        self._text_states = {}
         self._weights_epoch += 1
 
     _FP32_BUFFERS = ("weight", "bias", "scale")
@@ -353,20 +356,59 @@ class WanModel(nn.Module):
                                                 (D, 3 * dim), dense=dense, quant_out=quant_out)
         return res
 
-    def _cross_attention(self, i, blk, xn, context, quant_out=False, text_kv=None):
-        """xn [L, dim] (norm3 output), context [Lc, dim] -> [L, dim] (before the o projection)."""
+    def _text_kvt(self, i, blk, context, text_kv=None):
+        """Cross-attention K (RMSNorm'ed, head-major) and V^T tiles of block i for one batch entry's text tokens."""
         f = self._fused_weights(i, blk)
         ca = blk.cross_attn
         H, D, dim = self.num_heads, 128, self.dim
-        L_ = xn[0].shape[0] if isinstance(xn, tuple) else xn.shape[0]
         Lc = context.shape[0]
-        qc = self._lin_q(ca.q, xn[0], xn[1], context.dtype) if isinstance(xn, tuple) else self._lin(ca.q, xn)
-        if text_kv is not None:   # this block's columns of the all-blocks text K|V projection (forward)
+        if text_kv is not None:   # this block's columns of the all-blocks text K|V projection
             kv = text_kv[:, i * 2 * dim:(i + 1) * 2 * dim]
         else:
             kv = self._fused_lin(context, f["ckv_w"], f.get("ckv_s"), f["ckv_b"])  # [Lc, 2*dim]
         k = K.qk_norm_rope(kv, 0, H, D, ca.norm_k.weight, None, None, self.eps)
         vt = K.v_transpose(kv[:, dim:], D, kv.stride(0), Lc, H, D, context.dtype)
+        return k, vt
+
+    @torch.no_grad()
+    def prepare_text(self, crossattn_emb):
+        """Everything on the cross-attention K side depends on the text embedding only — the text MLP, the K|V projections
+        of all blocks, K's RMSNorm, the V^T tiles — and the text is constant over the 4 steps of a video
+        (wan2.1_t2v_infer.py:129-139 passes the same ``condition`` every step): compute it ONCE per text and keep it in
+        persistent buffers (over-written in place when the text changes, so a captured hipGraph keeps valid pointers).
+        ``forward`` calls this itself on a cache miss; ``GraphedModel`` calls it eagerly before replaying."""
+        key = (crossattn_emb.data_ptr(), crossattn_emb._version, tuple(crossattn_emb.shape), crossattn_emb.dtype)
+        st = self._text_states.get(key[0])
+        if st is not None and st[0] == key:
+            return st
+        context = self.text_embedding(crossattn_emb.to(self.dtype)).contiguous()  # [B, Lc, dim]
+        B = context.shape[0]
+        per_b = []
+        for b in range(B):
+            tkv = self._text_kv_all(context[b]) if self.batch_text_kv else None
+            per_b.append([self._text_kvt(i, blk, context[b], tkv) for i, blk in enumerate(self.blocks)])
+        if st is not None and st[2].shape == context.shape and len(st[3]) == B:
+            st[2].copy_(context)                       # same buffer, new contents: refresh the persistent tensors in place
+            for old_b, new_b in zip(st[3], per_b):
+                for (ok, ovt), (nk, nvt) in zip(old_b, new_b):
+                    ok.copy_(nk)
+                    ovt.copy_(nvt)
+            context, per_b = st[2], st[3]
+        # the entry holds a reference to the source tensor: its address cannot be recycled for another text while cached,
+        # so (address, version) identifies the contents.  A handful of entries (one per live text buffer), oldest dropped.
+        self._text_states.pop(key[0], None)
+        while len(self._text_states) >= 4:
+            self._text_states.pop(next(iter(self._text_states)))
+        self._text_states[key[0]] = (key, crossattn_emb, context, per_b)
+        return self._text_states[key[0]]
+
+    def _cross_attention(self, i, blk, xn, context, quant_out=False, text_kv=None, kvt=None):
+        """xn [L, dim] (norm3 output), context [Lc, dim] -> [L, dim] (before the o projection)."""
+        ca = blk.cross_attn
+        H, D, dim = self.num_heads, 128, self.dim
+        L_ = xn[0].shape[0] if isinstance(xn, tuple) else xn.shape[0]
+        qc = self._lin_q(ca.q, xn[0], xn[1], context.dtype) if isinstance(xn, tuple) else self._lin(ca.q, xn)
+        k, vt = kvt if kvt is not None else self._text_kvt(i, blk, context, text_kv)
         out = None if quant_out else torch.empty((L_, dim), dtype=context.dtype, device=context.device)
         if self.fuse_cross_q_norm:
             # RMSNorm(q) applied where the attention kernel loads Q: the head-major normalised copy is never written
@@ -376,7 +418,7 @@ class WanModel(nn.Module):
         q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
         return K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
 
-    def _block(self, i, blk, x, e0_B_6_D, cos, sin, context, tkv=None):
+    def _block(self, i, blk, x, e0_B_6_D, cos, sin, context, tkv=None, kvts=None):
         """x: [B, L_loc, dim] (updated in place); e0 fp32 [B, 6, dim]; context [B, Lc, dim]."""
         B, L_loc, dim = x.shape
         e = (blk.modulation.float() + e0_B_6_D)  # fp32 [B, 6, dim]  (wan2pt1.py:400)
@@ -409,7 +451,8 @@ class WanModel(nn.Module):
         else:
             xns = [x2[r] for r in rows]
         cs = [self._cross_attention(i, blk, xns[b], context[b], quant_out=self.quant_linear and B == 1,
-                                    text_kv=None if tkv is None else tkv[b]) for b in range(B)]
+                                    text_kv=None if tkv is None else tkv[b],
+                                    kvt=None if kvts is None else kvts[b][i]) for b in range(B)]
         c = cs[0] if B == 1 else torch.cat(cs, 0)
         self._residual_lin_(x2, blk.cross_attn.o, c, None)
         # ---- FFN ----
@@ -461,14 +504,17 @@ class WanModel(nn.Module):
         e = F.linear(e, te[0].weight.float(), te[0].bias.float())
         e_B_D = F.linear(F.silu(e), te[2].weight.float(), te[2].bias.float())
         e0 = F.linear(F.silu(e_B_D), tp[1].weight.float(), tp[1].bias.float()).unflatten(1, (6, self.dim))
-        context = self.text_embedding(crossattn_emb.to(dt)).contiguous()  # [B, Lc, dim]
-        tkv = None
-        if self.batch_text_kv:
-            # the cross-attention K|V projections of ALL blocks read the same 512 text tokens: one [Lc, nblk*2*dim] GEMM
-            # (2880 tiles) and one quantisation of the text instead of one 96-tile GEMM + quantisation per block
-            tkv = [self._text_kv_all(context[b]) for b in range(B)]
+        tkv = kvts = None
+        if self.cache_text_kv:
+            _, _, context, kvts = self.prepare_text(crossattn_emb)   # once per text (keyed on the tensor's identity + version)
+        else:
+            context = self.text_embedding(crossattn_emb.to(dt)).contiguous()  # [B, Lc, dim]
+            if self.batch_text_kv:
+                # the cross-attention K|V projections of ALL blocks read the same 512 text tokens: one [Lc, nblk*2*dim] GEMM
+                # (2880 tiles) and one quantisation of the text instead of one 96-tile GEMM + quantisation per block
+                tkv = [self._text_kv_all(context[b]) for b in range(B)]
         for i, blk in enumerate(self.blocks):
-            x = self._block(i, blk, x, e0, cos, sin, context, tkv)
+            x = self._block(i, blk, x, e0, cos, sin, context, tkv, kvts)
         if return_tokens:
             return x if sp is None else sp.gather_tokens(x, L_)
         # head (wan2pt1.py:444-454): fp32 modulate of the (bf16) norm, fp32 Linear
