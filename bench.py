@@ -244,7 +244,7 @@ def main():
     for kv in filter(None, os.environ.get("TD_BENCH_MODEL_FLAGS", "").split(",")):   # A/B runs: fuse_* attributes of WanModel
         key, val = kv.split("=")
         assert hasattr(net, key), key
-        setattr(net, key, bool(int(val)))
+        setattr(net, key, bool(int(val)) if val.isdigit() else val)
     use_graph = (sp == 1) and not args.no_graph  # (the RCCL all-gathers of a sequence-parallel step stay eager)
     run_net, run_low = net, net_low
     if use_graph:

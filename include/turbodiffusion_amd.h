@@ -207,6 +207,23 @@ int td_attn_i8_ex(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, cons
                   int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale,
                   td_stream_t stream);
 
+/* ---- a13, FP8-PV variant (the reference's sm89+ branch, SLA/core.py:217-239; SpargeAttn's
+ * fused.transpose_pad_permute_cuda + fused.scale_fuse_quant_cuda and qk_int8_sv_f8_*_fuse_v_scale_* kernels) ----
+ * td_v_fp8_tiles: V (element (h,l,d) at v + h*stride_h + l*stride_l + d, f16|bf16) ->
+ *   v_scale f32 [H, 128] = max_l |v[h,l,d]| / scale_max (the reference passes 2.25), and
+ *   vt8 [H, ceil(L/64), 128, 64] OCP e4m3 = e4m3(v / v_scale), keys of a block in the position order of the PV MFMA's
+ *   B operand (position 32hi + 16g + r holds key 32g + (r&3) + 8(r>>2) + 4hi), tail keys zero.
+ *   ws: f32 scratch [H, 64, 128] (partial maxima).
+ * td_attn_i8_fp8pv: td_attn_i8_ex with P rounded to e4m3 and P.V on the fp8 MFMA (fp32 accumulate), the V channel
+ *   scale applied in the epilogue. */
+int td_v_fp8_tiles(const void* v, int in_dtype, int64_t stride_h, int64_t stride_l, uint8_t* vt8, float* v_scale,
+                   float* ws, float scale_max, int64_t L, int H, int D, td_stream_t stream);
+int td_attn_i8_fp8pv(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                     const uint8_t* vt8, const float* v_scale, const int32_t* lut, int nsel, void* o, int out_dtype,
+                     int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
+                     int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale,
+                     td_stream_t stream);
+
 /* ---- a12 / a9 / a4: 16-bit QK attention (SLA Triton arithmetic; dense cross-attention) ----
  * q [H, L, 128], k [H, Lk, 128] dtype (bf16|f16); vt [H, ceil(Lk/64), 128, 64] same dtype;
  * P is rounded to dtype before P@V (SLA/kernel.py:68). lut as above. */

@@ -352,3 +352,72 @@ def test_block_map_vs_reference_golden(K):
     smap = torch.zeros(g["sparse_map"].shape[1:], dtype=torch.int8).scatter_(-1, lut, 1)
     agree = ((smap > 0) & (g["sparse_map"][0] > 0)).sum().item() / (g["sparse_map"][0] > 0).sum().item()
     assert agree >= 0.99, agree
+
+
+# ---------------------------------------------------------------- a13, FP8-PV variant (the reference's sm89+ branch)
+_POS2KEY8 = torch.tensor([32 * ((p >> 4) & 1) + ((p & 15) & 3) + 8 * ((p & 15) >> 2) + 4 * (p >> 5) for p in range(64)])
+
+
+@pytest.mark.parametrize("H,L", [(2, 64), (3, 700), (12, 1000)])
+def test_v_fp8_tiles_bit_exact(K, H, L):
+    """td_v_fp8_tiles == the oracle's v_fp8_quant (per-channel scale = max|v| / 2.25, e4m3 RNE of v / scale): scales and
+    every e4m3 byte, in the position order of the fp8 PV MFMA's B operand; tail keys zero."""
+    _, _, v = qkv(H, L, 31)
+    vt = torch.empty(1, H, 128, (L + 127) // 128 * 128, dtype=v.dtype)
+    S.transpose_pad_permute(v, vt)
+    q_ref, s_ref = S.v_fp8_quant(vt, L, 2.25)                       # [1,H,128,Lpad] e4m3, [1,H,128]
+    vl = v[0].transpose(0, 1).contiguous().to(DEV)                  # [L, H, D]
+    vt8, vs = K.v_fp8_tiles(vl, 128, H * 128, L, H, 128, 2.25)
+    assert torch.equal(vs.cpu(), s_ref[0]), "v scales must be bit-exact"
+    kb = (L + 63) // 64
+    ref = torch.zeros(H, 128, kb * 64, dtype=torch.uint8)
+    ref[:, :, :L] = q_ref[0].view(torch.uint8)[:, :, :L]
+    ref = ref.view(H, 128, kb, 64)[:, :, :, _POS2KEY8].permute(0, 2, 1, 3).contiguous()   # [H, kb, 128, 64 positions]
+    got = vt8.cpu()
+    # -0 and +0 are the same value (tail keys, exact zeros)
+    same = (got == ref) | (((got & 0x7f) == 0) & ((ref & 0x7f) == 0))
+    assert same.all(), f"{(~same).sum().item()} e4m3 bytes differ"
+
+
+@pytest.mark.parametrize("H,L,ratio", [(2, 1000, 0.3), (3, 777, 0.2), (2, 256, 1.0)])
+def test_attn_i8_fp8pv_vs_oracle(K, H, L, ratio):
+    """INT8-QK / FP8-PV attention against the oracle's statement of SpargeAttn's sm89 kernels (sage_sparse_attn_fp8):
+    same V8 / v_scale, P rounded to e4m3 against the kernel's lazy running max instead of the exact one.  e4m3 keeps 3
+    mantissa bits of every probability, so any two correct implementations that round against different reference
+    points differ by that noise (measured: both sit ~3e-2 from the FP16-PV result and ~2e-2 from each other); the
+    variant's distance to the FP16-PV result must be what the oracle's is."""
+    q, k, v, q_i8, q_s, k_i8, k_s = _sage_inputs(H, L, 5)
+    _, lut, topk = S.get_block_map(q, k, ratio, 128, 64)
+    vt = torch.empty(1, H, 128, (L + 127) // 128 * 128, dtype=v.dtype)
+    S.transpose_pad_permute(v, vt)
+    v8, vs = S.v_fp8_quant(vt, L, 2.25)
+    ref = S.sage_sparse_attn_fp8(q_i8, q_s, k_i8, k_s, v8, vs, lut, out_dtype=torch.bfloat16)[0]
+    ref16 = S.sage_sparse_attn(q_i8, q_s, k_i8, k_s, v, lut, out_dtype=torch.bfloat16)[0]
+    vl = v[0].transpose(0, 1).contiguous().to(DEV)
+    vt8, vsc = K.v_fp8_tiles(vl, 128, H * 128, L, H, 128, 2.25)
+    out = torch.empty(H, L, 128, dtype=torch.bfloat16, device=DEV)
+    dense = ratio >= 1.0
+    K.attn_i8(q_i8[0].to(DEV), q_s[0].to(DEV), k_i8[0].to(DEV), k_s[0].to(DEV), vt8,
+              None if dense else lut[0].int().to(DEV), out, L * 128, 128, v_scale=vsc)
+    assert cosine(out, ref) > 0.9995
+    assert rel_l2(out, ref) < 3.5e-2, rel_l2(out, ref)
+    gap_oracle, gap_hip = rel_l2(ref, ref16), rel_l2(out, ref16)
+    assert gap_hip < gap_oracle * 1.2 + 3e-3, (gap_hip, gap_oracle)
+
+
+def test_sagesla_fp8pv_module_vs_reference_golden(K):
+    """SageSparseLinearAttention with pv_dtype = 'fp8' against the output of the reference module's sm89 branch
+    (tests/golden/sla_tiny.pt: ref_sagesla_fp8pv, produced by SLA/core.py:217-239 with its leaves patched)."""
+    from turbodiffusion_amd.sla import SageSparseLinearAttention
+    g = _gold()
+    m = SageSparseLinearAttention(128, g["topk"])
+    m.pv_dtype = "fp8"
+    with torch.no_grad():
+        m.proj_l.weight.copy_(g["proj_w"])
+        m.proj_l.bias.copy_(g["proj_b"])
+    out = m.to(DEV)(g["q"].to(DEV), g["k"].to(DEV), g["v"].to(DEV))
+    assert cosine(out, g["ref_sagesla_fp8pv"]) > 0.9995
+    assert rel_l2(out, g["ref_sagesla_fp8pv"]) < 3.5e-2
+    # as far from the FP16-PV branch's output as the reference's own FP8 branch is
+    gap_ref = rel_l2(g["ref_sagesla_fp8pv"], g["ref_sagesla_f16pv"])
+    assert rel_l2(out, g["ref_sagesla_f16pv"]) < gap_ref * 1.2 + 3e-3

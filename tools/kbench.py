@@ -146,6 +146,12 @@ def main():
         fl = 4.0 * qb * 128 * topk * 64 * D * H
         by = H * qb * (128 * D + topk * 64 * D * 3 + 128 * D * 2)
         rep(f"attn_i8 sparse topk={topk}/{kb}", t, bytes_=by, flops=fl, peak_f=(I8 + F16) / 2 * 0 + 1.0 / (0.5 / I8 + 0.5 / F16))
+        t = timeit(lambda: K.v_fp8_tiles(qkv[:, 2 * dim:], D, 3 * dim, L, H, D), args.iters)
+        rep("v_fp8_tiles (amax + e4m3 tiles)", t, bytes_=5 * L * dim)
+        vt8, vsc = K.v_fp8_tiles(qkv[:, 2 * dim:], D, 3 * dim, L, H, D)
+        t = timeit(lambda: K.attn_i8(q8, qs, k8, ks, vt8, lut, out, D, H * D, v_scale=vsc), args.iters)
+        rep(f"attn_i8 FP8-PV sparse topk={topk}/{kb}", t, bytes_=H * qb * (128 * D + topk * 64 * D * 2 + 128 * D * 2), flops=fl,
+            peak_f=I8)
         vtb = K.v_transpose(qkv[:, 2 * dim:], D, 3 * dim, L, H, D, torch.bfloat16)
         t = timeit(lambda: K.attn_16(q, k, vtb, lut, out, D, H * D), args.iters)
         by16 = H * qb * (128 * D * 2 + topk * 64 * D * 4 + 128 * D * 2)

@@ -44,6 +44,9 @@ SIGNATURES = {
     "td_attn_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
     "td_attn_16": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
     "td_attn_i8_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "td_v_fp8_tiles": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp],
+    "td_attn_i8_fp8pv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp,
+                         _vp, _vp],
     "td_rms_stats": [_vp, _i64, _i32, _vp, _f32, _i64, _i64, _vp],
     "td_attn_16_qnorm": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32,
                          _vp, _vp, _vp, _vp],

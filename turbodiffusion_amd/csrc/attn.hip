@@ -48,6 +48,7 @@ struct AttnParams {
   int64_t q_stride_h, q_stride_l;   // bytes; 0 = the packed [H, L, 128] layout
   const float* q_rstd;              // [L] 1/rms of the row over the FULL model dim (td_rms_stats), or null
   const float* q_w;                 // [H*128] RMSNorm weight
+  const float* v_scale;             // FP8-PV instantiation: per-(h, d) channel scale of the e4m3 V tiles [H, 128]
 };
 
 template <bool QK_I8> struct KTile {
@@ -61,6 +62,18 @@ template <bool QK_I8> struct KTile {
 };
 typedef __attribute__((address_space(3))) void* lptr_a;
 #define VT_BYTES (128 * 128)
+#define VT8_BYTES (128 * 64)   // FP8-PV: e4m3 V^T tile [128 d][64 positions]
+// FP8-PV: row = 64 bytes = 4 slots; (row >> 2) & 3 spreads the 16-lane groups of ds_read_b128 over all banks
+__device__ __forceinline__ uint32_t vt8_off(uint32_t row, uint32_t slot) {
+  return row * 64u + ((slot ^ ((row >> 2) & 3u)) << 4);
+}
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+// FP8-PV: P is scaled by PV8_C before the e4m3 conversion (the row sum carries the same factor, so it cancels); with the
+// lazy running max P <= 2^PV8_TAU = 2, and PV8_C * 2 = 447 stays inside e4m3 (max 448).  The reference's kernels scale
+// by 448 against the exact running max (oracle/sla_ref.py: sage_sparse_attn_fp8) — the same representation up to where
+// in e4m3's uniform relative grid a value lands.
+#define PV8_TAU 1.0f
+#define PV8_LOG2C 7.8041310f   // log2(447 / 2)
 #define A_MAGIC_I 0x4B400000
 #define A_MAGIC_F 12582912.0f
 __device__ __forceinline__ uint32_t vt_off(uint32_t row, uint32_t slot) {
@@ -82,7 +95,7 @@ template <> struct Mma16<TD_BF16> {
 };
 
 // QK_I8: int8 QK; PDT: dtype of P / V^T (and of q,k when !QK_I8); ODT: output dtype
-template <bool QK_I8, int PDT, int ODT>
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false>
 // lut_all / ks_all / qs_all repeat p.lut / p.k_s / p.q_s as __restrict__ kernel arguments: only then are the per-iteration
 // LUT entry and K scale SCALAR loads (s_load, lgkmcnt).  As vector loads they drag an s_waitcnt vmcnt(0) into the loop,
 // which waits for every K/V tile in flight and undoes the fetch-ahead.
@@ -91,7 +104,9 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
                                                       const float* __restrict__ qs_all) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef KTile<QK_I8> KT;
-  constexpr int BUF = KT::BYTES + VT_BYTES;
+  constexpr int VTB = PV8 ? VT8_BYTES : VT_BYTES;
+  constexpr int BUF = KT::BYTES + VTB;
+  static_assert(!PV8 || QK_I8, "FP8 PV is the SageAttention variant");
   typedef typename Mma16<PDT>::frag frag16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -145,13 +160,14 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
   // image of a DMA piece is lane-linear, so the bank swizzle of the read side is applied to the global address.
   constexpr int NBUF = 2;
   constexpr int KPIECES = KT::BYTES / 1024 / 4;  // per wave: 2 (int8 K) or 4 (16-bit K); V^T: 4
-  constexpr int NPIECES = KPIECES + 4;
+  constexpr int VPIECES = PV8 ? 2 : 4;
+  constexpr int NPIECES = KPIECES + VPIECES;
   constexpr uint32_t K_ROWB = QK_I8 ? 128u : 256u;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((const char*)p.k + (int64_t)h * p.k_rows_alloc * KT::ROWB), 0, 0x7fffffff, 0x00020000);
   const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((const char*)p.vt + (int64_t)h * p.kb_alloc * VT_BYTES), 0, 0x7fffffff, 0x00020000);
+      (void*)((const char*)p.vt + (int64_t)h * p.kb_alloc * VTB), 0, 0x7fffffff, 0x00020000);
   int krow[KPIECES];       // row of the K tile this lane fetches, per piece
   uint32_t kchunk[KPIECES], voffs[4];
 #pragma unroll
@@ -162,8 +178,13 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int row = 8 * (wave_u + 4 * t) + (lane >> 3);
-    voffs[t] = (uint32_t)(row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    if constexpr (PV8) {   // piece = 16 rows x 64 B; LDS position (row, p) holds source slot p ^ ((row >> 2) & 3)
+      const int row = 16 * (wave_u + 4 * t) + (lane >> 2);
+      voffs[t] = (uint32_t)(row * 64 + (((lane & 3) ^ ((row >> 2) & 3)) * 16));
+    } else {
+      const int row = 8 * (wave_u + 4 * t) + (lane >> 3);
+      voffs[t] = (uint32_t)(row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+    }
   }
 #define TISSUE(kb_, buf_)                                                                              \
   {                                                                                                    \
@@ -175,9 +196,9 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lptr_a)(base_ + (wave_u + 4 * t) * 1024), 16, \
                                                vo_, 0, 0, 0);                                          \
     }                                                                                                  \
-    _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                      \
+    _Pragma("unroll") for (int t = 0; t < VPIECES; ++t)                                                \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lptr_a)(base_ + KT::BYTES + (wave_u + 4 * t) * 1024), 16, \
-                                               voffs[t], (kb_) * VT_BYTES, 0, 0);                      \
+                                               voffs[t], (kb_) * VTB, 0, 0);                           \
   }
 #define TWAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");
 
@@ -273,10 +294,10 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
     // lazy running max: the reference point of the exponentials only moves when the row max grows by more than 2^8
     // — softmax is invariant to it as long as numerator and denominator use the same one; P stays <= 256 (fp16-safe)
     // and the 64 accumulator rescales per lane are skipped for almost every K block
-    const float m_new = (mx > m_run + p.tau) ? mx : m_run;
+    const float m_new = (mx > m_run + (PV8 ? fminf(p.tau, PV8_TAU) : p.tau)) ? mx : m_run;
     const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first block: exp2(-inf) = 0
     m_run = m_new;
-    const float cc = fmaf(-OFFS, mult, -m_new);
+    const float cc = fmaf(-OFFS, mult, -m_new) + (PV8 ? PV8_LOG2C : 0.0f);
     float psum = 0.f;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
@@ -292,6 +313,25 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[c][r] *= alpha;
     }
+    if constexpr (PV8) {
+      // ---- P^T as ONE e4m3 B operand: byte j = 16g + r of this half-wave's 32 key positions ----
+      v8i_t p8;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const int g = w >> 2, r = 4 * (w & 3);
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(s[g][r], s[g][r + 1], 0, false);
+        p8[w] = __builtin_amdgcn_cvt_pk_fp8_f32(s[g][r + 2], s[g][r + 3], pk, true);
+      }
+      // ---- O^T += V8^T . P8^T : one 32x32x64 MFMA per 32-row d block ----
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const v4i a0 = *reinterpret_cast<const v4i*>(vtile + vt8_off(32 * c + li, 2 * hi));
+        const v4i a1 = *reinterpret_cast<const v4i*>(vtile + vt8_off(32 * c + li, 2 * hi + 1));
+        v8i_t a;
+        a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+        oacc[c] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, p8, oacc[c], 0, 0, 0, 0, 0, 0);
+      }
+    } else {
     // ---- P^T fragments (B operand): step ks = 2g+t uses registers 8t..8t+7 of group g ----
     uint4 pf[4];
 #pragma unroll
@@ -308,6 +348,7 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
         frag16 pv = *reinterpret_cast<const frag16*>(&pf[ks]);
         oacc[c] = Mma16<PDT>::mma(vf, pv, oacc[c]);
       }
+    }
     }
     // tile it+1 must have landed (this wave's pieces; the barrier makes it everyone's); tile it+2 may stay in flight
     if (NBUF == 3 && it + 2 < nsel) {
@@ -339,8 +380,13 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
     for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
-        uint32_t w0 = pack2<ODT>(oacc[c][4 * g4] * inv, oacc[c][4 * g4 + 1] * inv);      // o_s in the output dtype
-        uint32_t w1 = pack2<ODT>(oacc[c][4 * g4 + 2] * inv, oacc[c][4 * g4 + 3] * inv);
+        float e0 = oacc[c][4 * g4] * inv, e1 = oacc[c][4 * g4 + 1] * inv, e2 = oacc[c][4 * g4 + 2] * inv, e3 = oacc[c][4 * g4 + 3] * inv;
+        if constexpr (PV8) {   // the V channel scale, fused here (…fuse_v_scale… kernels, SLA/core.py:227-239)
+          const float4 vs = *reinterpret_cast<const float4*>(p.v_scale + h * 128 + 32 * c + 8 * g4 + 4 * hi);
+          e0 *= vs.x; e1 *= vs.y; e2 *= vs.z; e3 *= vs.w;
+        }
+        uint32_t w0 = pack2<ODT>(e0, e1);      // o_s in the output dtype
+        uint32_t w1 = pack2<ODT>(e2, e3);
         if (p.add_t) {                                                                    // o = o_s + o_l (16-bit add)
           float a0, a1, a2, a3, b0, b1, b2, b3;
           unpack2<ODT>(w0, a0, a1); unpack2<ODT>(w1, a2, a3);
@@ -408,10 +454,12 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
   }
 }
 
-template <bool QK_I8, int PDT, int ODT>
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
-  auto kern = attn_kernel<QK_I8, PDT, ODT>;
-  constexpr int lds = 2 * (KTile<QK_I8>::BYTES + VT_BYTES);
+  auto kern = attn_kernel<QK_I8, PDT, ODT, PV8>;
+  // two tile buffers, and at least the 128 x 272-byte staging area of the epilogue's transpose
+  constexpr int lds_tiles = 2 * (KTile<QK_I8>::BYTES + (PV8 ? VT8_BYTES : VT_BYTES));
+  constexpr int lds = lds_tiles > 128 * 272 ? lds_tiles : 128 * 272;
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, attr_mask);
   const unsigned nwg = (unsigned)p.H * (unsigned)p.Qb;
@@ -434,8 +482,8 @@ static int attn_stride_check(const char* who, int64_t o_stride_h, int64_t o_stri
   return TD_OK;
 }
 
-extern "C" int td_attn_i8_ex(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
-                             const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
+static int attn_i8_impl(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                             const void* vt, const float* v_scale, const int32_t* lut, int nsel, void* o, int out_dtype,
                              int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
                              int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out,
                              float* q_scale, td_stream_t stream) {
@@ -450,7 +498,7 @@ extern "C" int td_attn_i8_ex(const int8_t* q_i8, const float* q_s, const int8_t*
   p.q = q_i8; p.q_s = q_s; p.k = k_i8; p.k_s = k_s; p.vt = (const uint16_t*)vt; p.lut = lut;
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
-  p.q_stride_h = 0; p.q_stride_l = 0; p.q_rstd = nullptr; p.q_w = nullptr;
+  p.q_stride_h = 0; p.q_stride_l = 0; p.q_rstd = nullptr; p.q_w = nullptr; p.v_scale = v_scale;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
   if (Lk_alloc == 0) Lk_alloc = Lk;
@@ -458,8 +506,33 @@ extern "C" int td_attn_i8_ex(const int8_t* q_i8, const float* q_s, const int8_t*
   p.k_rows_alloc = Lk_alloc; p.kb_alloc = (int)td_cdiv(Lk_alloc, 64);
   p.tau = td_tuning(TD_TUNE_ATTN_TAU) < 0 ? 0.0f : (td_tuning(TD_TUNE_ATTN_TAU) == 0 ? 8.0f : (float)td_tuning(TD_TUNE_ATTN_TAU));
   hipStream_t st = (hipStream_t)stream;
+  if (v_scale) {
+    if (out_dtype == TD_BF16) return launch_attn<true, TD_F16, TD_BF16, true>(p, st);
+    return launch_attn<true, TD_F16, TD_F16, true>(p, st);
+  }
   if (out_dtype == TD_BF16) return launch_attn<true, TD_F16, TD_BF16>(p, st);
   return launch_attn<true, TD_F16, TD_F16>(p, st);
+}
+
+extern "C" int td_attn_i8_ex(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                             const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
+                             int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+                             int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out,
+                             float* q_scale, td_stream_t stream) {
+  return attn_i8_impl(q_i8, q_s, k_i8, k_s, vt, nullptr, lut, nsel, o, out_dtype, o_stride_h, o_stride_l, sm_scale, L, Lk,
+                      Lk_alloc, H, add_t, q_out, q_scale, stream);
+}
+
+// a13, FP8-PV variant (the reference's sm89+ branch, SLA/core.py:217-239): the same kernel with P and V in OCP e4m3 and
+// the PV contraction on v_mfma_f32_32x32x64_f8f6f4; vt8 / v_scale from td_v_fp8_tiles.
+extern "C" int td_attn_i8_fp8pv(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                                const uint8_t* vt8, const float* v_scale, const int32_t* lut, int nsel, void* o,
+                                int out_dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+                                int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out,
+                                float* q_scale, td_stream_t stream) {
+  TD_REQUIRE(v_scale, TD_ERR_INVALID, "td_attn_i8_fp8pv: null v_scale");
+  return attn_i8_impl(q_i8, q_s, k_i8, k_s, vt8, v_scale, lut, nsel, o, out_dtype, o_stride_h, o_stride_l, sm_scale, L, Lk,
+                      Lk_alloc, H, add_t, q_out, q_scale, stream);
 }
 
 extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
@@ -483,7 +556,7 @@ static int attn_16_impl(const char* who, const void* q, int64_t q_stride_h, int6
   p.q = q; p.q_s = nullptr; p.k = k; p.k_s = nullptr; p.vt = (const uint16_t*)vt; p.lut = lut;
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
-  p.q_stride_h = q_stride_h; p.q_stride_l = q_stride_l; p.q_rstd = q_rstd; p.q_w = q_w;
+  p.q_stride_h = q_stride_h; p.q_stride_l = q_stride_l; p.q_rstd = q_rstd; p.q_w = q_w; p.v_scale = nullptr;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
   if (Lk_alloc == 0) Lk_alloc = Lk;

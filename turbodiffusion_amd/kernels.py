@@ -303,28 +303,49 @@ def _attn_quant_outputs(L_, H, device):
 
 
 def attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, add_t=None,
-            quant_out=False):
+            quant_out=False, v_scale=None):
     """SageAttention INT8-QK/FP16-PV. q_i8 [H,L,128], k_i8 [H,Lk,128], vt f16 tiles; lut or None (dense).
     out: preallocated 16-bit tensor addressed as out_ptr + h*o_stride_h + l*o_stride_l + d.
     add_t: o_l from sla_linear_out_t (the output becomes o_s + o_l).  quant_out: instead of ``out`` return the
     [L, H*128] output block-quantised for the o projection: (int8 [L, H*128], f32 [ceil(L/128), H]); ``out`` then
     only supplies the 16-bit dtype (a tensor or a torch.dtype)."""
-    require_gpu(q_i8, k_i8, vt, lut, add_t)
-    _f32c(q_s, "q_s"), _f32c(k_s, "k_s")
+    require_gpu(q_i8, k_i8, vt, lut, add_t, v_scale)
+    _f32c(q_s, "q_s"), _f32c(k_s, "k_s"), _f32c(v_scale, "v_scale")
     H, L_, D = q_i8.shape
     lk_alloc = k_i8.shape[1]
     Lk = lk_alloc if lk is None else lk  # lk < allocation: rank-padded gathered layout
-    assert D == 128 and vt.dtype == torch.float16 and vt.shape[1] * 64 >= lk_alloc
+    fp8 = v_scale is not None   # vt: e4m3 tiles of v_fp8_tiles (uint8) + per-channel scale; else fp16 tiles of v_transpose
+    assert D == 128 and vt.dtype == (torch.uint8 if fp8 else torch.float16) and vt.shape[1] * 64 >= lk_alloc
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]
     odt = out if isinstance(out, torch.dtype) else out.dtype
     oq, os_ = _attn_quant_outputs(L_, H, q_i8.device) if quant_out else (None, None)
+    if fp8:
+        _timed("td_attn_i8", (H, L_, Lk, nsel), lambda: call(
+            "td_attn_i8_fp8pv", ptr(q_i8), ptr(q_s), ptr(k_i8), ptr(k_s), ptr(vt), ptr(v_scale), ptr(lut), nsel,
+            None if quant_out else ptr(out), dt_code(odt), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc, H,
+            ptr(add_t), ptr(oq), ptr(os_), stream_ptr()))
+        return (oq, os_) if quant_out else out
     _timed("td_attn_i8", (H, L_, Lk, nsel), lambda: call(
         "td_attn_i8_ex", ptr(q_i8), ptr(q_s), ptr(k_i8), ptr(k_s), ptr(vt), ptr(lut), nsel,
         None if quant_out else ptr(out), dt_code(odt), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc, H,
         ptr(add_t), ptr(oq), ptr(os_), stream_ptr()))
     return (oq, os_) if quant_out else out
+
+
+def v_fp8_tiles(v, stride_h, stride_l, L_, H, D, scale_max=2.25):
+    """V (element (h,l,d) at data_ptr + h*stride_h + l*stride_l + d) -> (vt8 e4m3 tiles [H, ceil(L/64), 128, 64] as uint8,
+    v_scale f32 [H, 128] = max_l |v| / scale_max) for attn_i8(..., v_scale=...) — the FP8-PV SageAttention variant
+    (SLA/core.py:217-224)."""
+    require_gpu(v)
+    kb = cdiv(L_, 64)
+    vt8 = torch.empty((H, kb, D, 64), dtype=torch.uint8, device=v.device)
+    vs = torch.empty((H, D), dtype=torch.float32, device=v.device)
+    ws = torch.empty((H, 64, D), dtype=torch.float32, device=v.device)
+    call("td_v_fp8_tiles", ptr(v), dt_code(v.dtype), stride_h, stride_l, ptr(vt8), ptr(vs), ptr(ws), float(scale_max), L_, H, D,
+         stream_ptr())
+    return vt8, vs
 
 
 def attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, add_t=None, quant_out=False):

@@ -41,7 +41,7 @@ def _check_geometry(head_dim, blkq, blkk):
 
 
 def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
-                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None):
+                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None, pv="fp16"):
     """Core of both modules on head-major tensors.
 
     q, k: [H, L, D] 16-bit (after RoPE); vt_src: tensor holding V with element (h,l,d) at
@@ -50,6 +50,8 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     km: the per-head sequence mean of k [H, D] when the caller already has it (K.qk_norm_rope_pair), else computed here.
     quant_out: return the [L, H*D] result block-quantised for the o projection ((int8, scales) in place of ``out``,
     which then only supplies the dtype).
+    pv: "fp16" (the reference's sm80 branch, SLA/core.py:211-216) or "fp8" (its sm89+ branch, :217-239: V as per-channel
+    scaled e4m3, P rounded to e4m3, P.V on the fp8 MFMA) — Sage only.
 
     The linear branch (needs only q, k, v) runs FIRST and leaves o_l in a lane-private layout; the attention kernel adds
     it in its epilogue (o = o_s + o_l, the 16-bit add of SLA/core.py:253) — no read-modify-write pass over the output.
@@ -82,7 +84,12 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
         pk, k_i8, k_s = K.sage_quant_pool(k, km, blkk, want_pool=not dense)
         if not dense:
             lut = K.sla_topk(pq, pk, topk)
-        res = K.attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out)
+        if pv == "fp8":
+            vt8, v_scale = K.v_fp8_tiles(vt_src, v_strides[0], v_strides[1], L_, H, D, 2.25)
+            res = K.attn_i8(q_i8, q_s, k_i8, k_s, vt8, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out,
+                            v_scale=v_scale)
+        else:
+            res = K.attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out)
     else:
         if not dense:
             pq, _, _ = K.sage_quant_pool(q, None, blkq, want_quant=False)
@@ -108,6 +115,8 @@ class _SLABase(nn.Module):
             nn.init.zeros_(self.proj_l.weight)
             nn.init.zeros_(self.proj_l.bias)
 
+    pv_dtype = "fp16"   # SageSparseLinearAttention: "fp8" selects the reference's sm89+ FP8-PV branch (SLA/core.py:217-239)
+
     def _forward(self, q, k, v, return_sparsity, sage, blkq, blkk):
         dtype = q.dtype
         B, L_, H, D = q.shape
@@ -120,7 +129,7 @@ class _SLABase(nn.Module):
             out = torch.empty((L_, H, D), dtype=self.dtype, device=q.device)
             _, real, kb_n = sparse_linear_attention_hld(
                 qb, kb_, vb, self.proj_l.weight.float().contiguous(), self.proj_l.bias.float().contiguous(),
-                self.topk, sage, out, D, H * D, (D, H * D), blkq, blkk)
+                self.topk, sage, out, D, H * D, (D, H * D), blkq, blkk, pv=self.pv_dtype if sage else "fp16")
             outs.append(out)
         o = torch.stack(outs, dim=0).to(dtype)  # [B, L, H, D]
         if return_sparsity:

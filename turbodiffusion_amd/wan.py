@@ -148,6 +148,7 @@ class WanModel(nn.Module):
         self.fuse_cross_q_norm = True
         self.batch_text_kv = True
         self._ckv_all = None
+        self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
         self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
         self._text_states = {}     # data_ptr -> (key, source tensor, context, [per batch entry: [per block: (k, vt)]])
         self._weights_epoch = 0   # bumped whenever derived weight copies are dropped (GraphedModel re-captures on a change)
@@ -353,7 +354,8 @@ class WanModel(nn.Module):
         # W8A8: the attention kernel's epilogue hands the o projection its INT8 activation directly
         res, _, _ = sparse_linear_attention_hld(q, k, qkv[:, 2 * dim:], f.get("proj_w") if not dense else None,
                                                 f.get("proj_b") if not dense else None, self.sla_topk, sage, out, D, dim,
-                                                (D, 3 * dim), dense=dense, quant_out=quant_out)
+                                                (D, 3 * dim), dense=dense, quant_out=quant_out,
+                                                pv=self.sage_pv if sage else "fp16")
         return res
 
     def _text_kvt(self, i, blk, context, text_kv=None):
