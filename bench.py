@@ -159,6 +159,11 @@ def main():
     ap.add_argument("--two-experts", action="store_true", help="Wan2.2-A14B as the reference runs it (wan2.2_i2v_infer.py:"
                     "186-197): high- and low-noise experts, switched at t < 0.9 — BOTH resident in HBM (2 x 14 GB int8), "
                     "the switch inside the timed region; sigma_max = 200")
+    ap.add_argument("--sage-pv", default="fp16", choices=["fp16", "fp8"], help="SageAttention P.V arithmetic: fp16 (the "
+                    "reference's sm80 branch; north-star default) or fp8 (its sm89+ branch, SLA/core.py:217-239: e4m3 P and V, "
+                    "fp8 MFMA)")
+    ap.add_argument("--gemm-fast", type=int, default=0, choices=[0, 2, 4, 8], help="W8A8 GEMM one-VALU dequant, re-centred "
+                    "every G K blocks (bounded difference to the exact arithmetic, csrc/gemm_w8a8_fi.hip); 0 = exact (default)")
     ap.add_argument("--sigma-max", type=float, default=0.0, help="0: 80 for T2V, 200 for I2V (the scripts' defaults)")
     ap.add_argument("--layers", type=int, default=0, help="debug: override num_layers (INVALID as a bench number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -238,6 +243,12 @@ def main():
 
     if args.gemm_variant:
         K.set_tuning(K.TUNE_GEMM_VARIANT, args.gemm_variant)
+    if args.gemm_fast:
+        K.set_tuning(K.TUNE_GEMM_VARIANT, args.gemm_variant or 5)   # the 32x32x32-MFMA kernel carries the fast schedule
+        K.set_tuning(K.TUNE_GEMM_FAST, args.gemm_fast)
+        K.set_tuning(4, 3)
+    for m_ in filter(None, (net, net_low)):
+        m_.sage_pv = args.sage_pv
     for kv in args.tune:
         key, val = kv.split("=")
         K.set_tuning(int(key), int(val))
@@ -403,7 +414,8 @@ def main():
             "vs_baseline": (value * PUBLISHED_S[(args.model, args.res)]) if (
                 args.workload == "turbo" and (args.model, args.res) in PUBLISHED_S and not args.layers
                 and args.num_steps == 4) else None,
-            "dtype": "int8 (W8A8 linears, QK^T) + fp16 PV + bf16 activations" if wl["quant_linear"] else "bf16 (+int8 QK^T)",
+            "dtype": (f"int8 (W8A8 linears{', one-VALU dequant G=%d' % args.gemm_fast if args.gemm_fast else ''}, QK^T) + "
+                      f"{args.sage_pv} PV + bf16 activations") if wl["quant_linear"] else f"bf16 (+int8 QK^T, {args.sage_pv} PV)",
             "data": "synthetic (seeded N(0,1) latents/text embedding, random-init weights of the named architecture)",
             "config": {"workload": wl["desc"].replace("Wan2.1-T2V-1.3B 480p", f"{args.model} {args.res}").replace(
                            "TurboWan2.1-T2V-1.3B-480P", f"Turbo{args.model}-{args.res.upper()}"), "model": args.model, "resolution": args.res, "tokens": L_tok,

@@ -3,12 +3,12 @@
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
 T=${1:-cfg}
 : > gpurun_out/other_configs_$T.jsonl
-for a in "--workload c2" "--workload c3" "--model Wan2.1-14B --res 720p" "--model Wan2.2-A14B --res 720p" "--model Wan2.1-14B --res 480p"; do
+for a in "--workload c2" "--workload c3" "--model Wan2.1-14B --res 720p" "--model Wan2.2-A14B --res 720p --two-experts" "--model Wan2.1-14B --res 480p" "--sage-pv fp8" "--gemm-fast 4" "--gemm-fast 4 --sage-pv fp8"; do
   timeout 600 python bench.py $a --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/cfg_tmp.log 2>&1
   grep '^{' gpurun_out/cfg_tmp.log >> gpurun_out/other_configs_$T.jsonl || { echo "FAILED: $a"; tail -5 gpurun_out/cfg_tmp.log; }
 done
 python - <<PY
 import json
 for l in open("gpurun_out/other_configs_$T.jsonl"):
-    d=json.loads(l); print(d["config"]["workload"][:70], "|", d["config"]["model"], d["config"]["resolution"], "| ms/step", round(d["dit_step_ms"],1), "| videos/s", round(d["value"],4), "| vs_baseline", d["vs_baseline"])
+    d=json.loads(l); print(d["config"]["workload"][:70], "|", d["config"]["model"], d["config"]["resolution"], "|", d["dtype"][:60], "| ms/step", round(d["dit_step_ms"],1), "| videos/s", round(d["value"],4), "| vs_baseline", d["vs_baseline"])
 PY

@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--topk", type=float, default=0.1)
     ap.add_argument("--ablate", action="store_true")
     ap.add_argument("--dense", action="store_true", help="also time dense attention (slow)")
+    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle (the reference's arithmetic restated, "
+                    "oracle/) per operator on the host cores, on a bounded slice (SURVEY §8d iii)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
     dev = "cuda"
@@ -173,6 +175,41 @@ def main():
         if args.dense:
             t = timeit(lambda: K.attn_i8(q8, qs, k8, ks, vt, None, out, D, H * D), max(1, args.iters // 5), warm=1)
             rep("attn_i8 dense", t, flops=4.0 * L * L * dim, peak_f=1.0 / (0.5 / I8 + 0.5 / F16))
+    if args.cpu:
+        import time
+        from oracle import ops_ref as O, sla_ref as S
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        Mc = 4096                                   # bounded slice of the L = 32760 rows; per-row costs scale linearly
+
+        def cpu_time(fn, reps=2):
+            fn()
+            t0 = time.time()
+            for _ in range(reps):
+                fn()
+            return (time.time() - t0) / reps
+
+        xc = torch.randn(Mc, dim).bfloat16()
+        wc = (torch.randn(dim, dim) / math.sqrt(dim)).bfloat16()
+        xq_, xs_ = O.quant_block128(xc)
+        wq_, ws_ = O.quant_block128(wc)
+        rows = []
+        rows.append(("quant_block128 [M,dim]", cpu_time(lambda: O.quant_block128(xc)), 3.0 * Mc * dim, None))
+        rows.append(("gemm_w8a8 M x dim x dim", cpu_time(lambda: O.gemm_w8a8(xq_, xs_, wq_, ws_)), None, 2.0 * Mc * dim * dim))
+        rows.append(("layernorm_fast + modulate [M,dim]", cpu_time(lambda: O.modulate(O.layernorm_fast(xc, None, None, 1e-6), torch.zeros(1, 1, dim), torch.zeros(1, 1, dim))), 4.0 * Mc * dim, None))
+        rows.append(("rmsnorm_fast [M,dim]", cpu_time(lambda: O.rmsnorm_fast(xc, torch.ones(dim), 1e-6)), 4.0 * Mc * dim, None))
+        qc, kc, vc = [torch.randn(1, Mc, H, 128).bfloat16() for _ in range(3)]
+        wp_, bp_ = torch.randn(128, 128) * 0.05, torch.zeros(128)
+        rows.append((f"sagesla_forward L={Mc} H={H} topk=0.1", cpu_time(lambda: S.sagesla_forward(qc, kc, vc, wp_, bp_, 0.1), 1), None, None))
+        rows.append((f"F.scaled_dot_product_attention (C1 dense, bf16) L={Mc} H={H}", cpu_time(lambda: torch.nn.functional.scaled_dot_product_attention(qc.transpose(1, 2), kc.transpose(1, 2), vc.transpose(1, 2)), 1), None, 4.0 * Mc * Mc * dim))
+        for name, t, by, fl in rows:
+            r = {"cpu_oracle": name, "rows": Mc, "cores": cores, "ms": round(t * 1e3, 2)}
+            if by:
+                r["GBps"] = round(by / t / 1e9, 2)
+            if fl:
+                r["GFLOPs"] = round(fl / t / 1e9, 1)
+            print(json.dumps(r), flush=True)
+            res.append(r)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/kbench.json", "w") as f:
         json.dump(res, f, indent=1)

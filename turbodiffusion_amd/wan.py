@@ -420,11 +420,11 @@ class WanModel(nn.Module):
         q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
         return K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
 
-    def _block(self, i, blk, x, e0_B_6_D, cos, sin, context, tkv=None, kvts=None):
-        """x: [B, L_loc, dim] (updated in place); e0 fp32 [B, 6, dim]; context [B, Lc, dim]."""
+    def _block(self, i, blk, x, e_B_6_D, cos, sin, context, tkv=None, kvts=None):
+        """x: [B, L_loc, dim] (updated in place); e fp32 [B, 6, dim] = this block's modulation + e0 (wan2pt1.py:400,
+        formed for all blocks at once in forward); context [B, Lc, dim]."""
         B, L_loc, dim = x.shape
-        e = (blk.modulation.float() + e0_B_6_D)  # fp32 [B, 6, dim]  (wan2pt1.py:400)
-        ec = [e[:, j].contiguous() for j in range(6)]
+        ec = [e_B_6_D[:, j].contiguous() for j in range(6)]   # (views when B == 1: no copy kernels)
         x2 = x.view(B * L_loc, dim)
         dt = x.dtype
         # the norms emit the INT8 activation of their consumer directly (td_layernorm_quant == td_layernorm +
@@ -515,8 +515,14 @@ class WanModel(nn.Module):
                 # the cross-attention K|V projections of ALL blocks read the same 512 text tokens: one [Lc, nblk*2*dim] GEMM
                 # (2880 tiles) and one quantisation of the text instead of one 96-tile GEMM + quantisation per block
                 tkv = [self._text_kv_all(context[b]) for b in range(B)]
+        # (modulation + e0) of every block in ONE add instead of one tiny kernel per block (+ 6 slice copies each)
+        ver = sum(blk.modulation._version for blk in self.blocks)   # (trainable parameters: a stacked copy must notice updates)
+        mods = self._fused.get("mods")
+        if mods is None or mods[1] != ver:
+            mods = self._fused["mods"] = (torch.stack([blk.modulation.detach().float() for blk in self.blocks], 0), ver)
+        e_all = mods[0] + e0.unsqueeze(0)                    # fp32 [nblk, B, 6, dim]
         for i, blk in enumerate(self.blocks):
-            x = self._block(i, blk, x, e0, cos, sin, context, tkv, kvts)
+            x = self._block(i, blk, x, e_all[i], cos, sin, context, tkv, kvts)
         if return_tokens:
             return x if sp is None else sp.gather_tokens(x, L_)
         # head (wan2pt1.py:444-454): fp32 modulate of the (bf16) norm, fp32 Linear
