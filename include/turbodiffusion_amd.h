@@ -247,6 +247,24 @@ int td_attn_16_qnorm(const void* q_src, int64_t ld_q, const float* q_rstd, const
                      int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int64_t Lk_alloc, int H,
                      const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream);
 
+/* ---- sequence parallelism: the same attention / block-map kernels reading the K side STRAIGHT from the
+ * output of the per-layer all-gather, which is rank-major: K block j (64 keys) is block j % kb_per_rank of rank
+ * j / kb_per_rank.  k / k_s / vt / pk point at rank 0's part ([H, kb_per_rank*64, 128], [H, kb_per_rank],
+ * [H, kb_per_rank, 128, 64], [H, kb_per_rank, D]); the *_rank_stride arguments are the distances to the next rank's part
+ * (k, vt: bytes, multiples of 16; k_s: floats; pk: elements).  No re-layout of the gathered state is needed.
+ * (Replaces the role of the sequence all-to-alls around local attention, rcm/utils/a2a_cp.py:146-182.) */
+int td_attn_i8_sp(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s, const void* vt,
+                  const int32_t* lut, int nsel, void* o, int out_dtype, int64_t o_stride_h, int64_t o_stride_l,
+                  float sm_scale, int64_t L, int64_t Lk, int H, int kb_per_rank, int64_t k_rank_stride,
+                  int64_t ks_rank_stride, int64_t vt_rank_stride, const void* add_t, int8_t* q_out, float* q_scale,
+                  td_stream_t stream);
+int td_attn_16_sp(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o, int dtype,
+                  int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int H,
+                  int kb_per_rank, int64_t k_rank_stride, int64_t vt_rank_stride, const void* add_t, int8_t* q_out,
+                  float* q_scale, td_stream_t stream);
+int td_sla_topk_sp(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb, int Kb, int kb_per_rank,
+                   int64_t pk_rank_stride, int D, int topk, td_stream_t stream);
+
 #define TD_SLA_NCH 32 /* partial-sum chunks per head of td_sla_linear_kv* (workspace leading extent) */
 
 /* ---- a14: linear-attention branch (SLA/core.py:243-253, feature_map = softmax) ----

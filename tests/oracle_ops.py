@@ -155,3 +155,23 @@ def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l):
 
 def seq_mean(k):
     return S.seq_mean(k[None])[0, :, 0]
+
+
+# ---- rank-major gathered K side (the *_sp entry points): the CPU stand-in re-lays it out and calls the flat versions
+def _seq_major(t):  # [W, H, n, ...] -> [H, W*n, ...]
+    W = t.shape[0]
+    return t.permute(1, 0, 2, *range(3, t.dim())).reshape(t.shape[1], W * t.shape[2], *t.shape[3:]).contiguous()
+
+
+def sla_topk_sp(pq, pk_g, topk, kb):
+    return sla_topk(pq, _seq_major(pk_g), topk, kb=kb)
+
+
+def attn_i8_sp(q_i8, q_s, k_g, ks_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
+    return attn_i8(q_i8, q_s, _seq_major(k_g), _seq_major(ks_g), _seq_major(vt_g), lut, out, o_stride_h, o_stride_l,
+                   sm_scale=sm_scale, lk=lk, add_t=add_t)
+
+
+def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
+    return attn_16(q, _seq_major(k_g), _seq_major(vt_g), lut, out, o_stride_h, o_stride_l, sm_scale=sm_scale, lk=lk,
+                   add_t=add_t)

@@ -421,3 +421,67 @@ def test_sagesla_fp8pv_module_vs_reference_golden(K):
     # as far from the FP16-PV branch's output as the reference's own FP8 branch is
     gap_ref = rel_l2(g["ref_sagesla_fp8pv"], g["ref_sagesla_f16pv"])
     assert rel_l2(out, g["ref_sagesla_f16pv"]) < gap_ref * 1.2 + 3e-3
+
+
+# ---------------------------------------------------------------- sequence parallelism: rank-major gathered K side
+@pytest.mark.parametrize("sage", [True, False])
+def test_gathered_layout_kernels_are_bit_identical_to_flat(K, sage):
+    """td_attn_i8_sp / td_attn_16_sp / td_sla_topk_sp read K, K scales, V^T tiles and pooled K straight from a rank-major
+    all-gather output (3 ranks x 256 tokens, the last one short): same bits as the flat layout."""
+    H, L, W, per = 3, 700, 3, 256
+    kbp = per // 64
+    q, k, v, q_i8, q_s, k_i8, k_s = _sage_inputs(H, L, 7)
+    dt = torch.bfloat16
+    pdt = torch.float16 if sage else dt
+    qd, kd = q[0].to(DEV), k[0].to(DEV)
+    vt = K.v_transpose(v[0].contiguous().to(DEV), L * 128, 128, L, H, 128, pdt)          # [H, 11, 128, 64]
+    km = K.seq_mean(kd)
+    pq, q8, qs = K.sage_quant_pool(qd, None, 128)
+    pk, k8, ks = K.sage_quant_pool(kd, km, 64)
+    kb_tot = (L + 63) // 64
+    topk = 4
+    lut = K.sla_topk(pq, pk, topk)
+    out_flat = torch.empty(H, L, 128, dtype=dt, device=DEV)
+    if sage:
+        K.attn_i8(q8, qs, k8, ks, vt, lut, out_flat, L * 128, 128)
+    else:
+        K.attn_16(qd, kd, vt, lut, out_flat, L * 128, 128)
+    # build the "all-gather output": [W, bytes] with per-rank slots k | ks | vt | pk (256-byte aligned)
+    ksrc = k8 if sage else kd
+    esz = ksrc.element_size()
+    sizes = {"k": H * per * 128 * esz, "ks": H * kbp * 4, "vt": H * kbp * 128 * 64 * 2, "pk": H * kbp * 128 * 2}
+    offs, o = {}, 0
+    for n_, sz in sizes.items():
+        offs[n_] = o
+        o += (sz + 255) // 256 * 256
+    allb = torch.zeros(W, o, dtype=torch.uint8, device=DEV)
+
+    def slot(name, dtype, shape):
+        return allb[:, offs[name]:offs[name] + sizes[name]].view(dtype).view((W,) + shape)
+
+    kg, ksg = slot("k", ksrc.dtype, (H, per, 128)), slot("ks", torch.float32, (H, kbp))
+    vtg, pkg = slot("vt", pdt, (H, kbp, 128, 64)), slot("pk", dt, (H, kbp, 128))
+    for r in range(W):
+        t0, t1 = r * per, min(L, (r + 1) * per)
+        b0, b1 = r * kbp, min(kb_tot, (r + 1) * kbp)
+        kg[r, :, : t1 - t0] = ksrc[:, t0:t1]
+        ksg[r, :, : b1 - b0] = ks[:, b0:b1]
+        vtg[r, :, : b1 - b0] = vt[:, b0:b1]
+        pkg[r, :, : b1 - b0] = pk[:, b0:b1]
+    lut_g = K.sla_topk_sp(pq, pkg, topk, kb_tot)
+    assert torch.equal(lut_g, lut)
+    out_g = torch.empty_like(out_flat)
+    if sage:
+        K.attn_i8_sp(q8, qs, kg, ksg, vtg, lut, out_g, L * 128, 128, L)
+    else:
+        K.attn_16_sp(qd, kg, vtg, lut, out_g, L * 128, 128, L)
+    assert torch.equal(out_g, out_flat)
+    # dense (no LUT) as well: every block of every rank, incl. the short tail block of the last rank
+    d_flat, d_g = torch.empty_like(out_flat), torch.empty_like(out_flat)
+    if sage:
+        K.attn_i8(q8, qs, k8, ks, vt, None, d_flat, L * 128, 128)
+        K.attn_i8_sp(q8, qs, kg, ksg, vtg, None, d_g, L * 128, 128, L)
+    else:
+        K.attn_16(qd, kd, vt, None, d_flat, L * 128, 128)
+        K.attn_16_sp(qd, kg, vtg, None, d_g, L * 128, 128, L)
+    assert torch.equal(d_g, d_flat)

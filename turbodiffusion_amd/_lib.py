@@ -44,6 +44,11 @@ SIGNATURES = {
     "td_attn_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
     "td_attn_16": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
     "td_attn_i8_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "td_attn_i8_sp": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _i64,
+                      _vp, _vp, _vp, _vp],
+    "td_attn_16_sp": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _vp, _vp, _vp,
+                      _vp],
+    "td_sla_topk_sp": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp],
     "td_v_fp8_tiles": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp],
     "td_attn_i8_fp8pv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp,
                          _vp, _vp],

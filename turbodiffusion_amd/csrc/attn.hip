@@ -49,6 +49,12 @@ struct AttnParams {
   const float* q_rstd;              // [L] 1/rms of the row over the FULL model dim (td_rms_stats), or null
   const float* q_w;                 // [H*128] RMSNorm weight
   const float* v_scale;             // FP8-PV instantiation: per-(h, d) channel scale of the e4m3 V tiles [H, 128]
+  // sequence-parallel GATHERED layout (kbp > 0): the K side is the output of an all-gather, rank-major — K block kb lives
+  // on rank r = kb / kbp as that rank's block kb % kbp: K rows at k + r*k_rs + (h*kbp*64 + ...)*row bytes, scales at
+  // k_s + r*ks_rs + h*kbp + ..., V^T tiles at vt + r*v_rs + (h*kbp + ...)*tile bytes.  k_rows_alloc = kbp*64 and
+  // kb_alloc = kbp then describe ONE rank's part, so the per-head bases below need no change.
+  int kbp;
+  int64_t k_rs, v_rs, ks_rs;        // rank strides: bytes, bytes, floats
 };
 
 template <bool QK_I8> struct KTile {
@@ -189,16 +195,25 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
 #define TISSUE(kb_, buf_)                                                                              \
   {                                                                                                    \
     char* base_ = smem + (buf_) * BUF;                                                                 \
+    int wb_ = (kb_);                       /* block index within its rank's part (flat layout: the block id) */ \
+    uint32_t ksoff_ = 0u, vsoff_ = 0u;     /* rank offsets, through the instruction's scalar offset */ \
+    if (p.kbp > 0) {                                                                                   \
+      const int r_ = (kb_) / p.kbp;                                                                    \
+      wb_ = (kb_) - r_ * p.kbp;                                                                        \
+      ksoff_ = (uint32_t)(r_ * p.k_rs);                                                                \
+      vsoff_ = (uint32_t)(r_ * p.v_rs);                                                                \
+    }                                                                                                  \
+    const int64_t lastrow_ = p.Lk - 1 - (int64_t)(kb_) * 64;   /* rows of block kb_ past this one are past Lk */ \
     _Pragma("unroll") for (int t = 0; t < KPIECES; ++t) {                                              \
-      int64_t kr_ = (int64_t)(kb_) * 64 + krow[t];                                                     \
-      if (kr_ > p.Lk - 1) kr_ = p.Lk - 1;                                                              \
-      const uint32_t vo_ = (uint32_t)kr_ * K_ROWB + kchunk[t]; /* (a temporary: an expression here loses the host stub) */ \
+      int64_t kr_ = krow[t];                                                                           \
+      if (kr_ > lastrow_) kr_ = lastrow_;                                                              \
+      const uint32_t vo_ = (uint32_t)((int64_t)wb_ * 64 + kr_) * K_ROWB + kchunk[t]; /* (a temporary: an expression here loses the host stub) */ \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lptr_a)(base_ + (wave_u + 4 * t) * 1024), 16, \
-                                               vo_, 0, 0, 0);                                          \
+                                               vo_, ksoff_, 0, 0);                                     \
     }                                                                                                  \
     _Pragma("unroll") for (int t = 0; t < VPIECES; ++t)                                                \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lptr_a)(base_ + KT::BYTES + (wave_u + 4 * t) * 1024), 16, \
-                                               voffs[t], (kb_) * VTB, 0, 0);                           \
+                                               voffs[t], vsoff_ + (uint32_t)wb_ * VTB, 0, 0);          \
   }
 #define TWAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");
 
@@ -243,7 +258,9 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
     float s[2][16];
     float mult = p.scale_log2;
     if constexpr (QK_I8) {
-      mult = (qs * ks_all[(int64_t)h * p.kb_alloc + kb]) * p.scale_log2;
+      int64_t ksi = (int64_t)h * p.kb_alloc + kb;
+      if (p.kbp > 0) { const int r_ = kb / p.kbp; ksi = (int64_t)r_ * p.ks_rs + (int64_t)h * p.kbp + (kb - r_ * p.kbp); }
+      mult = (qs * ks_all[ksi]) * p.scale_log2;
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         v16i acc = magic16;
@@ -482,11 +499,14 @@ static int attn_stride_check(const char* who, int64_t o_stride_h, int64_t o_stri
   return TD_OK;
 }
 
+struct AttnGather { int kbp; int64_t k_rs, v_rs, ks_rs; };
+static const AttnGather kFlat = {0, 0, 0, 0};
+
 static int attn_i8_impl(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
                              const void* vt, const float* v_scale, const int32_t* lut, int nsel, void* o, int out_dtype,
                              int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
                              int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out,
-                             float* q_scale, td_stream_t stream) {
+                             float* q_scale, td_stream_t stream, const AttnGather& ga = kFlat) {
   int rc = attn_common_checks("td_attn_i8", q_i8, k_i8, vt, q_out ? (void*)q_out : o, nsel, L, Lk, H, lut);
   TD_REQUIRE((q_out == nullptr) == (q_scale == nullptr), TD_ERR_INVALID, "td_attn_i8: q_out/q_scale mismatch");
   if (!q_out) { rc = attn_stride_check("td_attn_i8", o_stride_h, o_stride_l); if (rc) return rc; }
@@ -499,10 +519,12 @@ static int attn_i8_impl(const int8_t* q_i8, const float* q_s, const int8_t* k_i8
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
   p.q_stride_h = 0; p.q_stride_l = 0; p.q_rstd = nullptr; p.q_w = nullptr; p.v_scale = v_scale;
+  p.kbp = ga.kbp; p.k_rs = ga.k_rs; p.v_rs = ga.v_rs; p.ks_rs = ga.ks_rs;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
-  if (Lk_alloc == 0) Lk_alloc = Lk;
-  TD_REQUIRE(Lk_alloc >= Lk && (Lk_alloc == Lk || Lk_alloc % 64 == 0), TD_ERR_INVALID, "attn: Lk_alloc=%lld", (long long)Lk_alloc);
+  if (ga.kbp > 0) Lk_alloc = (int64_t)ga.kbp * 64;   // one rank's part
+  else if (Lk_alloc == 0) Lk_alloc = Lk;
+  TD_REQUIRE(ga.kbp > 0 || (Lk_alloc >= Lk && (Lk_alloc == Lk || Lk_alloc % 64 == 0)), TD_ERR_INVALID, "attn: Lk_alloc=%lld", (long long)Lk_alloc);
   p.k_rows_alloc = Lk_alloc; p.kb_alloc = (int)td_cdiv(Lk_alloc, 64);
   p.tau = td_tuning(TD_TUNE_ATTN_TAU) < 0 ? 0.0f : (td_tuning(TD_TUNE_ATTN_TAU) == 0 ? 8.0f : (float)td_tuning(TD_TUNE_ATTN_TAU));
   hipStream_t st = (hipStream_t)stream;
@@ -546,7 +568,8 @@ extern "C" int td_attn_i8(const int8_t* q_i8, const float* q_s, const int8_t* k_
 static int attn_16_impl(const char* who, const void* q, int64_t q_stride_h, int64_t q_stride_l, const float* q_rstd,
                         const float* q_w, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
                         int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
-                        int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream) {
+                        int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream,
+                        const AttnGather& ga = kFlat) {
   int rc = attn_common_checks(who, q, k, vt, q_out ? (void*)q_out : o, nsel, L, Lk, H, lut);
   TD_REQUIRE((q_out == nullptr) == (q_scale == nullptr), TD_ERR_INVALID, "%s: q_out/q_scale mismatch", who);
   if (!q_out) { rc = attn_stride_check(who, o_stride_h, o_stride_l); if (rc) return rc; }
@@ -557,10 +580,12 @@ static int attn_16_impl(const char* who, const void* q, int64_t q_stride_h, int6
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
   p.q_stride_h = q_stride_h; p.q_stride_l = q_stride_l; p.q_rstd = q_rstd; p.q_w = q_w; p.v_scale = nullptr;
+  p.kbp = ga.kbp; p.k_rs = ga.k_rs; p.v_rs = ga.v_rs; p.ks_rs = ga.ks_rs;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
-  if (Lk_alloc == 0) Lk_alloc = Lk;
-  TD_REQUIRE(Lk_alloc >= Lk && (Lk_alloc == Lk || Lk_alloc % 64 == 0), TD_ERR_INVALID, "attn: Lk_alloc=%lld", (long long)Lk_alloc);
+  if (ga.kbp > 0) Lk_alloc = (int64_t)ga.kbp * 64;
+  else if (Lk_alloc == 0) Lk_alloc = Lk;
+  TD_REQUIRE(ga.kbp > 0 || (Lk_alloc >= Lk && (Lk_alloc == Lk || Lk_alloc % 64 == 0)), TD_ERR_INVALID, "attn: Lk_alloc=%lld", (long long)Lk_alloc);
   p.k_rows_alloc = Lk_alloc; p.kb_alloc = (int)td_cdiv(Lk_alloc, 64);
   p.tau = td_tuning(TD_TUNE_ATTN_TAU) < 0 ? 0.0f : (td_tuning(TD_TUNE_ATTN_TAU) == 0 ? 8.0f : (float)td_tuning(TD_TUNE_ATTN_TAU));
   hipStream_t st = (hipStream_t)stream;
@@ -594,4 +619,33 @@ extern "C" int td_attn_16_qnorm(const void* q_src, int64_t ld_q, const float* q_
   TD_REQUIRE(ld_q >= (int64_t)H * 128 && ld_q % 8 == 0, TD_ERR_INVALID, "td_attn_16_qnorm: ld_q=%lld", (long long)ld_q);
   return attn_16_impl("td_attn_16_qnorm", q_src, 256, ld_q * 2, q_rstd, q_w, k, vt, lut, nsel, o, dtype, o_stride_h,
                       o_stride_l, sm_scale, L, Lk, Lk_alloc, H, add_t, q_out, q_scale, stream);
+}
+
+
+// ---- sequence-parallel entry points: the K side (K rows, K scales, V^T tiles) is read straight from the output of the
+// all-gather, rank-major (see AttnParams::kbp): no re-layout of the gathered state.  k / k_s / vt point at rank 0's part;
+// *_rank_stride are the distances to the next rank's (bytes, floats, bytes); kb_per_rank = blocks of 64 keys per rank.
+extern "C" int td_attn_i8_sp(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
+                             const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
+                             int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int H,
+                             int kb_per_rank, int64_t k_rank_stride, int64_t ks_rank_stride, int64_t vt_rank_stride,
+                             const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream) {
+  TD_REQUIRE(kb_per_rank > 0 && k_rank_stride > 0 && ks_rank_stride > 0 && vt_rank_stride > 0, TD_ERR_INVALID,
+             "td_attn_i8_sp: gathered layout kb_per_rank=%d", kb_per_rank);
+  TD_REQUIRE(k_rank_stride % 16 == 0 && vt_rank_stride % 16 == 0, TD_ERR_UNSUPPORTED, "td_attn_i8_sp: rank strides must be 16-byte multiples");
+  const AttnGather ga = {kb_per_rank, k_rank_stride, vt_rank_stride, ks_rank_stride};
+  return attn_i8_impl(q_i8, q_s, k_i8, k_s, vt, nullptr, lut, nsel, o, out_dtype, o_stride_h, o_stride_l, sm_scale, L, Lk,
+                      0, H, add_t, q_out, q_scale, stream, ga);
+}
+
+extern "C" int td_attn_16_sp(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
+                             int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
+                             int H, int kb_per_rank, int64_t k_rank_stride, int64_t vt_rank_stride, const void* add_t,
+                             int8_t* q_out, float* q_scale, td_stream_t stream) {
+  TD_REQUIRE(kb_per_rank > 0 && k_rank_stride > 0 && vt_rank_stride > 0, TD_ERR_INVALID,
+             "td_attn_16_sp: gathered layout kb_per_rank=%d", kb_per_rank);
+  TD_REQUIRE(k_rank_stride % 16 == 0 && vt_rank_stride % 16 == 0, TD_ERR_UNSUPPORTED, "td_attn_16_sp: rank strides must be 16-byte multiples");
+  const AttnGather ga = {kb_per_rank, k_rank_stride, vt_rank_stride, 0};
+  return attn_16_impl("td_attn_16_sp", q, 0, 0, nullptr, nullptr, k, vt, lut, nsel, o, dtype, o_stride_h, o_stride_l,
+                      sm_scale, L, Lk, 0, H, add_t, q_out, q_scale, stream, ga);
 }

@@ -316,7 +316,11 @@ template <int DT, int NPER>   // NPER >= ceil(Kb / 64): the wave's row lives in 
 __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restrict__ pq,
                                                        const uint16_t* __restrict__ pk,
                                                        int32_t* __restrict__ lut, int Qb, int Kb,
-                                                       int Kb_alloc, int topk) {
+                                                       int Kb_alloc, int topk, int kbp, int64_t pk_rs) {
+  // kbp > 0: pooled K in the rank-major layout of the sequence-parallel all-gather — block j is block j % kbp of rank
+  // j / kbp, rows at pk + rank*pk_rs + (h*kbp + ...)*128 (Kb_alloc = kbp then)
+#define TK_PKROW(key_) ((kbp > 0) ? ((int64_t)((key_) / kbp) * pk_rs + ((int64_t)h * kbp + ((key_) % kbp)) * 128) \
+                                  : (((int64_t)h * Kb_alloc + (key_)) * 128))
   extern __shared__ __attribute__((aligned(16))) char smem_tk[];
   uint16_t* sc = reinterpret_cast<uint16_t*>(smem_tk);                      // [4][Kb] sortable keys
   uint4* ktile = reinterpret_cast<uint4*>(smem_tk + (((size_t)TK_ROWS * Kb * 2 + 15) & ~(size_t)15));
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
   for (int it = 0; it < 4; ++it) {
     const int idx = tid + 256 * it, key = idx >> 4, v = idx & 15;
     nxt[it] = make_uint4(0, 0, 0, 0);
-    if (key < Kb) nxt[it] = *reinterpret_cast<const uint4*>(pk + ((int64_t)h * Kb_alloc + key) * 128 + v * 8);
+    if (key < Kb) nxt[it] = *reinterpret_cast<const uint4*>(pk + TK_PKROW(key) + v * 8);
   }
   for (int c0 = 0; c0 < Kb; c0 += 64) {
 #pragma unroll
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
       for (int it = 0; it < 4; ++it) {
         const int idx = tid + 256 * it, key = idx >> 4, v = idx & 15;
         nxt[it] = make_uint4(0, 0, 0, 0);
-        if (c0 + 64 + key < Kb) nxt[it] = *reinterpret_cast<const uint4*>(pk + ((int64_t)h * Kb_alloc + c0 + 64 + key) * 128 + v * 8);
+        if (c0 + 64 + key < Kb) nxt[it] = *reinterpret_cast<const uint4*>(pk + TK_PKROW(c0 + 64 + key) + v * 8);
       }
     }
     __syncthreads();
@@ -422,10 +426,10 @@ __global__ __launch_bounds__(256) void sla_topk_kernel(const uint16_t* __restric
   }
 }
 
-extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb,
-                           int Kb, int Kb_alloc, int D, int topk, td_stream_t stream) {
+static int sla_topk_impl(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb,
+                         int Kb, int Kb_alloc, int D, int topk, td_stream_t stream, int kbp, int64_t pk_rs) {
   if (Kb_alloc == 0) Kb_alloc = Kb;
-  TD_REQUIRE(Kb_alloc >= Kb, TD_ERR_INVALID, "td_sla_topk: Kb_alloc=%d < Kb=%d", Kb_alloc, Kb);
+  TD_REQUIRE(kbp > 0 || Kb_alloc >= Kb, TD_ERR_INVALID, "td_sla_topk: Kb_alloc=%d < Kb=%d", Kb_alloc, Kb);
   TD_REQUIRE(pq && pk && lut, TD_ERR_INVALID, "td_sla_topk: null pointer");
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_topk: D=%d (need 128)", D);
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_sla_topk: dtype %d", dtype);
@@ -440,7 +444,7 @@ extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* l
   {                                                                                                                \
     static std::atomic<uint64_t> a{0};                                                                             \
     td_ensure_dyn_lds(reinterpret_cast<const void*>(sla_topk_kernel<DT_, NP_>), TK_ROWS * TK_MAXKB * 2 + 16 + 64 * 17 * 16, a); \
-    sla_topk_kernel<DT_, NP_><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk); \
+    sla_topk_kernel<DT_, NP_><<<grid, 256, lds, st>>>((const uint16_t*)pq, (const uint16_t*)pk, lut, Qb, Kb, Kb_alloc, topk, kbp, pk_rs); \
   }
 #define TD_TK_DT(DT_)                                                                                              \
   {                                                                                                                \
@@ -451,4 +455,18 @@ extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* l
 #undef TD_TK
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_sla_topk(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb,
+                           int Kb, int Kb_alloc, int D, int topk, td_stream_t stream) {
+  return sla_topk_impl(pq, pk, dtype, lut, H, Qb, Kb, Kb_alloc, D, topk, stream, 0, 0);
+}
+
+// sequence parallelism: pooled K straight from the all-gather's rank-major output — block j = block j % kb_per_rank of
+// rank j / kb_per_rank, its row at pk + rank*pk_rank_stride + (h*kb_per_rank + ...)*D (strides in elements)
+extern "C" int td_sla_topk_sp(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb, int Kb,
+                              int kb_per_rank, int64_t pk_rank_stride, int D, int topk, td_stream_t stream) {
+  TD_REQUIRE(kb_per_rank > 0 && pk_rank_stride > 0 && pk_rank_stride % 8 == 0, TD_ERR_INVALID,
+             "td_sla_topk_sp: kb_per_rank=%d pk_rank_stride=%lld", kb_per_rank, (long long)pk_rank_stride);
+  return sla_topk_impl(pq, pk, dtype, lut, H, Qb, Kb, kb_per_rank, D, topk, stream, kb_per_rank, pk_rank_stride);
 }

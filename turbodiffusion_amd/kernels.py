@@ -468,3 +468,59 @@ def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l):
     call("td_sla_linear_out", ptr(q), dt_code(q.dtype), ptr(kv_t), ptr(ksum), ptr(wp), ptr(bp), ptr(out),
          o_stride_h, o_stride_l, L_, H, D, stream_ptr())
     return out
+
+
+# ----------------------------------------------------------------------------- sequence parallelism: gathered (rank-major) K side
+def _rank_major(t, inner_shape):
+    """t: a [W, *inner_shape] view of an all-gather output whose only non-contiguous dim is the rank dim -> byte stride."""
+    assert tuple(t.shape[1:]) == tuple(inner_shape) and t[0].is_contiguous(), "gathered part must be contiguous per rank"
+    return t.stride(0) * t.element_size()
+
+
+def sla_topk_sp(pq, pk_g, topk, kb):
+    """pq [H, Qb, D]; pk_g [W, H, kbp, D] rank-major view of the gathered pooled K (first ``kb`` global blocks valid)."""
+    require_gpu(pq, pk_g)
+    H, Qb, D = pq.shape
+    W, H2, kbp, _ = pk_g.shape
+    assert H2 == H and pq.is_contiguous()
+    rs = _rank_major(pk_g, (H, kbp, D)) // pk_g.element_size()
+    lut = torch.empty((H, Qb, topk), dtype=torch.int32, device=pq.device)
+    call("td_sla_topk_sp", ptr(pq), ptr(pk_g), dt_code(pq.dtype), ptr(lut), H, Qb, kb, kbp, rs, D, topk, stream_ptr())
+    return lut
+
+
+def attn_i8_sp(q_i8, q_s, k_g, ks_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
+    """attn_i8 with the K side read from the all-gather's rank-major output: k_g int8 [W, H, per, 128],
+    ks_g f32 [W, H, per/64], vt_g f16 [W, H, per/64, 128, 64] (views; only the rank dim may be strided)."""
+    require_gpu(q_i8, k_g, ks_g, vt_g, lut, add_t)
+    H, L_, D = q_i8.shape
+    W, H2, per, _ = k_g.shape
+    kbp = per // 64
+    assert H2 == H and D == 128 and per % 64 == 0 and vt_g.dtype == torch.float16 and q_i8.is_contiguous() and q_s.is_contiguous()
+    k_rs = _rank_major(k_g, (H, per, D))
+    ks_rs = _rank_major(ks_g, (H, kbp)) // 4
+    v_rs = _rank_major(vt_g, (H, kbp, D, 64))
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    nsel = 0 if lut is None else lut.shape[-1]
+    _timed("td_attn_i8", (H, L_, lk, nsel), lambda: call(
+        "td_attn_i8_sp", ptr(q_i8), ptr(q_s), ptr(k_g), ptr(ks_g), ptr(vt_g), ptr(lut), nsel, ptr(out), dt_code(out.dtype),
+        o_stride_h, o_stride_l, float(sm_scale), L_, lk, H, kbp, k_rs, ks_rs, v_rs, ptr(add_t), None, None, stream_ptr()))
+    return out
+
+
+def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
+    """attn_16 with rank-major gathered K [W, H, per, 128] / V^T tiles [W, H, per/64, 128, 64] (same 16-bit dtype as q)."""
+    require_gpu(q, k_g, vt_g, lut, add_t)
+    H, L_, D = q.shape
+    W, H2, per, _ = k_g.shape
+    kbp = per // 64
+    assert H2 == H and D == 128 and per % 64 == 0 and vt_g.dtype == q.dtype and k_g.dtype == q.dtype and q.is_contiguous()
+    k_rs = _rank_major(k_g, (H, per, D))
+    v_rs = _rank_major(vt_g, (H, kbp, D, 64))
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(D)
+    nsel = 0 if lut is None else lut.shape[-1]
+    call("td_attn_16_sp", ptr(q), ptr(k_g), ptr(vt_g), ptr(lut), nsel, ptr(out), dt_code(q.dtype), o_stride_h, o_stride_l,
+         float(sm_scale), L_, lk, H, kbp, k_rs, v_rs, ptr(add_t), None, None, stream_ptr())
+    return out

@@ -174,8 +174,8 @@ class SeqParallel:
                 elif not dense:
                     pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
 
-        def seq_major(t):  # [W, Hg, n, ...] -> [Hg, W*n, ...]
-            return t.permute(1, 0, 2, *range(3, t.dim())).reshape(t.shape[1], W * t.shape[2], *t.shape[3:]).contiguous()
+        # The attention / block-map kernels read the K side STRAIGHT from the all-gather's rank-major output (the *_sp
+        # entry points: block j = block j % kbp of rank j // kbp): no re-layout of the gathered K / V^T / scales / pooled K.
 
         topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
         for (h0, h1, sizes, offs, allb, work) in inflight:
@@ -187,29 +187,22 @@ class SeqParallel:
                 n = sizes[name]
                 return allb[:, offs[name]:offs[name] + n].view(dtype).view((W,) + shape)
 
-            vt_all = seq_major(gathered("vt", pdt, (Hg, kbp, D, 64)))              # [Hg, W*kbp, D, 64]
+            vt_g = gathered("vt", pdt, (Hg, kbp, D, 64))                            # [W, Hg, kbp, D, 64] view
             out_g = out.view(-1)[h0 * o_stride_h:]   # same buffer, origin moved to the group's first head
             lut = None
+            if not dense:
+                lut = ops.sla_topk_sp(pq[h0:h1], gathered("pk", dt, (Hg, kbp, D)), topk, kb_tot)
             if sage:
-                k_all = seq_major(gathered("k", torch.int8, (Hg, per, D)))         # [Hg, W*per, D]
-                ks_all = seq_major(gathered("ks", torch.float32, (Hg, kbp)))       # [Hg, W*kbp]
-                if not dense:
-                    pk_all = seq_major(gathered("pk", dt, (Hg, kbp, D)))           # [Hg, W*kbp, D]
-                    lut = ops.sla_topk(pq[h0:h1].contiguous(), pk_all, topk, kb=kb_tot)
-                ops.attn_i8(q_q[h0:h1].contiguous(), q_s[h0:h1].contiguous(), k_all, ks_all, vt_all, lut, out_g,
-                            o_stride_h, o_stride_l, lk=L)
+                ops.attn_i8_sp(q_q[h0:h1], q_s[h0:h1], gathered("k", torch.int8, (Hg, per, D)),
+                               gathered("ks", torch.float32, (Hg, kbp)), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
             else:
-                k_all = seq_major(gathered("k", dt, (Hg, per, D)))
-                if not dense:
-                    pk_all = seq_major(gathered("pk", dt, (Hg, kbp, D)))
-                    lut = ops.sla_topk(pq[h0:h1].contiguous(), pk_all, topk, kb=kb_tot)
-                ops.attn_16(q[h0:h1].contiguous(), k_all, vt_all, lut, out_g, o_stride_h, o_stride_l, lk=L)
+                ops.attn_16_sp(q[h0:h1], gathered("k", dt, (Hg, per, D)), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
             if linear:
                 kv_parts = gathered("kv", torch.float32, (Hg, D, D))   # [W, Hg, D, D]
                 ks_parts = gathered("kss", torch.float32, (Hg, D))     # [W, Hg, D]
                 kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D,
                                                      ks_parts.stride(0), Hg, D, dt)
-                ops.sla_linear_out_(q[h0:h1].contiguous(), kv_t, ksum, proj_w, proj_b, out_g, o_stride_h, o_stride_l)
+                ops.sla_linear_out_(q[h0:h1], kv_t, ksum, proj_w, proj_b, out_g, o_stride_h, o_stride_l)
         return out
 
 
