@@ -521,8 +521,11 @@ class WanModel(nn.Module):
         if mods is None or mods[1] != ver:
             mods = self._fused["mods"] = (torch.stack([blk.modulation.detach().float() for blk in self.blocks], 0), ver)
         e_all = mods[0] + e0.unsqueeze(0)                    # fp32 [nblk, B, 6, dim]
+        tap = getattr(self, "_tap_tokens", None)   # tools/drift.py: list that receives the tokens after every block
         for i, blk in enumerate(self.blocks):
             x = self._block(i, blk, x, e_all[i], cos, sin, context, tkv, kvts)
+            if tap is not None:
+                tap.append(x.clone())
         if return_tokens:
             return x if sp is None else sp.gather_tokens(x, L_)
         # head (wan2pt1.py:444-454): fp32 modulate of the (bf16) norm, fp32 Linear
