@@ -178,7 +178,7 @@ def main():
     if args.cpu:
         import time
         from oracle import ops_ref as O, sla_ref as S
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 32)       # the oracle's small per-block ops do not scale past a few dozen threads
         torch.set_num_threads(cores)
         Mc = 4096                                   # bounded slice of the L = 32760 rows; per-row costs scale linearly
 
