@@ -127,6 +127,25 @@ int td_layernorm_quant(const void* x, int dtype, const float* w, const float* b,
                        const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float* stats_ws, float eps,
                        int64_t m, int64_t n, td_stream_t stream);
 
+/* ---- a15 (+ a7) -> a5 / a6 statistics: row statistics of the NEXT norm from the producing GEMM's epilogue ----
+ * td_gemm_w8a8_stats: td_gemm_w8a8 (residual == 0: d_or_x = d with row stride ld) or td_gemm_w8a8_residual (residual != 0:
+ *   in place on x, gate f32 [n] or NULL) — same arithmetic, same bits — whose epilogue also writes, per output row and per
+ *   64-column piece of it, (sum, sum of squares) of the 16-bit values it stores: stats_ws float2 [m, n/64].
+ *   bf16, bias required, k % 128 == 0, n % 64 == 0, ld % 8 == 0.
+ * td_row_stats_finalize: the pieces -> mode 0: LayerNorm statistics out float2 [m] = (mean, 1/sqrt(E[x^2] - mean^2 + eps));
+ *   mode 1: RMSNorm out float [m] = 1/sqrt(E[x^2] + eps)   (== td_rms_stats up to summation order).
+ * td_layernorm_quant_stats: td_layernorm_quant's apply + quantise pass with the rows' (mean, rstd) supplied.
+ * Together they remove the statistics pass of WanLayerNorm / the cross-attention q RMSNorm over [L, dim]
+ * (wan2pt1.py:191-212,404-413): the residual stream is read once per LayerNorm instead of twice. */
+int td_gemm_w8a8_stats(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
+                       void* d_or_x, const float* gate, int residual, int dtype, int64_t m, int64_t n, int64_t k,
+                       int64_t ld, float* stats_ws, td_stream_t stream);
+int td_row_stats_finalize(const float* ws, int pieces, int64_t n, float eps, int mode, float* out, int64_t m,
+                          td_stream_t stream);
+int td_layernorm_quant_stats(const void* x, int dtype, const float* w, const float* b, const float* scale,
+                             const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, const float* row_stats,
+                             int64_t m, int64_t n, td_stream_t stream);
+
 /* ---- a7: gated residual  x = x + y*gate.type_as(x)  (wan2pt1.py:405-406,412-413) ----
  * x,y [m,n] f16|bf16 (in place on x), gate f32 [batch,n] or NULL (plain x += y, :410).
  * Rounding order of the reference: t = round(y*round(gate)); x = round(x + t). */

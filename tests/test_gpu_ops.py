@@ -304,3 +304,43 @@ def test_turbo_diffusion_ops_compat_drives_the_reference_call_sequence(K):
     assert layer_norm_cuda(xf, 1e-6, wn, bn, out) is out
     torch.testing.assert_close(out.cpu(), O.layernorm_fast(xf.cpu(), wn.cpu(), bn.cpu(), 1e-6), rtol=2e-5, atol=2e-6)
     torch.testing.assert_close(layer_norm_cuda(xf, 1e-6, None, None, None).cpu(), O.layernorm_fast(xf.cpu(), None, None, 1e-6), rtol=2e-5, atol=2e-6)
+
+
+# ---------------------------------------------------------------- row statistics from the GEMM epilogue
+@pytest.mark.parametrize("m,n,k", [(1300, 1536, 384), (2100, 5120, 256), (1024, 320, 128)])
+@pytest.mark.parametrize("residual", [True, False])
+def test_gemm_row_stats_epilogue(K, m, n, k, residual):
+    """td_gemm_w8a8_stats: the output bits are those of td_gemm_w8a8 / td_gemm_w8a8_residual, and the per-piece (sum, sum
+    of squares) finalised by td_row_stats_finalize give the LayerNorm statistics of the stored rows (vs an fp64 evaluation
+    of the stored 16-bit values) and the RMSNorm statistic td_rms_stats computes."""
+    g = torch.Generator().manual_seed(m + n)
+    a = act_like(m, k, torch.bfloat16, seed=m + n + k)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(n, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    gate = (torch.randn(1, n, generator=g) * 0.5).to(DEV)
+    aq, as_ = K.quant_i8_block128(a.to(DEV))
+    wq, ws = K.quant_i8_block128(w.to(DEV))
+    if residual:
+        x0 = (torch.randn(m, n, generator=g) * 2 + 0.3).to(torch.bfloat16).to(DEV)
+        ref = K.gemm_w8a8_residual_(x0.clone(), aq, as_, wq, ws, bias=b, gate=gate)
+        out, part = K.gemm_w8a8_stats(aq, as_, wq, ws, b, x=x0.clone(), gate=gate)
+    else:
+        ref = K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b)
+        out, part = K.gemm_w8a8_stats(aq, as_, wq, ws, b)
+    assert torch.equal(out, ref)
+    st = K.row_stats_finalize(part, n, 1e-6)
+    r64 = ref.double()
+    mean, var = r64.mean(-1), r64.var(-1, unbiased=False)
+    torch.testing.assert_close(st[:, 0].double(), mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(st[:, 1].double(), 1.0 / torch.sqrt(var + 1e-6), rtol=2e-5, atol=0)
+    rstd = K.row_stats_finalize(part, n, 1e-6, rms=True)
+    torch.testing.assert_close(rstd, K.rms_stats(ref, n, 1e-6), rtol=2e-6, atol=0)
+    # LayerNorm -> INT8 with the supplied statistics against its own statistics pass: same scales / codes except where a
+    # last-bit difference of (mean, rstd) moves a value across a rounding boundary
+    sc, sh = (0.2 * torch.randn(1, n, generator=g)).to(DEV), (0.2 * torch.randn(1, n, generator=g)).to(DEV)
+    if n <= K.LNQ_MAX_N:
+        q0, s0 = K.layernorm_quant(ref, None, None, 1e-6, sc, sh, rows_per_batch=m)
+        q1, s1 = K.layernorm_quant(ref, None, None, 1e-6, sc, sh, rows_per_batch=m, stats=st)
+        assert (q0 != q1).float().mean().item() < 2e-3 and (q0.int() - q1.int()).abs().max().item() <= 1
+        assert (s0 != s1).float().mean().item() < 0.05
+        torch.testing.assert_close(s0, s1, rtol=1e-2, atol=0)

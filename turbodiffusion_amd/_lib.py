@@ -44,6 +44,9 @@ SIGNATURES = {
     "td_attn_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
     "td_attn_16": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
     "td_attn_i8_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
+    "td_gemm_w8a8_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _vp, _vp],
+    "td_row_stats_finalize": [_vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp],
+    "td_layernorm_quant_stats": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
     "td_attn_i8_sp": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _i64,
                       _vp, _vp, _vp, _vp],
     "td_attn_16_sp": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _vp, _vp, _vp,

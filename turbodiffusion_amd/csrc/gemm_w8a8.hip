@@ -261,3 +261,18 @@ extern "C" int td_gemm_w8a8_residual(const int8_t* a, const float* a_s, const in
     return td_gemm_w8a8_m32_res(a, a_s, b, b_s, bias, x, gate, dtype, m, n, k, ldx, (hipStream_t)stream);
   return td_gemm_w8a8_fi_res(a, a_s, b, b_s, bias, x, gate, dtype, m, n, k, ldx, (hipStream_t)stream);
 }
+
+
+// a15 (+ a7) -> a5 / a6 statistics: td_gemm_w8a8 (x == NULL form: d, ldd) or td_gemm_w8a8_residual (residual != 0: in
+// place on x) whose epilogue also writes, per output row and 64-column piece, (sum, sum of squares) of the stored 16-bit
+// values: stats_ws float2 [m, n/64] for td_row_stats_finalize.  bf16, bias required, n % 64 == 0, m >= 1024.
+extern "C" int td_gemm_w8a8_stats(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
+                                  void* d_or_x, const float* gate, int residual, int dtype, int64_t m, int64_t n,
+                                  int64_t k, int64_t ld, float* stats_ws, td_stream_t stream) {
+  TD_REQUIRE(a && a_s && b && b_s && d_or_x && bias && stats_ws, TD_ERR_INVALID, "td_gemm_w8a8_stats: null pointer");
+  TD_REQUIRE(dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_stats: dtype %d (bf16 only)", dtype);
+  TD_REQUIRE(k % 128 == 0 && k > 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_stats: k=%lld must be a positive multiple of 128", (long long)k);
+  TD_REQUIRE(n % 64 == 0 && n > 0 && m > 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_stats: n=%lld must be a positive multiple of 64", (long long)n);
+  TD_REQUIRE(ld >= n && ld % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_stats: bad ld=%lld", (long long)ld);
+  return td_gemm_w8a8_fi_stats(a, a_s, b, b_s, bias, d_or_x, gate, residual, m, n, k, ld, stats_ws, (hipStream_t)stream);
+}

@@ -85,7 +85,11 @@ __device__ __forceinline__ uint32_t f_swz(uint32_t row, uint32_t chunk) {
 //   |fast - exact| <= 2^-24 * (G+1) * 1.5*2^23 * sum_k s_k = 0.75 (G+1) sum_k s_k     (fp32, before the 16-bit cast)
 // i.e. < 4 counts of a K block's integer sum per block for G = 4, against typical |isum| ~ 1e4 (rel. ~1e-4..3e-4, an
 // order below the bf16 rounding of the result).  1.25 VALU per element and K block instead of 2.
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0>
+// STATS: the (plain or RES) epilogue also emits, per output row and per 64-column piece of it, (sum, sum of squares) of the
+// 16-bit values it stores — QS is then a float2 workspace [M, ldqs] with ldqs = N / 64 pieces per row.  td_row_stats_finalize
+// turns the pieces into the row statistics of the LayerNorm / RMSNorm that reads this output next, which therefore needs no
+// statistics pass of its own over the [M, N] tensor.
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
@@ -457,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t m = m0 + wm * 128 + i * 16 + l16;
+    float st_s = 0.f, st_q = 0.f;   // STATS: this lane's share of the row's 64-column piece
     uint32_t pk[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -498,7 +503,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) xf[e] = xf[e] + yf[e];
           }
-          *reinterpret_cast<uint4*>(xp) = pack8<ODT>(xf);
+          const uint4 xn = pack8<ODT>(xf);
+          *reinterpret_cast<uint4*>(xp) = xn;
+          if constexpr (STATS) {
+            float sv[8];
+            unpack8<ODT>(xn, sv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { st_s += sv[e]; st_q = fmaf(sv[e], sv[e], st_q); }
+          }
         }
       } else
       if (m < (DBG == 3 ? (int64_t)(ldqs) : M) && n < N) {
@@ -508,7 +520,20 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         } else {
           *reinterpret_cast<uint4*>(D + m * ldd + n) = v;
         }
+        if constexpr (STATS) {
+          float sv[8];
+          unpack8<ODT>(v, sv);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { st_s += sv[e]; st_q = fmaf(sv[e], sv[e], st_q); }
+        }
       }
+    }
+    if constexpr (STATS) {
+      // the row's 64 columns of this wave tile sit in the 4 lanes l16 + 16*lq: fixed-order butterfly, then one 8-byte store
+      st_s += __shfl_xor(st_s, 16, 64); st_q += __shfl_xor(st_q, 16, 64);
+      st_s += __shfl_xor(st_s, 32, 64); st_q += __shfl_xor(st_q, 32, 64);
+      if (lq == 0 && m < M && n0 + wn * 64 < N)
+        reinterpret_cast<float2*>(QS)[m * ldqs + ((n0 + wn * 64) >> 6)] = make_float2(st_s, st_q);
     }
   }
   if constexpr (DBG >= 2) {
@@ -524,11 +549,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0>
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false>
 static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
-  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST>;
+  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS>;
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), F_LDS + F_DUMP, attr_mask);
   const int tiles_m = (int)td_cdiv(m, F_BM), tiles_n = (int)td_cdiv(n, F_BN);
@@ -628,4 +653,18 @@ int td_gemm_w8a8_fi_res(const int8_t* a, const float* a_s, const int8_t* b, cons
                 : launch_gemm_fi<TD_BF16, TD_EPI_NONE, false, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
   return bias ? launch_gemm_fi<TD_F16, TD_EPI_NONE, true, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate)
               : launch_gemm_fi<TD_F16, TD_EPI_NONE, false, 0, 0, false, true>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, nullptr, 0, gate);
+}
+
+
+// a15 (+a7) with the row-statistics partials of the NEXT norm (STATS epilogue): stats_ws float2 [m, n/64].
+// x == nullptr: plain GEMM into d (ldd); else the residual form on x (ldx).  BF16 + bias only (the model's linears).
+int td_gemm_w8a8_fi_stats(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
+                          void* d_or_x, const float* gate, int residual, int64_t m, int64_t n, int64_t k, int64_t ld,
+                          float* stats_ws, hipStream_t st) {
+  const int64_t pieces = n / 64;
+  if (residual)
+    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, true, 0, true>(a, a_s, b, b_s, bias, d_or_x, m, n, k, ld, st,
+                                                                                 stats_ws, pieces, gate);
+  return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, false, 0, true>(a, a_s, b, b_s, bias, d_or_x, m, n, k, ld, st,
+                                                                                stats_ws, pieces, nullptr);
 }

@@ -186,9 +186,42 @@ __global__ __launch_bounds__(256) void ln_apply_quant_kernel(
   }
 }
 
-extern "C" int td_layernorm_quant(const void* x, int dtype, const float* w, const float* b, const float* scale,
-                                  const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float* stats_ws,
-                                  float eps, int64_t m, int64_t n, td_stream_t stream) {
+// row statistics from the per-piece (sum, sum of squares) a GEMM's STATS epilogue wrote (gemm_w8a8_fi.hip): one thread per
+// row, the pieces summed in order (deterministic).  mode 0: LayerNorm -> out float2 [m] = (mean, 1/sqrt(var + eps)) with
+// var = E[x^2] - mean^2 (>= 0); mode 1: RMSNorm -> out float [m] = 1/sqrt(E[x^2] + eps).
+__global__ void row_stats_finalize_kernel(const float2* __restrict__ ws, int pieces, float inv_n, float eps, int mode,
+                                          float* __restrict__ out, int64_t m) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= m) return;
+  float s = 0.f, q = 0.f;
+  for (int p = 0; p < pieces; ++p) {
+    const float2 v = ws[row * pieces + p];
+    s += v.x;
+    q += v.y;
+  }
+  if (mode == 0) {
+    const float mean = s * inv_n;
+    const float var = fmaxf(fmaf(-mean, mean, q * inv_n), 0.f);
+    reinterpret_cast<float2*>(out)[row] = make_float2(mean, 1.0f / sqrtf(var + eps));
+  } else {
+    out[row] = 1.0f / sqrtf(q * inv_n + eps);
+  }
+}
+
+extern "C" int td_row_stats_finalize(const float* ws, int pieces, int64_t n, float eps, int mode, float* out, int64_t m,
+                                     td_stream_t stream) {
+  TD_REQUIRE(ws && out, TD_ERR_INVALID, "td_row_stats_finalize: null pointer");
+  TD_REQUIRE(pieces > 0 && n > 0 && m >= 0 && (mode == 0 || mode == 1), TD_ERR_INVALID, "td_row_stats_finalize: pieces=%d n=%lld mode=%d", pieces, (long long)n, mode);
+  if (m == 0) return TD_OK;
+  row_stats_finalize_kernel<<<(unsigned)td_cdiv(m, 256), 256, 0, (hipStream_t)stream>>>(
+      reinterpret_cast<const float2*>(ws), pieces, 1.0f / (float)n, eps, mode, out, m);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+static int ln_quant_impl(const void* x, int dtype, const float* w, const float* b, const float* scale,
+                         const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float* stats_ws,
+                         float eps, int64_t m, int64_t n, td_stream_t stream, bool have_stats) {
   TD_REQUIRE(x && q && qs && stats_ws, TD_ERR_INVALID, "td_layernorm_quant: null pointer");
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_layernorm_quant: dtype %d (need f16|bf16)", dtype);
   TD_REQUIRE(m >= 0 && n > 0, TD_ERR_INVALID, "td_layernorm_quant: bad size");
@@ -211,8 +244,10 @@ extern "C" int td_layernorm_quant(const void* x, int dtype, const float* w, cons
     if (dtype == TD_BF16) ln_stats_kernel<NV_, TD_BF16><<<g1, 256, 0, st>>>(xp, sp, eps, m, (int)n); \
     else ln_stats_kernel<NV_, TD_F16><<<g1, 256, 0, st>>>(xp, sp, eps, m, (int)n);           \
   }
+  if (!have_stats) {
   if (nv <= 1) TD_LNS(1) else if (nv <= 2) TD_LNS(2) else if (nv <= 3) TD_LNS(3) else if (nv <= 4) TD_LNS(4)
   else if (nv <= 6) TD_LNS(6) else if (nv <= 8) TD_LNS(8) else if (nv <= 10) TD_LNS(10) else TD_LNS(16)
+  }
 #undef TD_LNS
   TD_CHECK_LAUNCH();
   dim3 g2(nb_n, (unsigned)td_cdiv(m, 128));
@@ -234,4 +269,19 @@ extern "C" int td_layernorm_quant(const void* x, int dtype, const float* w, cons
 #undef TD_LNA
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_layernorm_quant(const void* x, int dtype, const float* w, const float* b, const float* scale,
+                                  const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float* stats_ws,
+                                  float eps, int64_t m, int64_t n, td_stream_t stream) {
+  return ln_quant_impl(x, dtype, w, b, scale, shift, rows_per_batch, q, qs, stats_ws, eps, m, n, stream, false);
+}
+
+// the apply + quantise pass alone, with the rows' (mean, rstd) supplied (float2 [m], e.g. from td_row_stats_finalize of
+// the producing GEMM's STATS epilogue): no statistics pass over x
+extern "C" int td_layernorm_quant_stats(const void* x, int dtype, const float* w, const float* b, const float* scale,
+                                        const float* shift, int64_t rows_per_batch, int8_t* q, float* qs,
+                                        const float* row_stats, int64_t m, int64_t n, td_stream_t stream) {
+  return ln_quant_impl(x, dtype, w, b, scale, shift, rows_per_batch, q, qs, const_cast<float*>(row_stats), 0.f, m, n,
+                       stream, true);
 }

@@ -189,12 +189,48 @@ def gemm_w8a8_residual_(x, a_q, a_s, b_q, b_s, bias=None, gate=None):
     return x
 
 
+def gemm_w8a8_stats(a_q, a_s, b_q, b_s, bias, x=None, gate=None, out_dtype=torch.bfloat16):
+    """gemm_w8a8 (x is None: returns (y, ws)) or gemm_w8a8_residual_ (in place on x: returns (x, ws)) whose epilogue also
+    writes the row-statistics partials ws f32 [m, n/64, 2] = per 64-column piece (sum, sum of squares) of the stored values
+    — same output bits as the plain calls."""
+    require_gpu(a_q, a_s, b_q, b_s, bias, x, gate)
+    m, k = a_q.shape
+    n = b_q.shape[0]
+    assert a_q.dtype == torch.int8 and b_q.dtype == torch.int8 and b_q.shape[1] == k and n % 64 == 0 and bias is not None
+    assert a_q.is_contiguous() and b_q.is_contiguous() and bias.dtype == torch.bfloat16 and bias.is_contiguous()
+    _f32c(a_s, "a_s"), _f32c(b_s, "b_s")
+    ws = torch.empty((m, n // 64, 2), dtype=torch.float32, device=a_q.device)
+    if x is None:
+        y = torch.empty((m, n), dtype=out_dtype, device=a_q.device)
+        tgt, ld, res = y, n, 0
+    else:
+        assert x.shape == (m, n) and x.stride(1) == 1 and x.dtype == torch.bfloat16
+        tgt, ld, res = x, x.stride(0), 1
+    if gate is not None:
+        gate = gate.float().contiguous().reshape(-1)
+        assert gate.numel() == n
+    _timed("td_gemm_w8a8", (m, n, k), lambda: call(
+        "td_gemm_w8a8_stats", ptr(a_q), ptr(a_s), ptr(b_q), ptr(b_s), ptr(bias), ptr(tgt), ptr(gate), res, dt_code(tgt.dtype),
+        m, n, k, ld, ptr(ws), stream_ptr()))
+    return tgt, ws
+
+
+def row_stats_finalize(ws, n, eps, rms=False):
+    """ws f32 [m, pieces, 2] -> LayerNorm (mean, rstd) f32 [m, 2], or (rms=True) the RMSNorm rstd f32 [m]."""
+    require_gpu(ws)
+    m, pieces, _ = ws.shape
+    out = torch.empty((m,) if rms else (m, 2), dtype=torch.float32, device=ws.device)
+    call("td_row_stats_finalize", ptr(ws), pieces, n, float(eps), 1 if rms else 0, ptr(out), m, stream_ptr())
+    return out
+
+
 LNQ_MAX_N = 8192
 
 
-def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0):
+def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, stats=None):
     """LayerNorm (+ affine, + AdaLN modulate) fused with the per-128x128-block INT8 quantiser of the consuming
-    Int8Linear: returns (q int8 [m,n], s f32 [ceil(m/128), ceil(n/128)]) == quant_i8_block128(layernorm(...))."""
+    Int8Linear: returns (q int8 [m,n], s f32 [ceil(m/128), ceil(n/128)]) == quant_i8_block128(layernorm(...)).
+    stats: the rows' (mean, rstd) f32 [m, 2] when the producer of x already supplied them (row_stats_finalize)."""
     require_gpu(x, w, b, scale, shift)
     assert x.is_contiguous() and x.dim() == 2, "Input must be a contiguous 2-D tensor"
     m, n = x.shape
@@ -212,6 +248,11 @@ def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0):
         shift = shift.float().contiguous().reshape(-1, n)
     q = torch.empty((m, n), dtype=torch.int8, device=x.device)
     s = torch.empty((cdiv(m, 128), cdiv(n, 128)), dtype=torch.float32, device=x.device)
+    if stats is not None:
+        assert stats.shape == (m, 2) and stats.dtype == torch.float32 and stats.is_contiguous()
+        call("td_layernorm_quant_stats", ptr(x), dt_code(x.dtype), ptr(w), ptr(b), ptr(scale), ptr(shift), rows_per_batch,
+             ptr(q), ptr(s), ptr(stats), m, n, stream_ptr())
+        return q, s
     ws = torch.empty((m, 2), dtype=torch.float32, device=x.device)   # rows' (mean, rstd) between the two passes
     call("td_layernorm_quant", ptr(x), dt_code(x.dtype), ptr(w), ptr(b), ptr(scale), ptr(shift), rows_per_batch,
          ptr(q), ptr(s), ptr(ws), float(eps), m, n, stream_ptr())

@@ -148,6 +148,7 @@ class WanModel(nn.Module):
         self.fuse_cross_q_norm = True
         self.batch_text_kv = True
         self._ckv_all = None
+        self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
         self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
         self._text_states = {}     # data_ptr -> (key, source tensor, context, [per batch entry: [per block: (k, vt)]])
@@ -229,22 +230,33 @@ class WanModel(nn.Module):
         hq, hs = K.gemm_w8a8_quant(xq, xs, lin1.int8_weight, lin1.scale, dtype, bias=lin1.bias, gelu_tanh=True)
         return K.gemm_w8a8(hq, hs, lin2.int8_weight, lin2.scale, dtype, bias=lin2.bias)
 
-    def _residual_lin_(self, x2, mod, y, gate):
+    def _residual_lin_(self, x2, mod, y, gate, stats=False):
         """x2 += Linear(y) * gate.type_as(x2)  (gate fp32 [B, dim] or None), in place (wan2pt1.py:405-406,412-413).
-        W8A8 and one batch entry: the GEMM's epilogue applies the residual (same bits, one pass less over [L, dim])."""
+        W8A8 and one batch entry: the GEMM's epilogue applies the residual (same bits, one pass less over [L, dim]).
+        stats: also return the LayerNorm statistics (mean, rstd) [L, 2] of the updated rows, from the same epilogue."""
         if isinstance(mod, Int8Linear) and (gate is None or gate.shape[0] == 1):
             yq, ys = y if isinstance(y, tuple) else K.quant_i8_block128(y)
-            return K.gemm_w8a8_residual_(x2, yq, ys, mod.int8_weight, mod.scale, bias=mod.bias, gate=gate)
-        return K.gated_residual_(x2, self._lin(mod, y), gate)
+            if stats:
+                _, ws = K.gemm_w8a8_stats(yq, ys, mod.int8_weight, mod.scale, mod.bias, x=x2, gate=gate)
+                return K.row_stats_finalize(ws, x2.shape[1], self.eps)
+            K.gemm_w8a8_residual_(x2, yq, ys, mod.int8_weight, mod.scale, bias=mod.bias, gate=gate)
+            return None
+        K.gated_residual_(x2, self._lin(mod, y), gate)
+        return None
 
-    def _ffn_residual_(self, x2, lin1, lin2, h, gate):
+    def _ffn_residual_(self, x2, lin1, lin2, h, gate, stats=False):
         """x2 += FFN(h) * gate: Linear -> GELU(tanh) -> Linear with both fusions (epilogue quantiser, epilogue residual)."""
         if isinstance(lin1, Int8Linear) and isinstance(lin2, Int8Linear) and gate.shape[0] == 1:
             xq, xs = h if isinstance(h, tuple) else K.quant_i8_block128(h)
             hq, hs = K.gemm_w8a8_quant(xq, xs, lin1.int8_weight, lin1.scale, x2.dtype, bias=lin1.bias, gelu_tanh=True)
-            return K.gemm_w8a8_residual_(x2, hq, hs, lin2.int8_weight, lin2.scale, bias=lin2.bias, gate=gate)
+            if stats:
+                _, ws = K.gemm_w8a8_stats(hq, hs, lin2.int8_weight, lin2.scale, lin2.bias, x=x2, gate=gate)
+                return K.row_stats_finalize(ws, x2.shape[1], self.eps)
+            K.gemm_w8a8_residual_(x2, hq, hs, lin2.int8_weight, lin2.scale, bias=lin2.bias, gate=gate)
+            return None
         f2 = self._ffn_q(lin1, lin2, h[0], h[1], x2.dtype) if isinstance(h, tuple) else self._ffn(lin1, lin2, h)
-        return K.gated_residual_(x2, f2, gate)
+        K.gated_residual_(x2, f2, gate)
+        return None
 
     def _ffn(self, lin1, lin2, x):
         """Linear -> GELU(tanh) -> Linear (wan2pt1.py:375).  W8A8: the first GEMM's epilogue also block-quantises its
@@ -409,16 +421,28 @@ class WanModel(nn.Module):
         ca = blk.cross_attn
         H, D, dim = self.num_heads, 128, self.dim
         L_ = xn[0].shape[0] if isinstance(xn, tuple) else xn.shape[0]
-        qc = self._lin_q(ca.q, xn[0], xn[1], context.dtype) if isinstance(xn, tuple) else self._lin(ca.q, xn)
+        rstd = None
+        if isinstance(xn, tuple) and self.fuse_cross_q_norm and self._stats_ok(L_):
+            # q projection whose epilogue also yields the RMSNorm statistic of its own output rows (no td_rms_stats pass)
+            qc, ws = K.gemm_w8a8_stats(xn[0], xn[1], ca.q.int8_weight, ca.q.scale, ca.q.bias, out_dtype=context.dtype)
+            rstd = K.row_stats_finalize(ws, dim, self.eps, rms=True)
+        else:
+            qc = self._lin_q(ca.q, xn[0], xn[1], context.dtype) if isinstance(xn, tuple) else self._lin(ca.q, xn)
         k, vt = kvt if kvt is not None else self._text_kvt(i, blk, context, text_kv)
         out = None if quant_out else torch.empty((L_, dim), dtype=context.dtype, device=context.device)
         if self.fuse_cross_q_norm:
             # RMSNorm(q) applied where the attention kernel loads Q: the head-major normalised copy is never written
             # (one statistics pass over q instead of td_qk_norm_rope's read + write; bit-identical)
-            rstd = K.rms_stats(qc, dim, self.eps)
+            if rstd is None:
+                rstd = K.rms_stats(qc, dim, self.eps)
             return K.attn_16_qnorm(qc, rstd, ca.norm_q.weight, k, vt, None, out, D, dim, quant_out=quant_out)
         q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
         return K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
+
+    def _stats_ok(self, rows):
+        """Row statistics from the GEMM epilogues: W8A8 bf16 model, fused norm->INT8 path, rows worth a 256x256-tile GEMM."""
+        return (self.fuse_row_stats and self.fuse_norm_quant and self.quant_linear and self.dtype == torch.bfloat16
+                and self.dim % 64 == 0 and self.dim <= K.LNQ_MAX_N and rows >= 1024)
 
     def _block(self, i, blk, x, e_B_6_D, cos, sin, context, tkv=None, kvts=None):
         """x: [B, L_loc, dim] (updated in place); e fp32 [B, 6, dim] = this block's modulation + e0 (wan2pt1.py:400,
@@ -433,20 +457,22 @@ class WanModel(nn.Module):
         fuse = self.fuse_norm_quant and self.quant_linear and dim <= K.LNQ_MAX_N
         rows = [slice(b * L_loc, (b + 1) * L_loc) for b in range(B)]
         # ---- self attention ----
+        fstats = fuse and B == 1 and self._stats_ok(L_loc)   # LayerNorm statistics ride on the GEMM that produced x
+        st1, self._carry_stats = getattr(self, "_carry_stats", None), None
         if fuse:
             hs_ = [K.layernorm_quant(x2[r], None, None, self.eps, scale=ec[1][b:b + 1], shift=ec[0][b:b + 1],
-                                     rows_per_batch=L_loc) for b, r in enumerate(rows)]
+                                     rows_per_batch=L_loc, stats=st1 if fstats else None) for b, r in enumerate(rows)]
         else:
             h = K.layernorm(x2, None, None, self.eps, scale=ec[1], shift=ec[0], rows_per_batch=L_loc)
             hs_ = [h[r] for r in rows]
         qo = self.quant_linear and B == 1 and self.seq_parallel is None  # attention epilogue quantises for the o proj
         ys = [self._self_attention(i, blk, hb, cos, sin, L_loc, dt, quant_out=qo) for hb in hs_]
         y = ys[0] if B == 1 else torch.cat(ys, 0)
-        self._residual_lin_(x2, blk.self_attn.o, y, ec[2])
+        st3 = self._residual_lin_(x2, blk.self_attn.o, y, ec[2], stats=fstats)
         # ---- cross attention ----
         if isinstance(blk.norm3, FastLayerNorm):
             if fuse:
-                xns = [K.layernorm_quant(x2[r], blk.norm3.weight, blk.norm3.bias, self.eps) for r in rows]
+                xns = [K.layernorm_quant(x2[r], blk.norm3.weight, blk.norm3.bias, self.eps, stats=st3) for r in rows]
             else:
                 xn = K.layernorm(x2, blk.norm3.weight, blk.norm3.bias, self.eps)
                 xns = [xn[r] for r in rows]
@@ -456,13 +482,13 @@ class WanModel(nn.Module):
                                     text_kv=None if tkv is None else tkv[b],
                                     kvt=None if kvts is None else kvts[b][i]) for b in range(B)]
         c = cs[0] if B == 1 else torch.cat(cs, 0)
-        self._residual_lin_(x2, blk.cross_attn.o, c, None)
+        st2 = self._residual_lin_(x2, blk.cross_attn.o, c, None, stats=fstats)
         # ---- FFN ----
         if fuse:
-            h2 = K.layernorm_quant(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
+            h2 = K.layernorm_quant(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc, stats=st2)
         else:
             h2 = K.layernorm(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
-        self._ffn_residual_(x2, blk.ffn[0], blk.ffn[2], h2, ec[5])
+        self._carry_stats = self._ffn_residual_(x2, blk.ffn[0], blk.ffn[2], h2, ec[5], stats=fstats)   # -> next block's norm1
         return x
 
     # ------------------------------------------------------------------ forward
@@ -521,6 +547,7 @@ class WanModel(nn.Module):
         if mods is None or mods[1] != ver:
             mods = self._fused["mods"] = (torch.stack([blk.modulation.detach().float() for blk in self.blocks], 0), ver)
         e_all = mods[0] + e0.unsqueeze(0)                    # fp32 [nblk, B, 6, dim]
+        self._carry_stats = None
         tap = getattr(self, "_tap_tokens", None)   # tools/drift.py: list that receives the tokens after every block
         for i, blk in enumerate(self.blocks):
             x = self._block(i, blk, x, e_all[i], cos, sin, context, tkv, kvts)
