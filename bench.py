@@ -393,11 +393,11 @@ def main():
                 by += H * qb * (128 * 128 * 1 + ns * 64 * 128 * 3 + 128 * 128 * 2)
                 half = 2.0 * H * qb * 128 * ns * 64 * 128            # FLOPs of QK^T = FLOPs of PV
                 fl += 2 * half
-                mt += half / I8_PEAK + half / F16_PEAK
+                mt += half / I8_PEAK + half / (I8_PEAK if args.sage_pv == "fp8" else F16_PEAK)   # fp8 MFMA = the int8 rate
             by, mt, fl = by / a["launches"], mt / a["launches"], fl / a["launches"]
             t_l = a["avg_ms"] * 1e-3
-            roof_attn = {"kernel": "attn_kernel<int8 QK, fp16 PV>", "bound": "mfma",
-                         "achieved": fl / t_l / 1e12, "peak": fl / mt / 1e12, "unit": "TFLOP/s (int8 QK^T + fp16 PV, harmonic)",
+            roof_attn = {"kernel": f"attn_kernel<int8 QK, {args.sage_pv} PV>", "bound": "mfma",
+                         "achieved": fl / t_l / 1e12, "peak": fl / mt / 1e12, "unit": f"TFLOP/s (int8 QK^T + {args.sage_pv} PV, harmonic)",
                          "frac": mt / t_l, "traffic": pmc_traffic(("attn_kernel<true",)),
                          "traffic_unit": "B/launch (HBM-side fetch+write, PMC)",
                          "streamed_bytes": by, "streamed_GBps": by / t_l / 1e9,
