@@ -57,11 +57,13 @@ const char* td_last_error(void);
 
 /* Kernel-selection knobs for benchmarking (results never depend on them: every variant of an
  * operator is bit-identical).  value 0 = automatic. */
-#define TD_TUNE_GEMM_VARIANT 0 /* 1 = 128x128-tile kernel, 2 = 256x256-tile LDS-DMA kernel, 3 = 256x256 ping-pong, 4 = 256x256 fine-interleaved */
-#define TD_TUNE_GEMM_ABLATE 1  /* profiling only, WRONG results: 1 no dequant, 2 no MFMA, 3 no LDS-DMA */
+#define TD_TUNE_GEMM_VARIANT 0 /* 1 = 128x128-tile kernel (default for m < 1024), 4 = 256x256 fine-interleaved on 16x16x64 MFMA (default),
+                                  5 = the same pipeline on 32x32x32 MFMA (carries the opt-in fast dequant / schedules); all exact variants are bit-identical */
+#define TD_TUNE_GEMM_ABLATE 1  /* profiling instantiations only (s_memtime traces / phase stamps: 6, 9, 16, 19; tools/gemm_*.py) */
 #define TD_TUNE_GEMM_LDPAD 2   /* profiling only: int8 operand row stride = k + value (buffers must be that large) */
 #define TD_TUNE_GEMM_GROUP_M 3 /* m-tiles per raster group of the 256x256 kernels (0 = default 4) */
-#define TD_TUNE_GEMM_SCHED 4   /* v4: 1 = LDS-DMA of the next stage right after the barrier, 2 = L2 prefetch */
+#define TD_TUNE_GEMM_SCHED 4   /* variant 5: bit 0 = barrier one chain earlier + refill spread over two chains, bit 1 = s_setprio for the
+                                  younger half-workgroup (bit-identical results); variant 4: 1 = early LDS-DMA, 2 = L2 prefetch */
 #define TD_TUNE_ATTN_TAU 5     /* attention: lazy running-max threshold in log2 units (0 = default 8, -1 = eager online softmax) */
 #define TD_TUNE_GEMM_FAST 6     /* W8A8 GEMM dequant: 0 = build default, 1 = exact (bit-identical to the reference arithmetic),
                                   G in {2,4,8} = one-VALU dequant re-centred every G K blocks (|diff| <= 0.75 (G+1) sum_k s_k) */

@@ -73,7 +73,7 @@ def test_gemm_w8a8(K, m, n, k, bias, gelu):
                                    (9000, 2304, 256)])
 @pytest.mark.parametrize("bias,gelu", [(False, False), (True, True)])
 def test_gemm_variants_bit_identical(K, m, n, k, bias, gelu):
-    """128x128-tile kernel, the four 256x256-tile LDS-DMA kernels and the oracle: same bits (ragged M and N tails)."""
+    """128x128-tile kernel, the two 256x256-tile LDS-DMA kernels (16x16x64 and 32x32x32 MFMA) and the oracle: same bits (ragged M and N tails)."""
     g = torch.Generator().manual_seed(m + n + k)
     xq = torch.randint(-128, 128, (m, k), generator=g, dtype=torch.int8)
     wq = torch.randint(-128, 128, (n, k), generator=g, dtype=torch.int8)
@@ -81,7 +81,7 @@ def test_gemm_variants_bit_identical(K, m, n, k, bias, gelu):
     ws = torch.rand((n + 127) // 128, k // 128, generator=g) * 0.02 + 1e-3
     b = (torch.randn(n, generator=g) * 0.1).to(torch.bfloat16) if bias else None
     outs = []
-    for var in (1, 2, 3, 4, 5):
+    for var in (1, 4, 5):
         K.set_tuning(K.TUNE_GEMM_VARIANT, var)
         try:
             outs.append(K.gemm_w8a8(xq.to(DEV), xs.to(DEV), wq.to(DEV), ws.to(DEV), torch.bfloat16,

@@ -199,7 +199,6 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
              "td_gemm_w8a8: epilogue %d", epilogue);
   if (m == 0 || n == 0) return TD_OK;
   hipStream_t st = (hipStream_t)stream;
-  // large problems: 256x256 LDS-DMA kernel (gemm_w8a8_256.hip), bit-identical results
   const int variant = td_tuning(TD_TUNE_GEMM_VARIANT);
   // large problems: the fine-interleaved 256x256 LDS-DMA kernel (gemm_w8a8_fi.hip); every variant is bit-identical
   if (variant == 4 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0)) {
@@ -210,12 +209,8 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
     TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 5 needs ldd %% 8 == 0");
     return td_gemm_w8a8_m32(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
   }
-  if (variant == 3) {
-    TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 3 needs ldd %% 8 == 0");
-    return td_gemm_w8a8_pp(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
-  }
-  if (variant == 2)
-    return td_gemm_w8a8_256(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
+  TD_REQUIRE(variant != 2 && variant != 3, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8: kernel variants 2 / 3 (round-1 256x256 and ping-pong kernels) were removed; use 1, 4 or 5");
 #define TD_GEMM_CASE(ODT)                                                                          \
   if (epilogue == TD_EPI_GELU_TANH) {                                                              \
     return bias ? launch_gemm<ODT, TD_EPI_GELU_TANH, true>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st) \

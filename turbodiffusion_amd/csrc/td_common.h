@@ -40,9 +40,6 @@ int td_tuning(int key);
 int td_gemm_fast_g(void);                  // resolved TD_TUNE_GEMM_FAST: 0 = exact dequant, else the recentring period G
 unsigned long long* td_dbg_buffer(void);  // 256 x u64 device scratch for the DBG kernel instantiations
 // internal kernel entry points shared between translation units
-int td_gemm_w8a8_pp(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
-                    const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
-                    int64_t k, int64_t ldd, hipStream_t st);
 int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                     const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
                     int64_t k, int64_t ldd, hipStream_t st);
@@ -64,9 +61,6 @@ int td_gemm_w8a8_m32_q(const int8_t* a, const float* a_s, const int8_t* b, const
 int td_gemm_w8a8_m32_res(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
                          void* x, const float* gate, int dtype, int64_t m, int64_t n, int64_t k, int64_t ldx,
                          hipStream_t st);
-int td_gemm_w8a8_256(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
-                     const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
-                     int64_t k, int64_t ldd, hipStream_t st);
 
 __host__ __device__ static inline int64_t td_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
