@@ -256,7 +256,8 @@ def main():
         key, val = kv.split("=")
         assert hasattr(net, key), key
         setattr(net, key, bool(int(val)) if val.isdigit() else val)
-    use_graph = (sp == 1) and not args.no_graph  # (the RCCL all-gathers of a sequence-parallel step stay eager)
+    # sp > 1: the forward is a chain of graph segments with the RCCL all-gathers re-issued eagerly between them (graph.py)
+    use_graph = not args.no_graph
     run_net, run_low = net, net_low
     if use_graph:
         from turbodiffusion_amd.graph import GraphedModel
@@ -428,8 +429,10 @@ def main():
                            f"dp{dp} x sp{sp}: {dp} independent videos, each sharded by sequence over {sp} GPUs "
                            f"(RCCL all-gather of the quantised K/V per layer)" if sp > 1 else f"dp{dp}: {dp} independent videos")},
             "roofline": roof, "roofline_attention": roof_attn,
-            "launch_mode": ("hipGraph replay, one graph per DiT forward; kernel events from one eager video after "
-                            "the timed region" if use_graph else "eager enqueue; kernel events inside the timed region"),
+            "launch_mode": (("hipGraph replay, one graph per DiT forward" if sp == 1 else
+                             "hipGraph replay in segments, the all-gathers issued eagerly between them") +
+                            "; kernel events from one eager video after the timed region"
+                            if use_graph else "eager enqueue; kernel events inside the timed region"),
         }
         if eager_elapsed is not None:
             res["eager_videos_per_s"] = 1.0 / eager_elapsed

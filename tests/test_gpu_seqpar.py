@@ -59,3 +59,49 @@ def test_seqpar_world2_on_gpu_matches_single_rank(attention):
     # not bit-identical: per-rank activation quantisation blocks start at rank boundaries and the global reductions
     # (smooth-K mean, linear-branch sums) are summed per rank first — same arithmetic class, stated tolerance
     assert ret["rel"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
+
+
+def _graph_worker(rank, world, port, attention, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import wan_ref as W
+        from tests.test_gpu_wan import make_net
+        from turbodiffusion_amd import seqpar
+        from turbodiffusion_amd.graph import GraphedModel
+        gold = torch.load(GOLD, weights_only=False)
+        cfg = gold["cfg"]
+        sd = W.make_state_dict(cfg, gold["sd_seed"])
+        net = make_net(cfg, sd, attention, True, topk=0.5)
+        g = torch.Generator().manual_seed(17)
+        xs = [torch.randn(1, 16, 5, 16, 24, generator=g).to("cuda").bfloat16() for _ in range(2)]
+        ctx = gold["ctx"].to("cuda").bfloat16()
+        ts = [gold["t"].to("cuda").bfloat16(), (gold["t"] * 0.5).to("cuda").bfloat16()]
+        seqpar.enable(net, dist.group.WORLD)
+        eager = [net(x, t, ctx).clone() for x, t in zip(xs, ts)]
+        gm = GraphedModel(net)
+        outs = [gm(x, t, ctx).clone() for x, t in zip(xs, ts)]          # first call captures, both replay
+        outs.append(gm(xs[0], ts[0], ctx).clone())                       # and back to the first input
+        rec = next(iter(gm._graphs.values()))[0]
+        if rank == 0:
+            ret["segments"] = rec.n_segments
+            ret["eager_points"] = len(rec.chain) - rec.n_segments
+            ret["same"] = [bool(torch.equal(outs[0], eager[0])), bool(torch.equal(outs[1], eager[1])),
+                           bool(torch.equal(outs[2], eager[0]))]
+            ret["differ"] = not torch.equal(eager[0], eager[1])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("attention", ["sagesla", "sage"])
+def test_seqpar_segmented_graph_replay_is_bit_identical_to_eager(attention):
+    """graph.SegmentRecorder: the sequence-parallel forward replayed as hipGraph segments with the all-gathers re-issued
+    between them gives the bits of the eager forward — for the captured inputs, for new inputs, and again for the first."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_graph_worker, args=(2, _free_port(), attention, ret), nprocs=2, join=True)
+    assert ret["differ"] and all(ret["same"]), dict(ret)
+    layers = 2
+    assert ret["segments"] >= 2 * layers + 1 and ret["eager_points"] >= 2 * layers + 1, dict(ret)

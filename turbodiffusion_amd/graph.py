@@ -9,13 +9,87 @@ buffers, the output is the graph's static output tensor (cloned, so the caller o
 
 The captured work is exactly the eager work: every C-ABI entry point launches on torch's *current*
 stream, which during capture is the capturing stream; outputs are allocated from the graph's private pool.
-Not used with sequence parallelism (the RCCL all-gathers stay eager).
+
+Sequence parallelism (``seqpar``): a forward then contains collectives (RCCL all-gathers and the waits for them).  They are
+NOT captured; the forward becomes a chain of graph SEGMENTS with the collectives re-issued eagerly between them
+(``SegmentRecorder``): ``seqpar`` wraps every collective / wait in ``eager_point(fn)``; while a recorder is capturing, that
+ends the current segment, runs ``fn`` for real, remembers it and opens the next segment; a replay walks the recorded chain
+(graph.replay() / fn()) in the same order.  All segments share one memory pool (legal because they are always replayed in
+capture order), so a tensor produced in one segment and consumed after the collective stays where it was.  Without this a
+rank of an 8-way split spends longer enqueueing its ~1100 launches from Python than the GPU spends executing them.
 """
 from __future__ import annotations
 
 from typing import Optional
 
 import torch
+
+
+_ACTIVE = None   # the SegmentRecorder that is capturing on this thread, if any
+
+
+def eager_point(fn):
+    """Run ``fn()`` now; if a segmented capture is in progress, outside of it (and again at this point of every replay).
+    ``fn`` must only touch tensors that stay alive (closure) — it is called again with the same objects."""
+    rec = _ACTIVE
+    if rec is None:
+        return fn()
+    return rec._eager(fn)
+
+
+class SegmentRecorder:
+    """A forward captured as graph segments separated by eager points (see module docstring)."""
+
+    def __init__(self):
+        self.chain = []          # ("graph", CUDAGraph) | ("eager", fn)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.stream = torch.cuda.Stream()
+        self._g = None
+
+    def _begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def _end(self):
+        self._g.capture_end()
+        self.chain.append(("graph", self._g))
+        self._g = None
+
+    def _eager(self, fn):
+        self._end()
+        out = fn()
+        self.chain.append(("eager", fn))
+        self._begin()
+        return out
+
+    def capture(self, fn):
+        """Run ``fn()`` once in capture mode (kernels are recorded, not executed; eager points execute) -> fn's result
+        (static tensors: valid after every ``replay``)."""
+        global _ACTIVE
+        assert _ACTIVE is None, "nested segmented capture"
+        torch.cuda.synchronize()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self._begin()
+            _ACTIVE = self
+            try:
+                out = fn()
+            finally:
+                _ACTIVE = None
+                self._end()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return out
+
+    def replay(self):
+        for kind, item in self.chain:
+            if kind == "graph":
+                item.replay()
+            else:
+                item()
+
+    @property
+    def n_segments(self):
+        return sum(1 for k, _ in self.chain if k == "graph")
 
 
 class GraphedModel(torch.nn.Module):
@@ -33,7 +107,7 @@ class GraphedModel(torch.nn.Module):
     @torch.no_grad()
     def forward(self, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, frame_cond_crossattn_emb_B_L_D=None,
                 y_B_C_T_H_W: Optional[torch.Tensor] = None, **kwargs):
-        if frame_cond_crossattn_emb_B_L_D is not None or getattr(self.net, "seq_parallel", None) is not None:
+        if frame_cond_crossattn_emb_B_L_D is not None:
             return self.net(x_B_C_T_H_W, timesteps_B_T, crossattn_emb,
                             frame_cond_crossattn_emb_B_L_D=frame_cond_crossattn_emb_B_L_D,
                             y_B_C_T_H_W=y_B_C_T_H_W, **kwargs)
@@ -67,9 +141,14 @@ class GraphedModel(torch.nn.Module):
                 self.net(sx, st, sc, y_B_C_T_H_W=sy)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                so = self.net(sx, st, sc, y_B_C_T_H_W=sy)
+            if getattr(self.net, "seq_parallel", None) is not None:
+                # segments between the collectives (identical chain on every rank: the eager points are collective calls)
+                g = SegmentRecorder()
+                so = g.capture(lambda: self.net(sx, st, sc, y_B_C_T_H_W=sy))
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    so = self.net(sx, st, sc, y_B_C_T_H_W=sy)
             text_ptr = self.net.prepare_text(sc)[2].data_ptr() if cache_text else 0
             ent = (g, sx, st, sc, sy, so, text_ptr)
             self._graphs[key] = ent

@@ -29,9 +29,38 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from .graph import eager_point
+
 
 def _cdiv(a, b):
     return (a + b - 1) // b
+
+
+class _Gather:
+    """One all-gather on fixed buffers: ``issue()`` / ``wait()`` may be called again (graph replay) — same tensors."""
+
+    def __init__(self, group, out, src, async_op):
+        self.group, self.out, self.src, self.async_op = group, out, src, async_op
+        self.work = None
+        # single-GPU test rig (several ranks on one device, tests/test_gpu_seqpar.py): gloo gathers host memory
+        self.via_host = src.is_cuda and dist.get_backend(group) == "gloo"
+
+    def issue(self):
+        if self.via_host:
+            host = torch.empty(self.out.shape, dtype=self.out.dtype)
+            dist.all_gather_into_tensor(host.view(-1), self.src.cpu(), group=self.group)
+            self.out.copy_(host)
+        else:
+            self.work = dist.all_gather_into_tensor(self.out.view(-1), self.src, group=self.group, async_op=self.async_op)
+
+    def _wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def wait(self):
+        if self.async_op and not self.via_host:
+            eager_point(self._wait)
 
 
 class SeqParallel:
@@ -65,20 +94,14 @@ class SeqParallel:
         return x[:, s:e].contiguous(), cos[s:e].contiguous(), sin[s:e].contiguous()
 
     def all_gather(self, t: torch.Tensor, async_op: bool = False):
-        """[...] -> [world, ...] (rank-major).  ``async_op``: returns (out, work); with RCCL the gather runs on the
-        communicator's own stream and ``work.wait()`` makes the compute stream wait for it, so kernels enqueued in
-        between overlap the transfer."""
+        """[...] -> [world, ...] (rank-major).  ``async_op``: returns (out, handle); with RCCL the gather runs on the
+        communicator's own stream and ``handle.wait()`` makes the compute stream wait for it, so kernels enqueued in
+        between overlap the transfer.  Both the issue and the wait are ``graph.eager_point``s: under a segmented hipGraph
+        capture they stay outside the graphs and are re-issued on the same buffers at every replay."""
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        work = None
-        if t.is_cuda and dist.get_backend(self.group) == "gloo":
-            # single-GPU test rig (two ranks on one device, tests/test_gpu_seqpar.py): gloo gathers host memory
-            host = torch.empty(out.shape, dtype=t.dtype)
-            dist.all_gather_into_tensor(host.view(-1), t.contiguous().view(-1).cpu(), group=self.group)
-            out.copy_(host)
-        else:
-            work = dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group,
-                                               async_op=async_op)
-        return (out, work) if async_op else out
+        h = _Gather(self.group, out, t.contiguous().view(-1), async_op)
+        eager_point(h.issue)
+        return (out, h) if async_op else out
 
     def gather_tokens(self, out_loc, L):
         """[B, L_loc, C] -> [B, L, C] on every rank (cat_outputs_cp)."""
@@ -168,7 +191,7 @@ class SeqParallel:
                 slot("kss", torch.float32, (Hg, D)).copy_(ks32[h0:h1])
             allb, work = self.all_gather(pack, async_op=True)  # [W, bytes]
             inflight.append((h0, h1, sizes, offs, allb, work))
-            if g == 0:  # the Q side of this rank (all heads) is prepared under the first transfers
+            if g == n_groups - 1:  # the Q side of this rank (all heads) is prepared under the transfers
                 if sage:
                     pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
                 elif not dense:
@@ -179,8 +202,7 @@ class SeqParallel:
 
         topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
         for (h0, h1, sizes, offs, allb, work) in inflight:
-            if work is not None:
-                work.wait()
+            work.wait()
             Hg = h1 - h0
 
             def gathered(name, dtype, shape, allb=allb, sizes=sizes, offs=offs):  # [W, *shape] strided VIEW (no copy)
