@@ -321,6 +321,25 @@ int td_sla_linear_out(const void* q, int dtype, const void* kvsum_t, const void*
 int td_sla_linear_out_t(const void* q, int dtype, const void* kvsum_t, const void* ksum, const float* wp,
                         const float* bp, void* t_out, int64_t L, int H, int D, td_stream_t stream);
 
+
+/* ---- sequence parallelism, producer side: write straight into the all-gather's send buffer ("pack") ----
+ * The K-side state a rank sends per self-attention layer (seqpar.py; reference exchange: rcm/utils/a2a_cp.py:146-182) is
+ * ONE buffer [groups][section][heads_per_group][...]: a group of heads is one contiguous range = one all-gather, so that
+ * attention on the first heads runs under the later groups' transfers.  The *_packed entry points are the flat ones above
+ * with the per-head OUTPUT (td_sla_linear_kv_partial_packed: the vt INPUT) placement generalised: head h of a section lives
+ * at  section_base + (h / hg) * gs_bytes + (h % hg) * (that section's per-head bytes at L_alloc rows);  L_alloc >= L rows
+ * (and ceil(L_alloc/blk) blocks, ceil(L_alloc/64) V^T tiles) are ALLOCATED per head — the rank-padded shard size — while L
+ * rows are produced.  hg = 0 (with gs_bytes = 0, L_alloc = L) is exactly the flat call.  H % hg == 0; gs_bytes % 16 == 0. */
+int td_sage_quant_pool_packed(const void* x, const void* km, int dtype, int pool_blk, void* pooled, int8_t* xq, float* xs,
+                              int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes, int H, int D, td_stream_t stream);
+int td_v_transpose_packed(const void* v, int in_dtype, int64_t stride_h, int64_t stride_l, void* vt, int out_dtype,
+                          int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes, int H, int D, td_stream_t stream);
+int td_sla_linear_kv_partial_packed(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv, float* ws_ks,
+                                    int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes, int H, int D, td_stream_t stream);
+int td_sla_linear_kv_final_packed(const float* ws_kv, const float* ws_ks, int nch, int64_t kv_stride_h, int64_t kv_stride_c,
+                                  int64_t ks_stride_h, int64_t ks_stride_c, void* kv_out, void* ks_out, int out_dtype, int hg,
+                                  int64_t gs_bytes, int H, int D, td_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

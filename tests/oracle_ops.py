@@ -175,3 +175,30 @@ def attn_i8_sp(q_i8, q_s, k_g, ks_g, vt_g, lut, out, o_stride_h, o_stride_l, lk,
 def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
     return attn_16(q, _seq_major(k_g), _seq_major(vt_g), lut, out, o_stride_h, o_stride_l, sm_scale=sm_scale, lk=lk,
                    add_t=add_t)
+
+
+def sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay):
+    """CPU stand-in of kernels.sp_pack_k_side: the flat oracle results copied into the sections of the send buffer."""
+    H, _, D = k.shape
+    kb_loc = -(-L_loc // 64)
+    pack = torch.zeros((lay.G, lay.gb), dtype=torch.uint8)
+
+    def put(name, t, n):   # t [H, n_valid, ...] -> section [G, hg, n_alloc, ...][:, :, :n]
+        lay.section(pack, name)[:, :, :n] = t.reshape((lay.G, lay.hg) + tuple(t.shape[1:]))
+
+    vt = v_transpose(v_src, v_strides[0], v_strides[1], L_loc, H, D, lay.pdt)
+    put("vt", vt, kb_loc)
+    if lay.sage:
+        pk, k_q, k_s = sage_quant_pool(k, km, 64, want_pool=not lay.dense)
+        put("k", k_q, L_loc)
+        put("ks", k_s, kb_loc)
+    else:
+        put("k", k, L_loc)
+        pk = sage_quant_pool(k, km, 64, want_quant=False)[0] if not lay.dense else None
+    if not lay.dense:
+        put("pk", pk, kb_loc)
+    if lay.linear:
+        kv32, ks32 = sla_linear_kv_partial_f32(k, vt)
+        lay.section(pack, "kv").copy_(kv32.reshape(lay.G, lay.hg, D, D))
+        lay.section(pack, "kss").copy_(ks32.reshape(lay.G, lay.hg, D))
+    return pack

@@ -485,3 +485,42 @@ def test_gathered_layout_kernels_are_bit_identical_to_flat(K, sage):
         K.attn_16(qd, kd, vt, None, d_flat, L * 128, 128)
         K.attn_16_sp(qd, kg, vtg, None, d_g, L * 128, 128, L)
     assert torch.equal(d_g, d_flat)
+
+
+@pytest.mark.parametrize("sage,dense", [(True, False), (True, True), (False, False), (False, True)])
+@pytest.mark.parametrize("L_loc,per", [(512, 512), (440, 512)])
+def test_sp_pack_k_side_is_bit_identical_to_flat_producers(K, sage, dense, L_loc, per):
+    """kernels.sp_pack_k_side (the *_packed entry points: producers write straight into the all-gather send buffer, heads
+    grouped two-level, rows padded to the rank's shard size) holds exactly the bits of the flat producers — a full shard and
+    the short last rank; 6 heads = 3 groups of 2."""
+    from turbodiffusion_amd.seqpar import PackLayout
+    H, D = 6, 128
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(L_loc + 2 * sage + dense)
+    k = (torch.randn(H, L_loc, D, generator=g) + 0.5).to(dt).cuda()
+    v = torch.randn(L_loc, H * D, generator=g).to(dt).cuda()              # element (h,l,d) at h*D + l*H*D + d
+    km = K.seq_mean(k) if (sage or not dense) else None
+    lay = PackLayout(H, per, D, 4, sage, dense, dt)
+    assert (lay.G, lay.hg) == (3, 2)
+    pack = K.sp_pack_k_side(k, km, v, (D, H * D), L_loc, lay)
+    assert pack.shape == (lay.G, lay.gb) and pack.dtype == torch.uint8
+    kb = -(-L_loc // 64)
+
+    def sec(name, n):
+        return lay.section(pack, name)[:, :, :n].reshape((H, n) + lay.spec[name][1][2:])
+
+    vt = K.v_transpose(v, D, H * D, L_loc, H, D, lay.pdt)
+    assert torch.equal(sec("vt", kb), vt)
+    if sage:
+        pk, k_q, k_s = K.sage_quant_pool(k, km, 64, want_pool=not dense)
+        assert torch.equal(sec("k", L_loc), k_q) and torch.equal(sec("ks", kb), k_s)
+    else:
+        assert torch.equal(sec("k", L_loc), k)
+        pk = K.sage_quant_pool(k, km, 64, want_quant=False)[0] if not dense else None
+    if not dense:
+        assert torch.equal(sec("pk", kb), pk)
+        kv32, ks32 = K.sla_linear_kv_partial_f32(k, vt)
+        assert torch.equal(lay.section(pack, "kv").reshape(H, D, D), kv32)
+        assert torch.equal(lay.section(pack, "kss").reshape(H, D), ks32)
+    if L_loc < per:   # the padding of a short rank is zero (never read as valid, but must be finite)
+        assert int(lay.section(pack, "vt")[:, :, kb:].abs().sum()) == 0

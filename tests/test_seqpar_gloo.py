@@ -85,8 +85,8 @@ def test_seqpar_world2_matches_single_rank(at, L, ratio):
 
 
 @pytest.mark.parametrize("world,at,L,ratio,H", [(4, "sagesla", 900, 0.3, 2),      # 8 Q blocks: 256, 256, 256, 132 tokens
-                                                 (8, "sagesla", 1970, 0.25, 5),    # 16 Q blocks: 7 x 256 + a 178-token tail rank;
-                                                                                   # 5 heads over 4 head groups (uneven groups)
+                                                 (8, "sagesla", 1970, 0.25, 6),    # 16 Q blocks: 7 x 256 + a 178-token tail rank;
+                                                                                   # 6 heads: 3 groups of 2 (largest divisor <= 4)
                                                  (8, "sage", 1100, 1.0, 1)])       # 9 Q blocks, per = 256: ranks 5-7 would be empty
 def test_seqpar_world4_and_world8(world, at, L, ratio, H):
     """The rank-padded gathered layout, the packed exchange and the head-group pipeline at world sizes 4 and 8 (gloo,
@@ -136,3 +136,21 @@ def test_plan_covers_all_tokens_block_aligned():
             assert spans[0][0] == 0 and spans[-1][1] == L
             for (a0, a1), (b0, b1) in zip(spans[:-1], spans[1:]):
                 assert a1 == b0 and a0 % 128 == 0 and b0 % 128 == 0
+
+
+def test_pack_layout_groups_and_alignment():
+    """PackLayout: equal head groups (largest divisor of H not above head_groups), 256-byte aligned sections, and the
+    section views address disjoint byte ranges of a group."""
+    import torch
+    from turbodiffusion_amd.seqpar import PackLayout
+    for H, want in ((12, 4), (40, 4), (6, 3), (5, 1), (2, 2), (1, 1)):
+        lay = PackLayout(H, 256, 128, 4, True, False, torch.bfloat16)
+        assert lay.G == want and lay.hg * lay.G == H
+        assert all(o % 256 == 0 for o in lay.offs.values()) and lay.gb % 256 == 0
+        ends = sorted((lay.offs[n], lay.offs[n] + lay.sizes[n]) for n in lay.sizes if lay.sizes[n])
+        assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])) and ends[-1][1] <= lay.gb
+        buf = torch.zeros((lay.G, lay.gb), dtype=torch.uint8)
+        assert lay.section(buf, "vt").shape == (lay.G, lay.hg, 4, 128, 64) and lay.section(buf, "vt").dtype == torch.float16
+        assert lay.section(buf, "k").dtype == torch.int8 and lay.section(buf, "kv").shape == (lay.G, lay.hg, 128, 128)
+    dense = PackLayout(12, 256, 128, 4, False, True, torch.bfloat16)     # "original": 16-bit K, no scales / pooled / partials
+    assert dense.sizes["ks"] == dense.sizes["pk"] == dense.sizes["kv"] == 0 and dense.spec["k"][0] == torch.bfloat16

@@ -62,6 +62,10 @@ SIGNATURES = {
     "td_sla_linear_out_t": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_kv_partial": [_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_kv_final": [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _i32, _vp],
+    "td_sage_quant_pool_packed": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, _i32, _vp],
+    "td_v_transpose_packed": [_vp, _i32, _i64, _i64, _vp, _i32, _i64, _i64, _i32, _i64, _i32, _i32, _vp],
+    "td_sla_linear_kv_partial_packed": [_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i64, _i32, _i64, _i32, _i32, _vp],
+    "td_sla_linear_kv_final_packed": [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp],
     "td_sla_linear_kv": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_out": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
 }

@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
                                                                 float* __restrict__ ws_kv,
                                                                 float* __restrict__ ws_ks,
                                                                 float* __restrict__ ws_km, int64_t L,
-                                                                int Kb) {
+                                                                int Kb, int Kb_alloc, int hg, int64_t gs) {
+  // vt may live in the sequence-parallel pack (td_head_off, td_common.h): Kb_alloc tiles allocated per head, (hg, gs)
   __shared__ __attribute__((aligned(16))) char ckT[128 * 128];  // [d1][64 positions] 16-bit
   __shared__ __attribute__((aligned(16))) char vT[128 * 128];   // [d2][64 positions] 16-bit
   __shared__ float ksred[16][128];
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
   for (int i = 0; i < 4; ++i) {
     vv[i] = make_uint4(0, 0, 0, 0);
     if (kb_lo < kb_hi)
-      vv[i] = *reinterpret_cast<const uint4*>(vt + ((int64_t)h * Kb + kb_lo) * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
+      vv[i] = *reinterpret_cast<const uint4*>(vt + td_head_off(h, hg, gs, (int64_t)Kb_alloc * (128 * 64)) + (int64_t)kb_lo * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
     if (more) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        vv[i] = *reinterpret_cast<const uint4*>(vt + ((int64_t)h * Kb + kb + 1) * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
+        vv[i] = *reinterpret_cast<const uint4*>(vt + td_head_off(h, hg, gs, (int64_t)Kb_alloc * (128 * 64)) + (int64_t)(kb + 1) * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
     }
     // softmax over D (16 lanes share a row), rounded to KDT; ck[t][j]
     float ck[4][8];
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __res
                                                               const float* __restrict__ ws_ks, int nch,
                                                               int64_t kv_sh, int64_t kv_sc, int64_t ks_sh,
                                                               int64_t ks_sc, void* __restrict__ kv_out,
-                                                              void* __restrict__ ks_out) {
+                                                              void* __restrict__ ks_out, int hg, int64_t gs) {
+  // (hg, gs in output elements): the outputs may live in the sequence-parallel pack (td_head_off, td_common.h)
   // 64 workgroups per head, one kv element per thread; the partials are summed in a fixed tree (four interleaved
   // running sums, then ((s0+s1)+(s2+s3))) with four loads in flight: deterministic, and not a chain of nch latencies
   const int h = blockIdx.x, part = blockIdx.y;
@@ -239,9 +241,9 @@ __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __res
     const float s = (s0 + s1) + (s2 + s3);
     if constexpr (ROUND) {
       const int d1 = i >> 7, d2 = i & 127;
-      ((uint16_t*)kv_out)[(int64_t)h * 128 * 128 + d2 * 128 + d1] = (uint16_t)f32_to_half_bits<DT>(s);
+      ((uint16_t*)kv_out)[td_head_off(h, hg, gs, 128 * 128) + d2 * 128 + d1] = (uint16_t)f32_to_half_bits<DT>(s);
     } else {
-      ((float*)kv_out)[(int64_t)h * 128 * 128 + i] = s;  // fp32, NOT transposed: still a partial
+      ((float*)kv_out)[td_head_off(h, hg, gs, 128 * 128) + i] = s;  // fp32, NOT transposed: still a partial
     }
   }
   if (part == 0 && threadIdx.x < 128) {
@@ -256,23 +258,26 @@ __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __res
     }
     for (; c < nch; ++c) s0 += p[(int64_t)c * ks_sc];
     const float s = (s0 + s1) + (s2 + s3);
-    if constexpr (ROUND) ((uint16_t*)ks_out)[h * 128 + threadIdx.x] = (uint16_t)f32_to_half_bits<DT>(s);
-    else ((float*)ks_out)[h * 128 + threadIdx.x] = s;
+    if constexpr (ROUND) ((uint16_t*)ks_out)[td_head_off(h, hg, gs, 128) + threadIdx.x] = (uint16_t)f32_to_half_bits<DT>(s);
+    else ((float*)ks_out)[td_head_off(h, hg, gs, 128) + threadIdx.x] = s;
   }
 }
 
 static int sla_linear_kv_partial_impl(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
-                                      float* ws_ks, float* ws_km, int64_t L, int H, int D, td_stream_t stream) {
+                                      float* ws_ks, float* ws_km, int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes,
+                                      int H, int D, td_stream_t stream) {
+  TD_REQUIRE(L_alloc >= L && hg >= 0 && gs_bytes >= 0 && gs_bytes % 16 == 0 && (hg == 0 || H % hg == 0), TD_ERR_INVALID,
+             "td_sla_linear_kv_partial: packed layout L_alloc=%lld hg=%d gs=%lld", (long long)L_alloc, hg, (long long)gs_bytes);
   TD_REQUIRE(k && vt && ws_kv && ws_ks, TD_ERR_INVALID, "td_sla_linear_kv_partial: null pointer");
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_linear_kv_partial: D=%d (need 128)", D);
   TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sla_linear_kv_partial: L=%lld H=%d", (long long)L, H);
-  const int Kb = (int)td_cdiv(L, 64);
+  const int Kb = (int)td_cdiv(L, 64), Kb_alloc = (int)td_cdiv(L_alloc, 64);
   dim3 grid(LK_NCH, H);
   hipStream_t st = (hipStream_t)stream;
 #define TD_LKP(KD_, VD_)                                                                                         \
   {                                                                                                               \
-    if (ws_km) linear_kv_partial_kernel<KD_, VD_, true><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb); \
-    else linear_kv_partial_kernel<KD_, VD_, false><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb);     \
+    if (ws_km) linear_kv_partial_kernel<KD_, VD_, true><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb, Kb_alloc, hg, gs_bytes / 2); \
+    else linear_kv_partial_kernel<KD_, VD_, false><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb, Kb_alloc, hg, gs_bytes / 2);     \
   }
   if (dtype == TD_BF16 && vt_dtype == TD_F16) TD_LKP(TD_BF16, TD_F16)
   else if (dtype == TD_BF16 && vt_dtype == TD_BF16) TD_LKP(TD_BF16, TD_BF16)
@@ -288,22 +293,31 @@ static int sla_linear_kv_partial_impl(const void* k, int dtype, const void* vt, 
 extern "C" int td_sla_linear_kv_partial(const void* k, int dtype, const void* vt, int vt_dtype,
                                         float* ws_kv, float* ws_ks, int64_t L, int H, int D,
                                         td_stream_t stream) {
-  return sla_linear_kv_partial_impl(k, dtype, vt, vt_dtype, ws_kv, ws_ks, nullptr, L, H, D, stream);
+  return sla_linear_kv_partial_impl(k, dtype, vt, vt_dtype, ws_kv, ws_ks, nullptr, L, L, 0, 0, H, D, stream);
 }
 
-extern "C" int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, int nch, int64_t kv_stride_h,
-                                      int64_t kv_stride_c, int64_t ks_stride_h, int64_t ks_stride_c,
-                                      void* kv_out, void* ks_out, int out_dtype, int H, int D,
-                                      td_stream_t stream) {
+// vt read from the sequence-parallel pack (L_alloc rows allocated per head, heads grouped: td_common.h td_head_off)
+extern "C" int td_sla_linear_kv_partial_packed(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
+                                               float* ws_ks, int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes, int H,
+                                               int D, td_stream_t stream) {
+  return sla_linear_kv_partial_impl(k, dtype, vt, vt_dtype, ws_kv, ws_ks, nullptr, L, L_alloc, hg, gs_bytes, H, D, stream);
+}
+
+extern "C" int td_sla_linear_kv_final_packed(const float* ws_kv, const float* ws_ks, int nch, int64_t kv_stride_h,
+                                             int64_t kv_stride_c, int64_t ks_stride_h, int64_t ks_stride_c,
+                                             void* kv_out, void* ks_out, int out_dtype, int hg, int64_t gs_bytes, int H,
+                                             int D, td_stream_t stream) {
   TD_REQUIRE(ws_kv && ws_ks && kv_out && ks_out, TD_ERR_INVALID, "td_sla_linear_kv_final: null pointer");
+  TD_REQUIRE(hg >= 0 && gs_bytes >= 0 && gs_bytes % 16 == 0 && (hg == 0 || H % hg == 0), TD_ERR_INVALID,
+             "td_sla_linear_kv_final: packed layout hg=%d gs=%lld", hg, (long long)gs_bytes);
   TD_REQUIRE(D == 128 && nch > 0 && H > 0, TD_ERR_UNSUPPORTED, "td_sla_linear_kv_final: D=%d nch=%d", D, nch);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == TD_BF16)
-    linear_kv_final_kernel<TD_BF16, true><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_BF16, true><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out, hg, gs_bytes / 2);
   else if (out_dtype == TD_F16)
-    linear_kv_final_kernel<TD_F16, true><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_F16, true><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out, hg, gs_bytes / 2);
   else if (out_dtype == TD_F32)
-    linear_kv_final_kernel<TD_F32, false><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out);
+    linear_kv_final_kernel<TD_F32, false><<<dim3(H, 64), 256, 0, st>>>(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out, hg, gs_bytes / 4);
   else {
     td_set_error("td_sla_linear_kv_final: out dtype %d", out_dtype);
     return TD_ERR_UNSUPPORTED;
@@ -312,12 +326,20 @@ extern "C" int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, in
   return TD_OK;
 }
 
+extern "C" int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, int nch, int64_t kv_stride_h,
+                                      int64_t kv_stride_c, int64_t ks_stride_h, int64_t ks_stride_c,
+                                      void* kv_out, void* ks_out, int out_dtype, int H, int D,
+                                      td_stream_t stream) {
+  return td_sla_linear_kv_final_packed(ws_kv, ws_ks, nch, kv_stride_h, kv_stride_c, ks_stride_h, ks_stride_c, kv_out, ks_out,
+                                       out_dtype, 0, 0, H, D, stream);
+}
+
 extern "C" int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
                                 float* ws_ks, void* kvsum_t, void* ksum, float* ws_km, void* km, int64_t L, int H,
                                 int D, td_stream_t stream) {
   TD_REQUIRE(kvsum_t && ksum, TD_ERR_INVALID, "td_sla_linear_kv: null pointer");
   TD_REQUIRE((ws_km == nullptr) == (km == nullptr), TD_ERR_INVALID, "td_sla_linear_kv: ws_km / km must come together");
-  int rc = sla_linear_kv_partial_impl(k, dtype, vt, vt_dtype, ws_kv, ws_ks, ws_km, L, H, D, stream);
+  int rc = sla_linear_kv_partial_impl(k, dtype, vt, vt_dtype, ws_kv, ws_ks, ws_km, L, L, 0, 0, H, D, stream);
   if (rc) return rc;
   rc = td_sla_linear_kv_final(ws_kv, ws_ks, LK_NCH, (int64_t)LK_NCH * 128 * 128, 128 * 128,
                               (int64_t)LK_NCH * 128, 128, kvsum_t, ksum, dtype, H, D, stream);

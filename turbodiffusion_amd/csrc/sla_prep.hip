@@ -13,7 +13,8 @@
 template <int IDT, int ODT>
 __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __restrict__ v,
                                                           int64_t stride_h, int64_t stride_l,
-                                                          uint16_t* __restrict__ vt, int64_t L, int Kb) {
+                                                          uint16_t* __restrict__ vt, int64_t L, int Kb_alloc,
+                                                          int hg, int64_t gs) {
   // LDS tile [64 keys][128 d + 2 pad] 16-bit: the pad makes the column reads below conflict-light
   __shared__ uint16_t tile[64][130];
   const int tid = threadIdx.x;
@@ -31,7 +32,7 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __rest
     for (int j = 0; j < 8; ++j) tile[key][c8 * 8 + j] = (uint16_t)f32_to_half_bits<ODT>(f[j]);
   }
   __syncthreads();
-  uint16_t* out = vt + ((int64_t)h * Kb + kb) * (128 * 64);
+  uint16_t* out = vt + td_head_off(h, hg, gs, (int64_t)Kb_alloc * (128 * 64)) + (int64_t)kb * (128 * 64);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int vec = tid + 256 * i;          // output vector: row d = vec/8, slot = vec%8
@@ -53,18 +54,21 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const uint16_t* __rest
   }
 }
 
-extern "C" int td_v_transpose(const void* v, int in_dtype, int64_t stride_h, int64_t stride_l, void* vt,
-                              int out_dtype, int64_t L, int H, int D, td_stream_t stream) {
+extern "C" int td_v_transpose_packed(const void* v, int in_dtype, int64_t stride_h, int64_t stride_l, void* vt,
+                                     int out_dtype, int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes, int H, int D,
+                                     td_stream_t stream) {
   TD_REQUIRE(v && vt, TD_ERR_INVALID, "td_v_transpose: null pointer");
+  TD_REQUIRE(L_alloc >= L && hg >= 0 && gs_bytes >= 0 && gs_bytes % 16 == 0 && (hg == 0 || H % hg == 0), TD_ERR_INVALID,
+             "td_v_transpose: packed layout L_alloc=%lld hg=%d gs=%lld", (long long)L_alloc, hg, (long long)gs_bytes);
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_v_transpose: D=%d (need 128)", D);
   TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_v_transpose: L=%lld H=%d", (long long)L, H);
   TD_REQUIRE(stride_l % 8 == 0 && stride_h % 8 == 0, TD_ERR_UNSUPPORTED, "td_v_transpose: strides");
-  const int Kb = (int)td_cdiv(L, 64);
+  const int Kb = (int)td_cdiv(L, 64), Kb_alloc = (int)td_cdiv(L_alloc, 64);
   dim3 grid(Kb, H);
   hipStream_t st = (hipStream_t)stream;
 #define TD_VT(I_, O_)                                                                            \
   v_transpose_kernel<I_, O_><<<grid, 256, 0, st>>>((const uint16_t*)v, stride_h, stride_l,       \
-                                                   (uint16_t*)vt, L, Kb)
+                                                   (uint16_t*)vt, L, Kb_alloc, hg, gs_bytes / 2)
   if (in_dtype == TD_BF16 && out_dtype == TD_F16) TD_VT(TD_BF16, TD_F16);
   else if (in_dtype == TD_BF16 && out_dtype == TD_BF16) TD_VT(TD_BF16, TD_BF16);
   else if (in_dtype == TD_F16 && out_dtype == TD_F16) TD_VT(TD_F16, TD_F16);
@@ -75,6 +79,11 @@ extern "C" int td_v_transpose(const void* v, int in_dtype, int64_t stride_h, int
 #undef TD_VT
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_v_transpose(const void* v, int in_dtype, int64_t stride_h, int64_t stride_l, void* vt,
+                              int out_dtype, int64_t L, int H, int D, td_stream_t stream) {
+  return td_v_transpose_packed(v, in_dtype, stride_h, stride_l, vt, out_dtype, L, L, 0, 0, H, D, stream);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -177,7 +186,10 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
                                                               const uint16_t* __restrict__ km,
                                                               uint16_t* __restrict__ pooled,
                                                               int8_t* __restrict__ xq,
-                                                              float* __restrict__ xs, int64_t L, int nb) {
+                                                              float* __restrict__ xs, int64_t L, int64_t L_alloc,
+                                                              int nb, int hg, int64_t gs) {
+  // nb = blocks ALLOCATED per head in pooled / xs (>= the blocks of L), L_alloc = rows allocated per head in xq; (hg, gs
+  // in bytes): the packed head layout of td_common.h for the three outputs
   __shared__ float red[16][128];
   __shared__ float wmax[4];
   constexpr int NIT = BLK / 16;
@@ -235,12 +247,12 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
     for (int r = 0; r < 16; ++r) s += red[r][tid];
     const int64_t rem = L - (int64_t)blk * BLK;
     const float cnt = (float)(rem < BLK ? rem : BLK);
-    pooled[((int64_t)h * nb + blk) * 128 + tid] = (uint16_t)f32_to_half_bits<DT>(s / cnt);
+    pooled[td_head_off(h, hg, gs / 2, (int64_t)nb * 128) + (int64_t)blk * 128 + tid] = (uint16_t)f32_to_half_bits<DT>(s / cnt);
   }
   if (xq == nullptr) return;
   amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
   const float scale = amax / 127.0f + 1e-7f;
-  if (tid == 0) xs[(int64_t)h * nb + blk] = scale;
+  if (tid == 0) xs[td_head_off(h, hg, gs / 4, nb) + blk] = scale;
   // y = x / scale, correctly rounded (== the IEEE division of the oracle): rinv = RN(1/scale) by one Newton step on
   // v_rcp_f32, then q0 = RN(x*rinv), r = x - q0*scale exactly (fma), q = RN(q0 + r*rinv)  (Markstein's correction)
   float rinv = __builtin_amdgcn_rcpf(scale);
@@ -262,30 +274,38 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
     }
     const uint32_t w0 = __builtin_amdgcn_perm(c[1], c[0], 0x0c0c0400u) | __builtin_amdgcn_perm(c[3], c[2], 0x04000c0cu);
     const uint32_t w1 = __builtin_amdgcn_perm(c[5], c[4], 0x0c0c0400u) | __builtin_amdgcn_perm(c[7], c[6], 0x04000c0cu);
-    if (l < L) *reinterpret_cast<uint2*>(xq + ((int64_t)h * L + l) * 128 + c8 * 8) = make_uint2(w0, w1);
+    if (l < L) *reinterpret_cast<uint2*>(xq + td_head_off(h, hg, gs, L_alloc * 128) + l * 128 + c8 * 8) = make_uint2(w0, w1);
   }
 }
 
-extern "C" int td_sage_quant_pool(const void* x, const void* km, int dtype, int pool_blk, void* pooled,
-                                  int8_t* xq, float* xs, int64_t L, int H, int D, td_stream_t stream) {
+extern "C" int td_sage_quant_pool_packed(const void* x, const void* km, int dtype, int pool_blk, void* pooled,
+                                         int8_t* xq, float* xs, int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes,
+                                         int H, int D, td_stream_t stream) {
   TD_REQUIRE(x, TD_ERR_INVALID, "td_sage_quant_pool: null input");
+  TD_REQUIRE(L_alloc >= L && hg >= 0 && gs_bytes >= 0 && gs_bytes % 16 == 0 && (hg == 0 || H % hg == 0), TD_ERR_INVALID,
+             "td_sage_quant_pool: packed layout L_alloc=%lld hg=%d gs=%lld", (long long)L_alloc, hg, (long long)gs_bytes);
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sage_quant_pool: D=%d (need 128)", D);
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_sage_quant_pool: dtype %d", dtype);
   TD_REQUIRE(pool_blk == 64 || pool_blk == 128, TD_ERR_UNSUPPORTED, "td_sage_quant_pool: blk %d", pool_blk);
   TD_REQUIRE((xq == nullptr) == (xs == nullptr), TD_ERR_INVALID, "td_sage_quant_pool: xq/xs mismatch");
   TD_REQUIRE(pooled || xq, TD_ERR_INVALID, "td_sage_quant_pool: nothing to do");
   TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sage_quant_pool: L=%lld H=%d", (long long)L, H);
-  const int nb = (int)td_cdiv(L, pool_blk);
+  const int nb = (int)td_cdiv(L, pool_blk), nb_alloc = (int)td_cdiv(L_alloc, pool_blk);
   dim3 grid(nb, H);
   hipStream_t st = (hipStream_t)stream;
 #define TD_SQP(DT_, B_)                                                                              \
   sage_quant_pool_kernel<DT_, B_><<<grid, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)km,      \
-                                                        (uint16_t*)pooled, xq, xs, L, nb)
+                                                        (uint16_t*)pooled, xq, xs, L, L_alloc, nb_alloc, hg, gs_bytes)
   if (dtype == TD_BF16) { if (pool_blk == 64) TD_SQP(TD_BF16, 64); else TD_SQP(TD_BF16, 128); }
   else { if (pool_blk == 64) TD_SQP(TD_F16, 64); else TD_SQP(TD_F16, 128); }
 #undef TD_SQP
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_sage_quant_pool(const void* x, const void* km, int dtype, int pool_blk, void* pooled,
+                                  int8_t* xq, float* xs, int64_t L, int H, int D, td_stream_t stream) {
+  return td_sage_quant_pool_packed(x, km, dtype, pool_blk, pooled, xq, xs, L, L, 0, 0, H, D, stream);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -198,3 +198,11 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
   uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
 }
+
+// Sequence-parallel PACK layout (seqpar.py): the per-head outputs of a producer kernel are written straight into the send
+// buffer of the K-side all-gather, which is [groups][section][heads_per_group][...] — head h of a section lives at
+// section base + (h / hg) * gs + (h % hg) * hs  (hs = that section's natural per-head extent; gs = group stride, both in
+// elements of the section's type).  hg == 0: the flat layout, h * hs.
+__device__ __forceinline__ int64_t td_head_off(int h, int hg, int64_t gs, int64_t hs) {
+  return hg > 0 ? (int64_t)(h / hg) * gs + (int64_t)(h % hg) * hs : (int64_t)h * hs;
+}

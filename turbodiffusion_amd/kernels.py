@@ -565,3 +565,35 @@ def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None
     call("td_attn_16_sp", ptr(q), ptr(k_g), ptr(vt_g), ptr(lut), nsel, ptr(out), dt_code(q.dtype), o_stride_h, o_stride_l,
          float(sm_scale), L_, lk, H, kbp, k_rs, v_rs, ptr(add_t), None, None, stream_ptr())
     return out
+
+
+def sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay):
+    """This rank's K-side state written STRAIGHT into the send buffer of the sequence-parallel all-gathers (``lay``: a
+    ``seqpar.PackLayout``; buffer uint8 [groups, group_bytes], group g = heads [g*hg, (g+1)*hg), sections k | vt | ks | pk |
+    kv | kss): the Sage INT8 codes + scales + pooled block means of ``k`` (smooth-K mean ``km``), the V^T MFMA tiles of V
+    (element (h,l,d) at v_src + h*v_strides[0] + l*v_strides[1] + d) and the fp32 linear-branch partials — four launches
+    over all heads (the *_packed entry points), no staging copies."""
+    require_gpu(k, km, v_src)
+    H, L_, D = k.shape
+    assert L_ == L_loc and k.is_contiguous() and H == lay.G * lay.hg and D == lay.D
+    pack = (torch.zeros if L_loc < lay.per else torch.empty)((lay.G, lay.gb), dtype=torch.uint8, device=k.device)
+    base = pack.data_ptr()
+
+    def at(name):
+        return L.ctypes.c_void_p(base + lay.offs[name])
+
+    call("td_v_transpose_packed", ptr(v_src), dt_code(v_src.dtype), v_strides[0], v_strides[1], at("vt"), dt_code(lay.pdt),
+         L_loc, lay.per, lay.hg, lay.gb, H, D, stream_ptr())
+    if lay.sage or not lay.dense:
+        call("td_sage_quant_pool_packed", ptr(k), ptr(km), dt_code(k.dtype), 64, at("pk") if not lay.dense else None,
+             at("k") if lay.sage else None, at("ks") if lay.sage else None, L_loc, lay.per, lay.hg, lay.gb, H, D, stream_ptr())
+    if not lay.sage:   # 16-bit K travels as it is: one strided copy into the k section
+        lay.section(pack, "k")[:, :, :L_loc].copy_(k.view(lay.G, lay.hg, L_loc, D))
+    if lay.linear:
+        ws_kv = torch.empty((H, SLA_NCH, D, D), dtype=torch.float32, device=k.device)
+        ws_ks = torch.empty((H, SLA_NCH, D), dtype=torch.float32, device=k.device)
+        call("td_sla_linear_kv_partial_packed", ptr(k), dt_code(k.dtype), at("vt"), dt_code(lay.pdt), ptr(ws_kv), ptr(ws_ks),
+             L_loc, lay.per, lay.hg, lay.gb, H, D, stream_ptr())
+        call("td_sla_linear_kv_final_packed", ptr(ws_kv), ptr(ws_ks), SLA_NCH, SLA_NCH * D * D, D * D, SLA_NCH * D, D,
+             at("kv"), at("kss"), L.TD_F32, lay.hg, lay.gb, H, D, stream_ptr())
+    return pack

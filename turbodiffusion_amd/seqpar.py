@@ -63,6 +63,45 @@ class _Gather:
             eager_point(self._wait)
 
 
+class PackLayout:
+    """Byte layout of the K-side send buffer of one self-attention layer: uint8 [G, gb]; group g = heads [g*hg, (g+1)*hg),
+    inside a group the sections  k (int8 codes, or the 16-bit K when not Sage) | vt (V^T MFMA tiles) | ks (K scales) |
+    pk (pooled K blocks) | kv, kss (fp32 linear-branch partials), each [hg, ...] at the rank-padded extents (``per`` rows,
+    ``per/64`` blocks) and 256-byte aligned.  G = the largest divisor of H not above ``head_groups`` (equal groups: the
+    producer kernels address head h as group h // hg, member h % hg — td_common.h ``td_head_off``)."""
+
+    def __init__(self, H, per, D, head_groups, sage, dense, dt):
+        self.H, self.per, self.D, self.sage, self.dense, self.linear, self.dt = H, per, D, sage, dense, not dense, dt
+        self.G = max(g for g in range(1, max(1, min(head_groups, H)) + 1) if H % g == 0)
+        self.hg = hg = H // self.G
+        self.kbp = kbp = per // 64
+        self.pdt = torch.float16 if sage else dt
+        self.spec = {   # name -> (dtype, per-group shape)
+            "k": (torch.int8 if sage else dt, (hg, per, D)),
+            "vt": (self.pdt, (hg, kbp, D, 64)),
+            "ks": (torch.float32, (hg, kbp)) if sage else None,
+            "pk": (dt, (hg, kbp, D)) if not dense else None,
+            "kv": (torch.float32, (hg, D, D)) if self.linear else None,
+            "kss": (torch.float32, (hg, D)) if self.linear else None,
+        }
+        self.offs, self.sizes, o = {}, {}, 0
+        for name, sp in self.spec.items():
+            n = 0
+            if sp is not None:
+                n = torch.empty((), dtype=sp[0]).element_size()
+                for d in sp[1]:
+                    n *= d
+            self.offs[name], self.sizes[name] = o, n
+            o += _cdiv(n, 256) * 256
+        self.gb = o
+
+    def section(self, buf, name):
+        """buf uint8 [N, gb] (the pack: N = G; one group's all-gather output: N = world) -> [N, *per-group shape] VIEW."""
+        dtype, shape = self.spec[name]
+        off, n = self.offs[name], self.sizes[name]
+        return buf[:, off:off + n].view(dtype).view((buf.shape[0],) + shape)
+
+
 class SeqParallel:
     def __init__(self, group=None, ops=None):
         self.group = group if group is not None else dist.group.WORLD
@@ -120,14 +159,12 @@ class SeqParallel:
         H, L_loc, D = q.shape
         L, per = self.L, self.per
         kbp = per // 64
-        kb_loc = _cdiv(L_loc, 64)
         kb_tot = _cdiv(L, 64)
         sage = attention_type in ("sage", "sagesla")
         dense = attention_type in ("original", "sage")
         linear = not dense
         dt = q.dtype
         dev = q.device
-        pdt = torch.float16 if sage else dt
 
         # ---- (1) global smooth-K mean ----
         km = None
@@ -136,92 +173,51 @@ class SeqParallel:
             allp = self.all_gather(part)                       # [W, H, D]
             km = ops.seq_mean_final(allp, W, D, H * D, L, H, D, dt)
 
-        # ---- (2) local K-side state -> packed buffer -> ONE all-gather ----
-        vt = ops.v_transpose(v_src, v_strides[0], v_strides[1], L_loc, H, D, pdt)   # [H, kb_loc, D, 64]
-        pk = k_q = k_s = None
-        if sage:
-            pk, k_q, k_s = ops.sage_quant_pool(k, km, 64, want_pool=not dense)
-        elif not dense:
-            pk, _, _ = ops.sage_quant_pool(k, km, 64, want_quant=False)
-        kv32 = ks32 = None
-        if linear:
-            kv32, ks32 = ops.sla_linear_kv_partial_f32(k, vt)
+        # ---- (2) local K-side state, written by the producer kernels straight into the send buffer: ONE buffer
+        # [groups][k | vt | ks | pk | kv | kss][heads of the group][...] (PackLayout), one all-gather per head group ----
+        lay = PackLayout(H, per, D, self.head_groups, sage, dense, dt)
+        pack = ops.sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay)          # uint8 [G, group_bytes]
 
-        # ---- (2) + (3), pipelined over head groups: every group's K-side state is packed and its all-gather issued
-        # (asynchronously, RCCL's own stream executes them in order); then, group by group, the gather is awaited and
-        # that group's block map / attention / linear branch run while the later groups' bytes are still on the links.
-        # The bytes on the wire are the same as with one gather; what changes is that attention — about a third of a
-        # layer's compute — now overlaps most of the exchange instead of waiting for all of it.
-        k_elem = 1 if sage else 2
-        n_groups = min(self.head_groups, H)
-        bounds = [(H * g) // n_groups for g in range(n_groups + 1)]
-        pq = q_q = q_s = None
+        # ---- (2) + (3), pipelined over head groups: the groups' all-gathers are issued back to back (asynchronously,
+        # RCCL's own stream executes them in order); then, group by group, the gather is awaited and that group's block
+        # map / attention / linear branch run while the later groups' bytes are still on the links.  The bytes on the wire
+        # are the same as with one gather; what changes is that attention — about a third of a layer's compute — overlaps
+        # most of the exchange instead of waiting for all of it.
         inflight = []
-        for g in range(n_groups):
-            h0, h1 = bounds[g], bounds[g + 1]
-            Hg = h1 - h0
-            sizes = {
-                "k": Hg * per * D * k_elem,
-                "vt": Hg * kbp * D * 64 * 2,
-                "ks": Hg * kbp * 4 if sage else 0,
-                "pk": Hg * kbp * D * 2 if not dense else 0,
-                "kv": Hg * D * D * 4 if linear else 0,
-                "kss": Hg * D * 4 if linear else 0,
-            }
-            offs, o = {}, 0
-            for name, sz in sizes.items():
-                offs[name] = o
-                o += _cdiv(sz, 256) * 256
-            pack = torch.zeros(o, dtype=torch.uint8, device=dev)
-
-            def slot(name, dtype, shape, pack=pack, sizes=sizes, offs=offs):
-                n = sizes[name]
-                return pack[offs[name]:offs[name] + n].view(dtype).view(shape)
-
-            if sage:
-                slot("k", torch.int8, (Hg, per, D))[:, :L_loc] = k_q[h0:h1]
-                slot("ks", torch.float32, (Hg, kbp))[:, :kb_loc] = k_s[h0:h1]
-            else:
-                slot("k", dt, (Hg, per, D))[:, :L_loc] = k[h0:h1]
-            slot("vt", pdt, (Hg, kbp, D, 64))[:, :kb_loc] = vt[h0:h1]
-            if not dense:
-                slot("pk", dt, (Hg, kbp, D))[:, :kb_loc] = pk[h0:h1]
-            if linear:
-                slot("kv", torch.float32, (Hg, D, D)).copy_(kv32[h0:h1])
-                slot("kss", torch.float32, (Hg, D)).copy_(ks32[h0:h1])
-            allb, work = self.all_gather(pack, async_op=True)  # [W, bytes]
-            inflight.append((h0, h1, sizes, offs, allb, work))
-            if g == n_groups - 1:  # the Q side of this rank (all heads) is prepared under the transfers
-                if sage:
-                    pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
-                elif not dense:
-                    pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
+        for g in range(lay.G):
+            allb, work = self.all_gather(pack[g], async_op=True)   # [W, group_bytes]
+            inflight.append((g * lay.hg, (g + 1) * lay.hg, allb, work))
+        # the Q side of this rank (all heads) is prepared under the transfers
+        pq = q_q = q_s = None
+        if sage:
+            pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
+        elif not dense:
+            pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
 
         # The attention / block-map kernels read the K side STRAIGHT from the all-gather's rank-major output (the *_sp
         # entry points: block j = block j % kbp of rank j // kbp): no re-layout of the gathered K / V^T / scales / pooled K.
 
         topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
-        for (h0, h1, sizes, offs, allb, work) in inflight:
+        for (h0, h1, allb, work) in inflight:
             work.wait()
             Hg = h1 - h0
 
-            def gathered(name, dtype, shape, allb=allb, sizes=sizes, offs=offs):  # [W, *shape] strided VIEW (no copy)
-                n = sizes[name]
-                return allb[:, offs[name]:offs[name] + n].view(dtype).view((W,) + shape)
+            def gathered(name, allb=allb):  # [W, hg, ...] strided VIEW of one section of the group's gather (no copy)
+                return lay.section(allb, name)
 
-            vt_g = gathered("vt", pdt, (Hg, kbp, D, 64))                            # [W, Hg, kbp, D, 64] view
+            vt_g = gathered("vt")                                                   # [W, Hg, kbp, D, 64] view
             out_g = out.view(-1)[h0 * o_stride_h:]   # same buffer, origin moved to the group's first head
             lut = None
             if not dense:
-                lut = ops.sla_topk_sp(pq[h0:h1], gathered("pk", dt, (Hg, kbp, D)), topk, kb_tot)
+                lut = ops.sla_topk_sp(pq[h0:h1], gathered("pk"), topk, kb_tot)
             if sage:
-                ops.attn_i8_sp(q_q[h0:h1], q_s[h0:h1], gathered("k", torch.int8, (Hg, per, D)),
-                               gathered("ks", torch.float32, (Hg, kbp)), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
+                ops.attn_i8_sp(q_q[h0:h1], q_s[h0:h1], gathered("k"),
+                               gathered("ks"), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
             else:
-                ops.attn_16_sp(q[h0:h1], gathered("k", dt, (Hg, per, D)), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
+                ops.attn_16_sp(q[h0:h1], gathered("k"), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
             if linear:
-                kv_parts = gathered("kv", torch.float32, (Hg, D, D))   # [W, Hg, D, D]
-                ks_parts = gathered("kss", torch.float32, (Hg, D))     # [W, Hg, D]
+                kv_parts = gathered("kv")   # [W, Hg, D, D]
+                ks_parts = gathered("kss")     # [W, Hg, D]
                 kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D,
                                                      ks_parts.stride(0), Hg, D, dt)
                 ops.sla_linear_out_(q[h0:h1], kv_t, ksum, proj_w, proj_b, out_g, o_stride_h, o_stride_l)
