@@ -434,6 +434,8 @@ def main():
                             "; kernel events from one eager video after the timed region"
                             if use_graph else "eager enqueue; kernel events inside the timed region"),
         }
+        if use_graph and getattr(run_net, "sp_capture_error", None):
+            res["launch_mode"] = "eager enqueue (segmented hipGraph capture failed: " + run_net.sp_capture_error + ")"
         if eager_elapsed is not None:
             res["eager_videos_per_s"] = 1.0 / eager_elapsed
         if replicas is not None:

@@ -99,6 +99,8 @@ class GraphedModel(torch.nn.Module):
         self._graphs = {}
         self._text_src = {}   # per graph: identity/version of the text tensor last copied into its static buffer
         self._epoch = getattr(net, "_weights_epoch", 0)
+        self._sp_eager = False        # set when a segmented capture failed: eager from then on (sp_capture_error says why)
+        self.sp_capture_error = None
 
     def _key(self, x, t, ctx, y):
         return (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype,
@@ -107,7 +109,7 @@ class GraphedModel(torch.nn.Module):
     @torch.no_grad()
     def forward(self, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, frame_cond_crossattn_emb_B_L_D=None,
                 y_B_C_T_H_W: Optional[torch.Tensor] = None, **kwargs):
-        if frame_cond_crossattn_emb_B_L_D is not None:
+        if frame_cond_crossattn_emb_B_L_D is not None or self._sp_eager:
             return self.net(x_B_C_T_H_W, timesteps_B_T, crossattn_emb,
                             frame_cond_crossattn_emb_B_L_D=frame_cond_crossattn_emb_B_L_D,
                             y_B_C_T_H_W=y_B_C_T_H_W, **kwargs)
@@ -144,7 +146,16 @@ class GraphedModel(torch.nn.Module):
             if getattr(self.net, "seq_parallel", None) is not None:
                 # segments between the collectives (identical chain on every rank: the eager points are collective calls)
                 g = SegmentRecorder()
-                so = g.capture(lambda: self.net(sx, st, sc, y_B_C_T_H_W=sy))
+                try:
+                    so = g.capture(lambda: self.net(sx, st, sc, y_B_C_T_H_W=sy))
+                except Exception as e:   # deterministic across ranks (same code, same shapes): every rank lands here
+                    import warnings
+                    warnings.warn(f"segmented hipGraph capture of the sequence-parallel forward failed ({e!r}); "
+                                  f"this model now enqueues eagerly (slower, same results)")
+                    torch.cuda.synchronize()
+                    self.sp_capture_error = repr(e)
+                    self._sp_eager = True
+                    return self.net(x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=y_B_C_T_H_W, **kwargs)
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

@@ -166,11 +166,19 @@ class SeqParallel:
         dt = q.dtype
         dev = q.device
 
-        # ---- (1) global smooth-K mean ----
-        km = None
+        # ---- (1) global smooth-K mean: a tiny all-gather (latency-bound); the Q side of this rank — independent of it —
+        # is prepared while it is in flight ----
+        km = allp = km_work = None
         if sage or not dense:
             part = ops.seq_sum_partial(k).sum(dim=1)           # [H, D] f32, this rank's column sums
-            allp = self.all_gather(part)                       # [W, H, D]
+            allp, km_work = self.all_gather(part, async_op=True)   # [W, H, D]
+        pq = q_q = q_s = None
+        if sage:
+            pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
+        elif not dense:
+            pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
+        if allp is not None:
+            km_work.wait()
             km = ops.seq_mean_final(allp, W, D, H * D, L, H, D, dt)
 
         # ---- (2) local K-side state, written by the producer kernels straight into the send buffer: ONE buffer
@@ -183,23 +191,22 @@ class SeqParallel:
         # map / attention / linear branch run while the later groups' bytes are still on the links.  The bytes on the wire
         # are the same as with one gather; what changes is that attention — about a third of a layer's compute — overlaps
         # most of the exchange instead of waiting for all of it.
-        inflight = []
-        for g in range(lay.G):
-            allb, work = self.all_gather(pack[g], async_op=True)   # [W, group_bytes]
-            inflight.append((g * lay.hg, (g + 1) * lay.hg, allb, work))
-        # the Q side of this rank (all heads) is prepared under the transfers
-        pq = q_q = q_s = None
-        if sage:
-            pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
-        elif not dense:
-            pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
+        handles = [_Gather(self.group, torch.empty((W, lay.gb), dtype=torch.uint8, device=dev), pack[g], True)
+                   for g in range(lay.G)]
 
+        def issue_all():   # ONE eager point (graph.py): all groups' gathers, and the wait for the first
+            for h in handles:
+                h.issue()
+            handles[0]._wait()
+        eager_point(issue_all)
+        inflight = [(g * lay.hg, (g + 1) * lay.hg, handles[g].out, handles[g]) for g in range(lay.G)]
         # The attention / block-map kernels read the K side STRAIGHT from the all-gather's rank-major output (the *_sp
         # entry points: block j = block j % kbp of rank j // kbp): no re-layout of the gathered K / V^T / scales / pooled K.
 
         topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
         for (h0, h1, allb, work) in inflight:
-            work.wait()
+            if h0 > 0:
+                work.wait()
             Hg = h1 - h0
 
             def gathered(name, allb=allb):  # [W, hg, ...] strided VIEW of one section of the group's gather (no copy)
