@@ -142,6 +142,14 @@ int td_layernorm_quant(const void* x, int dtype, const float* w, const float* b,
 int td_gemm_w8a8_stats(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
                        void* d_or_x, const float* gate, int residual, int dtype, int64_t m, int64_t n, int64_t k,
                        int64_t ld, float* stats_ws, td_stream_t stream);
+
+/* td_gemm_w8a8 of a fused q|k|v projection (wan2pt1.py:256-262 computes the three Linears; a15 each) whose V columns
+ * [v_col0, n) leave the kernel as the V^T MFMA tiles of td_v_transpose — [head][ceil(m/64)][128][64], vt_dtype f16 (the cast
+ * of SLA/core.py:213 `v.to(torch.float16)`) or the output dtype — instead of row-major: bit-identical to td_gemm_w8a8 followed
+ * by td_v_transpose on those columns; d's V columns are NOT written.  bias required; n and v_col0 multiples of 256. */
+int td_gemm_w8a8_vt(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias, void* d,
+                    int out_dtype, int64_t m, int64_t n, int64_t k, int64_t ldd, int64_t v_col0, void* vt, int vt_dtype,
+                    td_stream_t stream);
 int td_row_stats_finalize(const float* ws, int pieces, int64_t n, float eps, int mode, float* out, int64_t m,
                           td_stream_t stream);
 int td_layernorm_quant_stats(const void* x, int dtype, const float* w, const float* b, const float* scale,

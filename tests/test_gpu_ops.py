@@ -344,3 +344,25 @@ def test_gemm_row_stats_epilogue(K, m, n, k, residual):
         assert (q0 != q1).float().mean().item() < 2e-3 and (q0.int() - q1.int()).abs().max().item() <= 1
         assert (s0 != s1).float().mean().item() < 0.05
         torch.testing.assert_close(s0, s1, rtol=1e-2, atol=0)
+
+
+# ---------------------------------------------------------------- V^T tiles from the q|k|v GEMM's epilogue
+@pytest.mark.parametrize("m,dim,k", [(1000, 256, 256), (2100, 512, 384), (1024, 1536, 128)])
+@pytest.mark.parametrize("dt,vt_dt", [(torch.bfloat16, torch.float16), (torch.bfloat16, torch.bfloat16), (torch.float16, torch.float16)])
+def test_gemm_vt_epilogue_is_gemm_plus_v_transpose(K, m, dim, k, dt, vt_dt):
+    """td_gemm_w8a8_vt: q|k columns = td_gemm_w8a8's bits; the V columns leave as exactly the tiles td_v_transpose makes
+    of td_gemm_w8a8's V columns (incl. the fp16 cast, the bit-2/3 key permutation, zero tail keys, a ragged last 64-key
+    block and a partial last 256-row tile)."""
+    g = torch.Generator().manual_seed(m + dim)
+    a = act_like(m, k, torch.bfloat16, seed=m + k)
+    w = (torch.randn(3 * dim, k, generator=g) / k ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(3 * dim, generator=g) * 0.1).to(dt).to(DEV)
+    aq, as_ = K.quant_i8_block128(a.to(DEV))
+    wq, ws = K.quant_i8_block128(w.to(DEV))
+    ref = K.gemm_w8a8(aq, as_, wq, ws, dt, bias=b)
+    H = dim // 128
+    vt_ref = K.v_transpose(ref[:, 2 * dim:], 128, 3 * dim, m, H, 128, vt_dt)
+    d, vt = K.gemm_w8a8_vt(aq, as_, wq, ws, b, 2 * dim, vt_dt, out_dtype=dt)
+    assert torch.equal(d[:, :2 * dim], ref[:, :2 * dim])
+    assert vt.shape == vt_ref.shape and vt.dtype == vt_dt
+    assert torch.equal(vt.view(torch.int16), vt_ref.view(torch.int16))

@@ -96,6 +96,12 @@ def main():
                 t = timeit(lambda: K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=(nm == "ffn1")), args.iters)
                 rep(f"gemm_w8a8[v{var}] {nm} M={L} N={n} K={k}", t, bytes_=L * k + n * k + 2 * L * n, flops=2.0 * L * n * k, peak_f=I8)
             K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
+            if nm == "fused qkv":   # V columns leaving as V^T tiles (td_gemm_w8a8_vt) vs GEMM + td_v_transpose
+                t = timeit(lambda: K.gemm_w8a8_vt(aq, as_, wq, ws, b, 2 * dim, torch.float16), args.iters)
+                rep(f"gemm_w8a8_vt (V^T tiles from the epilogue) {nm} M={L} N={n} K={k}", t, bytes_=L * k + n * k + 2 * L * n, flops=2.0 * L * n * k, peak_f=I8)
+                o_ = outs[GEMM_VARIANTS[0]]
+                t = timeit(lambda: K.v_transpose(o_[:, 2 * dim:], 128, 3 * dim, L, dim // 128, 128, torch.float16), args.iters)
+                rep("v_transpose of the V columns (what the vt epilogue replaces)", t, bytes_=4 * L * dim)
             print(json.dumps({"gemm_variants_bit_identical": bool(all(torch.equal(outs[GEMM_VARIANTS[0]], o) for o in outs.values()))}), flush=True)
             del outs
             del a, aq, wq

@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libturbodiffusion_amd.so")
+# TD_LIB_PATH: development aid for A/B runs against another build of the SAME ABI (tools/gpu/*_ab.sh); never a fallback
+LIB_PATH = os.environ.get("TD_LIB_PATH") or os.path.join(_HERE, "libturbodiffusion_amd.so")
 
 TD_F16, TD_BF16, TD_F32 = 0, 1, 2
 TD_EPI_NONE, TD_EPI_GELU_TANH = 0, 1
@@ -45,6 +46,7 @@ SIGNATURES = {
     "td_attn_16": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp],
     "td_attn_i8_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
     "td_gemm_w8a8_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _vp, _vp],
+    "td_gemm_w8a8_vt": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _i32, _vp],
     "td_row_stats_finalize": [_vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp],
     "td_layernorm_quant_stats": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
     "td_attn_i8_sp": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _i64,

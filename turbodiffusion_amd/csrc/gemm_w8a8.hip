@@ -271,3 +271,21 @@ extern "C" int td_gemm_w8a8_stats(const int8_t* a, const float* a_s, const int8_
   TD_REQUIRE(ld >= n && ld % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_stats: bad ld=%lld", (long long)ld);
   return td_gemm_w8a8_fi_stats(a, a_s, b, b_s, bias, d_or_x, gate, residual, m, n, k, ld, stats_ws, (hipStream_t)stream);
 }
+
+
+// a15 of a fused q|k|v projection whose V columns [v_col0, n) leave the kernel as the attention kernels' V^T tiles
+// (td_v_transpose's layout and values; vt_dtype f16 = the Sage PV operand, or the output dtype) instead of row-major:
+// d's V columns are NOT written.  bias required; n, v_col0 multiples of 256 (whole tiles; heads of 128 columns).
+extern "C" int td_gemm_w8a8_vt(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
+                               void* d, int out_dtype, int64_t m, int64_t n, int64_t k, int64_t ldd, int64_t v_col0,
+                               void* vt, int vt_dtype, td_stream_t stream) {
+  TD_REQUIRE(a && a_s && b && b_s && d && bias && vt, TD_ERR_INVALID, "td_gemm_w8a8_vt: null pointer");
+  TD_REQUIRE(out_dtype == TD_F16 || out_dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_vt: out dtype %d", out_dtype);
+  TD_REQUIRE(vt_dtype == out_dtype || vt_dtype == TD_F16, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_vt: vt dtype %d (f16 or the output dtype)", vt_dtype);
+  TD_REQUIRE(k % 128 == 0 && k > 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_vt: k=%lld must be a positive multiple of 128", (long long)k);
+  TD_REQUIRE(m > 0 && n > 0 && n % 256 == 0 && v_col0 % 256 == 0 && v_col0 >= 0 && v_col0 < n, TD_ERR_UNSUPPORTED,
+             "td_gemm_w8a8_vt: n=%lld v_col0=%lld must be multiples of 256 with v_col0 < n", (long long)n, (long long)v_col0);
+  TD_REQUIRE(ldd >= n && ldd % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_vt: bad ldd=%lld", (long long)ldd);
+  return td_gemm_w8a8_fi_vt(a, a_s, b, b_s, bias, d, out_dtype, m, n, k, ldd, v_col0, vt, vt_dtype == TD_F16 && out_dtype != TD_F16,
+                            (hipStream_t)stream);
+}

@@ -89,7 +89,14 @@ __device__ __forceinline__ uint32_t f_swz(uint32_t row, uint32_t chunk) {
 // 16-bit values it stores — QS is then a float2 workspace [M, ldqs] with ldqs = N / 64 pieces per row.  td_row_stats_finalize
 // turns the pieces into the row statistics of the LayerNorm / RMSNorm that reads this output next, which therefore needs no
 // statistics pass of its own over the [M, N] tensor.
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false>
+// VT = 1 | 2 (plain epilogue only): the columns n >= ldqs (a multiple of 256: whole tiles) are V of a fused q|k|v
+// projection, heads of 128 columns — instead of storing them row-major the epilogue writes them as the attention kernels'
+// V^T MFMA tiles (td_v_transpose's layout: [head][ceil(M/64)][128 d][64 key positions], position = key with bits 2/3
+// swapped, rows m >= M zero), fp16 (VT = 1, the Sage PV operand: cast of the stored 16-bit value) or the output dtype
+// (VT = 2), into QS (reinterpreted as 16-bit): bit-identical to td_gemm_w8a8 followed by td_v_transpose, minus a 2-byte
+// write, a 2-byte read and a launch.  Each wave transposes its 128 keys x 64 d through a private LDS region (the stage
+// buffers are free after the main loop) in two 64-key halves: 2-byte scatter writes, 16-byte row reads, full-line stores.
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
@@ -458,6 +465,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         if (m < M && n < N) xres[i][jp] = *reinterpret_cast<const uint4*>(D + m * ldd + n);
       }
   }
+  // Full-line stores (round 2; tools/gemm_store_exp.py -> profiles/r02_gemm_store_exp.txt): after the lane swap a lane
+  // holds 8 consecutive n of ONE row, so a direct store instruction writes 32-byte pieces of 16 different rows — the
+  // epilogue of a K = 1536 tile took 11.7 k cycles.  The rows go through a wave-private LDS region instead (the stage
+  // buffers are free after the main loop; [64 rows][64 cols + 8 pad] 16-bit, one 64-row half at a time: conflict-free
+  // ds_write_b128 / ds_read_b128) and every store instruction writes 8 rows x one full 128-byte line: 6.9 k cycles,
+  // -4...-5.5 % per GEMM, bit-identical.
+  __syncthreads();                    // every wave has read its last fragments: the stages may be overwritten
+  uint16_t* stg_lds = reinterpret_cast<uint16_t*>(smem) + wave * (64 * 72);
+  bool vtile = false;                 // VT: this tile's columns are V -> V^T tiles instead of row-major
+  uint16_t* vt_lds = stg_lds;         // the wave's transposition buffer [64 d][64 positions (+8 pad)] 16-bit
+  if constexpr (VT != 0) vtile = n0 >= ldqs;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t m = m0 + wm * 128 + i * 16 + l16;
@@ -484,9 +502,31 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
       const int jt = hi ? jb : ja;
       const int64_t n = n0 + wn * 64 + jt * 16 + 8 * (lq & 1);
+      if constexpr (VT != 0) {
+        if (vtile) {   // (workgroup-uniform) this lane: key (i&3)*16 + l16 of the half, d = jt*16 + 8*(lq&1) + e
+          const int key = (i & 3) * 16 + l16;
+          const int pos = (key & 0x33) | ((key & 4) << 1) | ((key & 8) >> 1);
+          const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+          uint16_t* col = vt_lds + (jt * 16 + 8 * (lq & 1)) * 72 + pos;
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            uint32_t lo = w4[e2] & 0xffffu, hi16 = w4[e2] >> 16;
+            if constexpr (VT == 1 && ODT != TD_F16) {
+              float f0, f1;
+              unpack2<ODT>(w4[e2], f0, f1);
+              lo = f32_to_half_bits<TD_F16>(f0);
+              hi16 = f32_to_half_bits<TD_F16>(f1);
+            }
+            if (m >= M) { lo = 0; hi16 = 0; }
+            col[(2 * e2) * 72] = (uint16_t)lo;
+            col[(2 * e2 + 1) * 72] = (uint16_t)hi16;
+          }
+          continue;
+        }
+      }
+      uint4 outv = v;
       if constexpr (RES) {
         if (m < M && n < N) {
-          uint16_t* xp = D + m * ldd + n;
           float xf[8], yf[8];
           unpack8<ODT>(xres[i][jp], xf);
           unpack8<ODT>(v, yf);
@@ -503,29 +543,48 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 #pragma unroll
             for (int e = 0; e < 8; ++e) xf[e] = xf[e] + yf[e];
           }
-          const uint4 xn = pack8<ODT>(xf);
-          *reinterpret_cast<uint4*>(xp) = xn;
-          if constexpr (STATS) {
-            float sv[8];
-            unpack8<ODT>(xn, sv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { st_s += sv[e]; st_q = fmaf(sv[e], sv[e], st_q); }
-          }
+          outv = pack8<ODT>(xf);
         }
-      } else
-      if (m < (DBG == 3 ? (int64_t)(ldqs) : M) && n < N) {
-        if constexpr (DBG == 4) {  // experiment: non-temporal (streaming) stores
-          typedef unsigned v4u __attribute__((ext_vector_type(4)));
-          __builtin_nontemporal_store((v4u){v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(D + m * ldd + n));
-        } else {
-          *reinterpret_cast<uint4*>(D + m * ldd + n) = v;
-        }
-        if constexpr (STATS) {
+      }
+      if constexpr (STATS) {
+        if (m < M && n < N) {
           float sv[8];
-          unpack8<ODT>(v, sv);
+          unpack8<ODT>(outv, sv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) { st_s += sv[e]; st_q = fmaf(sv[e], sv[e], st_q); }
         }
+      }
+      *reinterpret_cast<uint4*>(stg_lds + ((i & 3) * 16 + l16) * 72 + jt * 16 + 8 * (lq & 1)) = outv;
+    }
+    if ((i & 3) == 3 && !vtile) {   // a 64-row half is complete in LDS: 8 rows x one 128-byte line per store instruction
+      {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+          const int64_t mm = m0 + wm * 128 + (i >> 2) * 64 + row, nn = n0 + wn * 64 + chunk * 8;
+          const uint4 r = *reinterpret_cast<const uint4*>(stg_lds + row * 72 + chunk * 8);
+          if (mm < M && nn < N) *reinterpret_cast<uint4*>(D + mm * ldd + nn) = r;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    if constexpr (VT != 0) {
+      if (vtile && (i & 3) == 3) {   // a 64-key half is complete in LDS: 8 d rows x 128 B per store instruction
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t Kb = (M + 63) >> 6;
+        const int64_t kb = ((m0 + wm * 128) >> 6) + (i >> 2);
+        const int64_t head = ((n0 - ldqs) >> 7) + (wn >> 1);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(QS) + (head * Kb + kb) * (128 * 64) + (int64_t)((wn & 1) * 64) * 64;
+        if (kb < Kb) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int d = it * 8 + (lane >> 3), slot = lane & 7;
+            const uint4 r = *reinterpret_cast<const uint4*>(vt_lds + d * 72 + slot * 8);
+            *reinterpret_cast<uint4*>(dst + d * 64 + slot * 8) = r;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next half overwrites
       }
     }
     if constexpr (STATS) {
@@ -549,11 +608,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false>
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0>
 static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
-  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS>;
+  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT>;
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), F_LDS + F_DUMP, attr_mask);
   const int tiles_m = (int)td_cdiv(m, F_BM), tiles_n = (int)td_cdiv(n, F_BN);
@@ -575,10 +634,6 @@ int td_gemm_w8a8_fi(const int8_t* a, const float* a_s, const int8_t* b, const fl
     return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
   if (td_tuning(TD_TUNE_GEMM_ABLATE) == 6)  // phase stamps (prologue / main loop / epilogue)
     return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
-  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 4)  // phase stamps, non-temporal stores
-    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
-  if (td_tuning(TD_TUNE_GEMM_ABLATE) == 5)  // phase stamps with every store predicated off (WRONG results: nothing is written)
-    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 3>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, nullptr, 0);
   if (td_tuning(TD_TUNE_GEMM_ABLATE) == 8)  // s_memtime trace, early-DMA schedule
     return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 1, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st);
   if (epilogue == TD_EPI_NONE && bias && out_dtype == TD_BF16) {
@@ -667,4 +722,18 @@ int td_gemm_w8a8_fi_stats(const int8_t* a, const float* a_s, const int8_t* b, co
                                                                                  stats_ws, pieces, gate);
   return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, false, 0, true>(a, a_s, b, b_s, bias, d_or_x, m, n, k, ld, st,
                                                                                 stats_ws, pieces, nullptr);
+}
+
+
+// a15 of the fused q|k|v projection + the V^T tiles of td_v_transpose (VT epilogue): columns [v_col0, n) are NOT stored
+// row-major, they go to vt as [head][ceil(m/64)][128][64] tiles (fp16 when vt_f16, else the output dtype).
+int td_gemm_w8a8_fi_vt(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias, void* d,
+                       int out_dtype, int64_t m, int64_t n, int64_t k, int64_t ldd, int64_t v_col0, void* vt, int vt_f16,
+                       hipStream_t st) {
+  float* vq = reinterpret_cast<float*>(vt);
+  if (out_dtype == TD_BF16) {
+    if (vt_f16) return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, false, 0, false, 1>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, vq, v_col0);
+    return launch_gemm_fi<TD_BF16, TD_EPI_NONE, true, 0, 0, false, false, 0, false, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, vq, v_col0);
+  }
+  return launch_gemm_fi<TD_F16, TD_EPI_NONE, true, 0, 0, false, false, 0, false, 2>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, vq, v_col0);
 }

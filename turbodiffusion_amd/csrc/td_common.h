@@ -52,6 +52,9 @@ int td_gemm_w8a8_fi_res(const int8_t* a, const float* a_s, const int8_t* b, cons
 int td_gemm_w8a8_fi_stats(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
                           void* d_or_x, const float* gate, int residual, int64_t m, int64_t n, int64_t k, int64_t ld,
                           float* stats_ws, hipStream_t st);
+int td_gemm_w8a8_fi_vt(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias, void* d,
+                       int out_dtype, int64_t m, int64_t n, int64_t k, int64_t ldd, int64_t v_col0, void* vt, int vt_f16,
+                       hipStream_t st);
 int td_gemm_w8a8_m32(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                      const void* bias, void* d, int out_dtype, int epilogue, int64_t m, int64_t n,
                      int64_t k, int64_t ldd, hipStream_t st);

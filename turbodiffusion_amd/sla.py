@@ -41,7 +41,7 @@ def _check_geometry(head_dim, blkq, blkk):
 
 
 def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
-                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None, pv="fp16"):
+                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None, pv="fp16", vt=None):
     """Core of both modules on head-major tensors.
 
     q, k: [H, L, D] 16-bit (after RoPE); vt_src: tensor holding V with element (h,l,d) at
@@ -50,6 +50,8 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     km: the per-head sequence mean of k [H, D] when the caller already has it (K.qk_norm_rope_pair), else computed here.
     quant_out: return the [L, H*D] result block-quantised for the o projection ((int8, scales) in place of ``out``,
     which then only supplies the dtype).
+    vt: the V^T tiles when the caller already has them (K.gemm_w8a8_vt: the q|k|v GEMM's epilogue wrote them) — vt_src is
+    then not read (pv = "fp16" only).
     pv: "fp16" (the reference's sm80 branch, SLA/core.py:211-216) or "fp8" (its sm89+ branch, :217-239: V as per-channel
     scaled e4m3, P rounded to e4m3, P.V on the fp8 MFMA) — Sage only.
 
@@ -65,7 +67,10 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
         raise ValueError(f"block-sparse attention with topk ratio {topk_ratio} selects no block of {kb} "
                          f"(L = {L_} tokens): use a longer sequence or a larger ratio")
     pdt = torch.float16 if sage else q.dtype
-    vt = K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, pdt)
+    if vt is None:
+        vt = K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, pdt)
+    else:
+        assert vt.dtype == pdt and tuple(vt.shape) == (H, kb, D, 64) and not (sage and pv == "fp8")
     o_l = None
     if proj_w is not None:
         # the linear branch's pass over K also accumulates the smooth-K mean (k.mean(dim=-2), SLA/core.py:197)

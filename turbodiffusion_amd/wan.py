@@ -149,6 +149,7 @@ class WanModel(nn.Module):
         self.batch_text_kv = True
         self._ckv_all = None
         self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
+        self.fuse_vt = True         # self-attention V leaves the q|k|v GEMM as the attention kernel's V^T tiles (K.gemm_w8a8_vt)
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
         self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
         self._text_states = {}     # data_ptr -> (key, source tensor, context, [per batch entry: [per block: (k, vt)]])
@@ -349,7 +350,16 @@ class WanModel(nn.Module):
         f = self._fused_weights(i, blk)
         sa = blk.self_attn
         H, D, dim = self.num_heads, 128, self.dim
-        if isinstance(h, tuple):
+        at = self.attention_type
+        sage = at in ("sage", "sagesla")
+        vt = None
+        if (isinstance(h, tuple) and self.fuse_vt and self.seq_parallel is None and dim % 256 == 0 and f["qkv_b"] is not None
+                and not (sage and self.sage_pv == "fp8")):
+            # the V third of the projection leaves the GEMM as the attention kernel's V^T tiles (no v_transpose pass;
+            # qkv's V columns are not written)
+            qkv, vt = K.gemm_w8a8_vt(h[0], h[1], f["qkv_w"], f["qkv_s"], f["qkv_b"], 2 * dim,
+                                     torch.float16 if sage else dtype, out_dtype=dtype)
+        elif isinstance(h, tuple):
             qkv = K.gemm_w8a8(h[0], h[1], f["qkv_w"], f["qkv_s"], dtype, bias=f["qkv_b"])
         else:
             qkv = self._fused_lin(h, f["qkv_w"], f.get("qkv_s"), f["qkv_b"])  # [L, 3*dim]
@@ -360,14 +370,12 @@ class WanModel(nn.Module):
         out = dtype if quant_out else torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
         if self.seq_parallel is not None:
             return self.seq_parallel.self_attention(self, f, q, k, qkv, out)
-        at = self.attention_type
-        sage = at in ("sage", "sagesla")
         dense = at in ("original", "sage")
         # W8A8: the attention kernel's epilogue hands the o projection its INT8 activation directly
         res, _, _ = sparse_linear_attention_hld(q, k, qkv[:, 2 * dim:], f.get("proj_w") if not dense else None,
                                                 f.get("proj_b") if not dense else None, self.sla_topk, sage, out, D, dim,
                                                 (D, 3 * dim), dense=dense, quant_out=quant_out,
-                                                pv=self.sage_pv if sage else "fp16")
+                                                pv=self.sage_pv if sage else "fp16", vt=vt)
         return res
 
     def _text_kvt(self, i, blk, context, text_kv=None):
