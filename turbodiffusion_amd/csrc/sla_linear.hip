@@ -350,7 +350,7 @@ extern "C" int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt
 // ---------------------------------------------------------------------------------------
 // pass 2: o += proj_l( (cq @ kvsum) / (1e-5 + sum(cq*ksum)) )
 // ---------------------------------------------------------------------------------------
-#define LO_QB_PER_WG 8
+#define LO_QB_PER_WG 4   // 768 workgroups at the C1 shape = 3 per CU: 67 us vs 75 (8) / 84 (6) / 104 (12), tools/lin_qb_exp.py
 template <int DT>
 __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __restrict__ q,
                                                          const uint16_t* __restrict__ kvT,
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
                                                          const float* __restrict__ bp,
                                                          uint16_t* __restrict__ o, int64_t o_stride_h,
                                                          int64_t o_stride_l, int64_t L, int Qb,
-                                                         uint16_t* __restrict__ t_out) {
+                                                         uint16_t* __restrict__ t_out, int qb_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem_lo[];
   char* kvs = smem_lo;               // kvsum^T [d2][d1] DT, 256-B rows, swizzled
   char* wps = smem_lo + 128 * 256;   // Wp [d3][d2 in MFMA k order] DT
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
   // and only ~6 waves fit a CU beside the 64 KB of LDS, so an un-prefetched load is a fully exposed HBM round trip)
   uint4 qraw[8];
   {
-    int64_t tok0 = (int64_t)blockIdx.x * LO_QB_PER_WG * 128 + wave * 32 + li;
+    int64_t tok0 = (int64_t)blockIdx.x * qb_per_wg * 128 + wave * 32 + li;
     if (tok0 > L - 1) tok0 = L - 1;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks)
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
   for (int ks = 0; ks < 8; ++ks)
     unpack8<DT>(*reinterpret_cast<const uint4*>(ksum + h * 128 + 16 * ks + 8 * hi), ksf[ks]);
 
-  for (int qq = 0; qq < LO_QB_PER_WG; ++qq) {
-    const int qb = blockIdx.x * LO_QB_PER_WG + qq;
+  for (int qq = 0; qq < qb_per_wg; ++qq) {
+    const int qb = blockIdx.x * qb_per_wg + qq;
     if (qb >= Qb) break;
     int64_t tok = (int64_t)qb * 128 + wave * 32 + li;
     const bool ok = tok < L;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
 #pragma unroll
       for (int e = 0; e < 8; ++e) mx = fmaxf(mx, qf[ks][e]);
     }
-    if (qq + 1 < LO_QB_PER_WG && qb + 1 < Qb) {
+    if (qq + 1 < qb_per_wg && qb + 1 < Qb) {
       int64_t tokn = (int64_t)(qb + 1) * 128 + wave * 32 + li;
       if (tokn > L - 1) tokn = L - 1;
 #pragma unroll
@@ -546,18 +546,19 @@ static int sla_linear_out_impl(const void* q, int dtype, const void* kvsum_t, co
   TD_REQUIRE(o_stride_l % 4 == 0 && o_stride_h % 4 == 0, TD_ERR_UNSUPPORTED, "td_sla_linear_out: strides");
   const int Qb = (int)td_cdiv(L, 128);
   const int lds = 2 * 128 * 256;
-  dim3 grid((unsigned)td_cdiv(Qb, LO_QB_PER_WG), H);
+  const int qpw = td_tuning(TD_TUNE_LIN_QB) > 0 ? td_tuning(TD_TUNE_LIN_QB) : LO_QB_PER_WG;
+  dim3 grid((unsigned)td_cdiv(Qb, qpw), H);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16) {
     static std::atomic<uint64_t> a{0};
     td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<TD_BF16>), lds, a);
     linear_out_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
-        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out);
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw);
   } else {
     static std::atomic<uint64_t> a{0};
     td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<TD_F16>), lds, a);
     linear_out_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
-        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out);
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw);
   }
   TD_CHECK_LAUNCH();
   return TD_OK;
