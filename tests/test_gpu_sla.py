@@ -524,3 +524,22 @@ def test_sp_pack_k_side_is_bit_identical_to_flat_producers(K, sage, dense, L_loc
         assert torch.equal(lay.section(pack, "kss").reshape(H, D), ks32)
     if L_loc < per:   # the padding of a short rank is zero (never read as valid, but must be finite)
         assert int(lay.section(pack, "vt")[:, :, kb:].abs().sum()) == 0
+
+
+def test_attn_i8_two_per_cu_build_is_bit_identical(K):
+    """TD_TUNE_ATTN_OCC = 2 (experiment kept selectable: two workgroups per CU, three tile buffers, explicit K / V fragment
+    prefetch) computes the bits of the default three-per-CU build — sparse with a ragged tail and dense."""
+    H, L = 3, 1000
+    q, k, v, q_i8, q_s, k_i8, k_s = _sage_inputs(H, L, 11)
+    _, lut, topk = S.get_block_map(q, k, 0.3, 128, 64)
+    vt = K.v_transpose(v[0].contiguous().to(DEV), L * 128, 128, L, H, 128, torch.float16)
+    args = (q_i8[0].to(DEV), q_s[0].to(DEV), k_i8[0].to(DEV), k_s[0].to(DEV), vt)
+    for lt in (lut[0].int().to(DEV), None):
+        outs = []
+        for occ in (0, 2):
+            K.set_tuning(K.TUNE_ATTN_OCC, occ)
+            o = torch.zeros(H, L, 128, dtype=torch.bfloat16, device=DEV)
+            K.attn_i8(*args, lt, o, L * 128, 128)
+            outs.append(o)
+        K.set_tuning(K.TUNE_ATTN_OCC, 0)
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])

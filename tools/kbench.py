@@ -146,6 +146,15 @@ def main():
         fl = 4.0 * qb * 128 * topk * 64 * D * H
         by = H * qb * (128 * D + topk * 64 * D * 3 + 128 * D * 2)
         rep(f"attn_i8 sparse topk={topk}/{kb}", t, bytes_=by, flops=fl, peak_f=(I8 + F16) / 2 * 0 + 1.0 / (0.5 / I8 + 0.5 / F16))
+        ref_o = out.clone()
+        K.set_tuning(K.TUNE_ATTN_OCC, 2)
+        t = timeit(lambda: K.attn_i8(q8, qs, k8, ks, vt, lut, out, D, H * D), args.iters)
+        rep(f"attn_i8 sparse topk={topk}/{kb} [2 workgroups/CU, 3 tile buffers, fragment prefetch]", t, bytes_=by, flops=fl,
+            peak_f=1.0 / (0.5 / I8 + 0.5 / F16))
+        print(json.dumps({"attn_occ2_bit_identical": bool(torch.equal(out, ref_o))}), flush=True)
+        K.set_tuning(K.TUNE_ATTN_OCC, 0)
+        t = timeit(lambda: K.attn_i8(q8, qs, k8, ks, vt, lut, out, D, H * D), args.iters)
+        rep(f"attn_i8 sparse topk={topk}/{kb} (again)", t, bytes_=by, flops=fl, peak_f=1.0 / (0.5 / I8 + 0.5 / F16))
         t = timeit(lambda: K.v_fp8_tiles(qkv[:, 2 * dim:], D, 3 * dim, L, H, D), args.iters)
         rep("v_fp8_tiles (amax + e4m3 tiles)", t, bytes_=5 * L * dim)
         vt8, vsc = K.v_fp8_tiles(qkv[:, 2 * dim:], D, 3 * dim, L, H, D)

@@ -101,11 +101,15 @@ template <> struct Mma16<TD_BF16> {
 };
 
 // QK_I8: int8 QK; PDT: dtype of P / V^T (and of q,k when !QK_I8); ODT: output dtype
-template <bool QK_I8, int PDT, int ODT, bool PV8 = false>
+// OCC2 (INT8 kernels, experiment TD_TUNE_ATTN_OCC): two workgroups per CU with 256 VGPRs each instead of three with 168 —
+// room for THREE tile buffers and for explicit fragment prefetch: all 8 K fragments of a tile are requested before the
+// first QK MFMA (the 168-register build reuses one fragment register: ds_read -> wait -> MFMA, eight times), and the V
+// fragments of d-block c+1 are requested before the MFMAs of d-block c.
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false>
 // lut_all / ks_all / qs_all repeat p.lut / p.k_s / p.q_s as __restrict__ kernel arguments: only then are the per-iteration
 // LUT entry and K scale SCALAR loads (s_load, lgkmcnt).  As vector loads they drag an s_waitcnt vmcnt(0) into the loop,
 // which waits for every K/V tile in flight and undoes the fetch-ahead.
-__global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, const int32_t* __restrict__ lut_all,
+__global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(AttnParams p, const int32_t* __restrict__ lut_all,
                                                       const float* __restrict__ ks_all,
                                                       const float* __restrict__ qs_all) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
   // A K/V tile fetch is a scattered 24-32 KB read (the LUT picks the blocks).  The INT8 kernel keeps THREE tiles in
   // LDS (72 KB, two workgroups per CU) and fetches two iterations ahead; no staging VGPRs, no ds_write.  The LDS
   // image of a DMA piece is lane-linear, so the bank swizzle of the read side is applied to the global address.
-  constexpr int NBUF = 2;
+  constexpr int NBUF = OCC2 ? 3 : 2;
   constexpr int KPIECES = KT::BYTES / 1024 / 4;  // per wave: 2 (int8 K) or 4 (16-bit K); V^T: 4
   constexpr int VPIECES = PV8 ? 2 : 4;
   constexpr int NPIECES = KPIECES + VPIECES;
@@ -261,6 +265,25 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
       int64_t ksi = (int64_t)h * p.kb_alloc + kb;
       if (p.kbp > 0) { const int r_ = kb / p.kbp; ksi = (int64_t)r_ * p.ks_rs + (int64_t)h * p.kbp + (kb - r_ * p.kbp); }
       mult = (qs * ks_all[ksi]) * p.scale_log2;
+      if constexpr (OCC2) {
+        v4i kfr[2][4];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) kfr[g][kc] = *reinterpret_cast<const v4i*>(kt + KT::off(32 * g + li, 2 * kc + hi));
+        __builtin_amdgcn_sched_barrier(0);   // all eight reads are in flight before the first MFMA
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          v16i acc = magic16;
+#pragma unroll
+          for (int kc = 0; kc < 4; ++kc) {
+            v4i qv; qv[0] = qf[kc].x; qv[1] = qf[kc].y; qv[2] = qf[kc].z; qv[3] = qf[kc].w;
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kfr[g][kc], qv, acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[g][r] = __int_as_float(acc[r]);
+        }
+      } else {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         v16i acc = magic16;
@@ -272,6 +295,7 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[g][r] = __int_as_float(acc[r]);
+      }
       }
     } else {
 #pragma unroll
@@ -357,6 +381,25 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
       pf[ks] = pack8<PDT>(&s[g][8 * t]);
     }
     // ---- O^T += V^T . P^T ----
+    if constexpr (OCC2) {
+      frag16 vfr[2][4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) vfr[0][ks] = *reinterpret_cast<const frag16*>(vtile + vt_off(li, 2 * ks + hi));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            vfr[(c + 1) & 1][ks] = *reinterpret_cast<const frag16*>(vtile + vt_off(32 * (c + 1) + li, 2 * ks + hi));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the next d-block's reads are issued before this d-block's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          frag16 pv = *reinterpret_cast<const frag16*>(&pf[ks]);
+          oacc[c] = Mma16<PDT>::mma(vfr[c & 1][ks], pv, oacc[c]);
+        }
+      }
+    } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -365,6 +408,7 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
         frag16 pv = *reinterpret_cast<const frag16*>(&pf[ks]);
         oacc[c] = Mma16<PDT>::mma(vf, pv, oacc[c]);
       }
+    }
     }
     }
     // tile it+1 must have landed (this wave's pieces; the barrier makes it everyone's); tile it+2 may stay in flight
@@ -471,11 +515,14 @@ __global__ __launch_bounds__(256, QK_I8 ? 3 : 2) void attn_kernel(AttnParams p, 
   }
 }
 
-template <bool QK_I8, int PDT, int ODT, bool PV8 = false>
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false>
 static int launch_attn(const AttnParams& p, hipStream_t st) {
-  auto kern = attn_kernel<QK_I8, PDT, ODT, PV8>;
-  // two tile buffers, and at least the 128 x 272-byte staging area of the epilogue's transpose
-  constexpr int lds_tiles = 2 * (KTile<QK_I8>::BYTES + (PV8 ? VT8_BYTES : VT_BYTES));
+  if constexpr (QK_I8 && !PV8 && !OCC2) {
+    if (td_tuning(TD_TUNE_ATTN_OCC) == 2) return launch_attn<QK_I8, PDT, ODT, PV8, true>(p, st);
+  }
+  auto kern = attn_kernel<QK_I8, PDT, ODT, PV8, OCC2>;
+  // two (three: OCC2) tile buffers, and at least the 128 x 272-byte staging area of the epilogue's transpose
+  constexpr int lds_tiles = (OCC2 ? 3 : 2) * (KTile<QK_I8>::BYTES + (PV8 ? VT8_BYTES : VT_BYTES));
   constexpr int lds = lds_tiles > 128 * 272 ? lds_tiles : 128 * 272;
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, attr_mask);
