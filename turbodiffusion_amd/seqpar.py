@@ -165,6 +165,9 @@ class SeqParallel:
         linear = not dense
         dt = q.dtype
         dev = q.device
+        if not dense and min(kb_tot, int(topk_ratio * kb_tot)) < 1:
+            # same condition on every rank, raised BEFORE any collective (sla.py mirrors SLA/utils.py:61-62 the same way)
+            raise ValueError(f"block-sparse attention with topk ratio {topk_ratio} selects no block of {kb_tot} (L = {L} tokens)")
 
         # ---- (1) global smooth-K mean: a tiny all-gather (latency-bound); the Q side of this rank — independent of it —
         # is prepared while it is in flight ----
