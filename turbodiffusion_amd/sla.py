@@ -41,7 +41,8 @@ def _check_geometry(head_dim, blkq, blkk):
 
 
 def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
-                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None, pv="fp16", vt=None):
+                                v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None, pv="fp16", vt=None,
+                                side=None, q_fn=None):
     """Core of both modules on head-major tensors.
 
     q, k: [H, L, D] 16-bit (after RoPE); vt_src: tensor holding V with element (h,l,d) at
@@ -50,6 +51,11 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     km: the per-head sequence mean of k [H, D] when the caller already has it (K.qk_norm_rope_pair), else computed here.
     quant_out: return the [L, H*D] result block-quantised for the o projection ((int8, scales) in place of ``out``,
     which then only supplies the dtype).
+    side, q_fn: two-stream schedule (SageSLA, FP16 PV): ``q`` is None and ``q_fn()`` produces it; the Q-side chain
+    (q_fn -> Sage quant/pool of q -> pass 2 of the linear branch) is enqueued on the stream ``side`` while the K-side chain
+    (linear-branch pass 1 + smooth-K mean -> Sage quant/pool of k) runs on the current stream; they meet at the block map and
+    at the attention kernel.  The Q-side kernels are HBM-bound, pass 1 / pass 2 of the linear branch instruction-bound: run
+    side by side they share the CUs instead of queueing.  Same kernels, same arguments: bit-identical.
     vt: the V^T tiles when the caller already has them (K.gemm_w8a8_vt: the q|k|v GEMM's epilogue wrote them) — vt_src is
     then not read (pv = "fp16" only).
     pv: "fp16" (the reference's sm80 branch, SLA/core.py:211-216) or "fp8" (its sm89+ branch, :217-239: V as per-channel
@@ -58,7 +64,7 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     The linear branch (needs only q, k, v) runs FIRST and leaves o_l in a lane-private layout; the attention kernel adds
     it in its epilogue (o = o_s + o_l, the 16-bit add of SLA/core.py:253) — no read-modify-write pass over the output.
     """
-    H, L_, D = q.shape
+    H, L_, D = k.shape
     _check_geometry(D, blkq, blkk)
     kb = K.cdiv(L_, blkk)
     topk = min(kb, int(topk_ratio * kb))
@@ -66,6 +72,11 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
         # SLA/utils.py:61-62 would select zero blocks here (and divide 0 by 0 downstream): refuse instead
         raise ValueError(f"block-sparse attention with topk ratio {topk_ratio} selects no block of {kb} "
                          f"(L = {L_} tokens): use a longer sequence or a larger ratio")
+    if side is not None and q_fn is not None:
+        if sage and not dense and proj_w is not None and pv == "fp16" and vt is not None and km is None:
+            return _sagesla_two_streams(q_fn, k, vt, proj_w, proj_b, topk, kb, out, o_stride_h, o_stride_l, blkq, blkk,
+                                        quant_out, side)
+        q = q_fn()
     pdt = torch.float16 if sage else q.dtype
     if vt is None:
         vt = K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, pdt)
@@ -101,6 +112,36 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
             pk, _, _ = K.sage_quant_pool(k, km, blkk, want_quant=False)
             lut = K.sla_topk(pq, pk, topk)
         res = K.attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out)
+    return res, topk, kb
+
+
+def _sagesla_two_streams(q_fn, k, vt, proj_w, proj_b, topk, kb, out, o_stride_h, o_stride_l, blkq, blkk, quant_out, side):
+    """The SageSLA kernel sequence of ``sparse_linear_attention_hld`` with the Q-side chain on ``side`` (see there).
+    Allocation safety without record_stream: tensors made on ``side`` are consumed on the current stream before this
+    function's last kernel, and ``side`` only starts new work after waiting for an event of the current stream that is
+    recorded later than that kernel (the next call's fork) — and vice versa for kv_t / ksum through ``e_ol``."""
+    main = torch.cuda.current_stream()
+    e_fork = torch.cuda.Event()
+    e_fork.record(main)                      # q's source (the q|k|v projection) is complete
+    side.wait_event(e_fork)
+    with torch.cuda.stream(side):
+        q = q_fn()
+        pq, q_i8, q_s = K.sage_quant_pool(q, None, blkq, want_pool=True)
+        e_pq = torch.cuda.Event()
+        e_pq.record(side)
+    kv_t, ksum, km = K.sla_linear_kv(k, vt, want_kmean=True)
+    e_kv = torch.cuda.Event()
+    e_kv.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(e_kv)
+        o_l = K.sla_linear_out_t(q, kv_t, ksum, proj_w, proj_b)
+        e_ol = torch.cuda.Event()
+        e_ol.record(side)
+    pk, k_i8, k_s = K.sage_quant_pool(k, km, blkk, want_pool=True)
+    main.wait_event(e_pq)
+    lut = K.sla_topk(pq, pk, topk)
+    main.wait_event(e_ol)
+    res = K.attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out)
     return res, topk, kb
 
 

@@ -150,6 +150,8 @@ class WanModel(nn.Module):
         self._ckv_all = None
         self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
         self.fuse_vt = True         # self-attention V leaves the q|k|v GEMM as the attention kernel's V^T tiles (K.gemm_w8a8_vt)
+        self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
+        self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
         self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
         self._text_states = {}     # data_ptr -> (key, source tensor, context, [per batch entry: [per block: (k, vt)]])
@@ -363,7 +365,12 @@ class WanModel(nn.Module):
             qkv = K.gemm_w8a8(h[0], h[1], f["qkv_w"], f["qkv_s"], dtype, bias=f["qkv_b"])
         else:
             qkv = self._fused_lin(h, f["qkv_w"], f.get("qkv_s"), f["qkv_b"])  # [L, 3*dim]
-        q = K.qk_norm_rope(qkv, 0, H, D, sa.norm_q.weight, cos, sin, self.eps)
+        two = (self.two_streams and self.seq_parallel is None and vt is not None and at == "sagesla" and self.sage_pv == "fp16"
+               and f.get("proj_w") is not None)
+
+        def q_fn():
+            return K.qk_norm_rope(qkv, 0, H, D, sa.norm_q.weight, cos, sin, self.eps)
+        q = None if two else q_fn()
         k = K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
         if self.seq_parallel is not None:
             quant_out = False
@@ -375,8 +382,21 @@ class WanModel(nn.Module):
         res, _, _ = sparse_linear_attention_hld(q, k, qkv[:, 2 * dim:], f.get("proj_w") if not dense else None,
                                                 f.get("proj_b") if not dense else None, self.sla_topk, sage, out, D, dim,
                                                 (D, 3 * dim), dense=dense, quant_out=quant_out,
-                                                pv=self.sage_pv if sage else "fp16", vt=vt)
+                                                pv=self.sage_pv if sage else "fp16", vt=vt,
+                                                side=self._side() if two else None, q_fn=q_fn if two else None)
         return res
+
+    def _side(self):
+        """The second HIP stream of the two-stream self-attention schedule: one per (device, calling stream), so that two
+        host threads driving this model on two streams never share one (the allocation-safety argument of
+        sla._sagesla_two_streams is per pair of streams)."""
+        key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+        st = self._side_streams.get(key)
+        if st is None:
+            if len(self._side_streams) >= 16:
+                self._side_streams.clear()
+            st = self._side_streams[key] = torch.cuda.Stream()
+        return st
 
     def _text_kvt(self, i, blk, context, text_kv=None):
         """Cross-attention K (RMSNorm'ed, head-major) and V^T tiles of block i for one batch entry's text tokens."""
