@@ -359,10 +359,22 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
                                                          const float* __restrict__ bp,
                                                          uint16_t* __restrict__ o, int64_t o_stride_h,
                                                          int64_t o_stride_l, int64_t L, int Qb,
-                                                         uint16_t* __restrict__ t_out, int qb_per_wg) {
+                                                         uint16_t* __restrict__ t_out, int qb_per_wg,
+                                                         unsigned long long* __restrict__ dbg) {
+  // dbg != nullptr (TD_TUNE_LIN_QB < 0 selects it, tools/lin_qb_exp.py): s_memtime at the phase boundaries of every Q block
+  // of wave 0 of workgroup (0, 0): {block start, softmax done, GEMM 1 done, o_l done, GEMM 2 + stores issued}
+  int dbg_n = 0;
+#define LO_STAMP()                                                                                         \
+  if (dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && dbg_n < 60) {           \
+    dbg[dbg_n++] = __builtin_amdgcn_s_memtime();                                                           \
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_lo[];
   char* kvs = smem_lo;               // kvsum^T [d2][d1] DT, 256-B rows, swizzled
   char* wps = smem_lo + 128 * 256;   // Wp [d3][d2 in MFMA k order] DT
+  // proj_l bias, autocast-rounded once, in LDS: read per d-block with ds_read (lgkmcnt).  As a global load inside the
+  // store loop it brought an s_waitcnt vmcnt(0) per d-block, i.e. a wait for the PREVIOUS d-block's stores (gfx9 counts
+  // stores in vmcnt): 8-13 k of a Q block's 13-18 k cycles (tools/lin_qb_exp.py phase stamps)
+  float* bps = reinterpret_cast<float*>(smem_lo + 2 * 128 * 256);
   typedef typename MmaT<DT>::frag frag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hi = lane >> 5;
@@ -392,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
     *reinterpret_cast<uint4*>(wps + sw256(d3, slot)) =
         make_uint4(pack2<DT>(lo.x, lo.y), pack2<DT>(lo.z, lo.w), pack2<DT>(hi4.x, hi4.y), pack2<DT>(hi4.z, hi4.w));
   }
+  if (tid < 128) bps[tid] = round_half<DT>(bp[tid]);
   __syncthreads();
 
   // this lane's half of ksum: d1 = 16*ks + 8*hi + e
@@ -406,6 +419,7 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
     int64_t tok = (int64_t)qb * 128 + wave * 32 + li;
     const bool ok = tok < L;
     if (!ok) tok = L - 1;
+    LO_STAMP()
     // ---- cq = softmax_D(q) rounded; lane holds d1 = 16ks + 8hi + e ----
     float qf[8][8];
     float mx = -INFINITY;
@@ -454,6 +468,7 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
     den = round_half<DT>(den);            // .sum(-1) -> dt
     den = round_half<DT>(1e-5f + den);    // 1e-5 + ... -> dt
     const float rden = __builtin_amdgcn_rcpf(den);
+    LO_STAMP()
     // ---- num^T[d2][tok] = kvsum^T . cq^T ----
     v16f a1[4];
 #pragma unroll
@@ -467,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
         a1[c] = MmaT<DT>::mma(af, bf, a1[c]);
       }
     }
+    LO_STAMP()
     // ---- o_l = dt(dt(num) / den); its registers are the B fragments of the projection ----
     uint4 olf[8];
 #pragma unroll
@@ -482,6 +498,7 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
       olf[2 * c] = pack8<DT>(&t[0]);
       olf[2 * c + 1] = pack8<DT>(&t[8]);
     }
+    LO_STAMP()
     // ---- out^T[d3][tok] = Wp . o_l^T ----
     uint16_t* op = o + (int64_t)h * o_stride_h + tok * o_stride_l;
 #pragma unroll
@@ -502,37 +519,34 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int d3 = 32 * c + 8 * g4 + 4 * hi;
-          const float4 bb = *reinterpret_cast<const float4*>(bp + d3);
+          const float4 bb = *reinterpret_cast<const float4*>(bps + d3);                            // autocast bias (LDS)
           const float bias[4] = {bb.x, bb.y, bb.z, bb.w};
           uint32_t res[2];
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            float b0, b1;
-            unpack2<DT>(pack2<DT>(bias[e], bias[e + 1]), b0, b1);                                  // autocast bias
-            res[e >> 1] = pack2<DT>(a2[4 * g4 + e] + b0, a2[4 * g4 + e + 1] + b1);                 // o_l in dt
-          }
+          for (int e = 0; e < 4; e += 2)
+            res[e >> 1] = pack2<DT>(a2[4 * g4 + e] + bias[e], a2[4 * g4 + e + 1] + bias[e + 1]);   // o_l in dt
           tp[(c * 4 + g4) * 64] = make_uint2(res[0], res[1]);
         }
       } else if (ok) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int d3 = 32 * c + 8 * g4 + 4 * hi;
-          const float4 bb = *reinterpret_cast<const float4*>(bp + d3);
+          const float4 bb = *reinterpret_cast<const float4*>(bps + d3);                            // autocast bias (LDS)
           const float bias[4] = {bb.x, bb.y, bb.z, bb.w};
           const uint2 ov = *reinterpret_cast<const uint2*>(op + d3);
           const uint32_t ob[4] = {ov.x & 0xffffu, ov.x >> 16, ov.y & 0xffffu, ov.y >> 16};
           uint32_t res[2];
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
-            float b0, b1, l0, l1;
-            unpack2<DT>(pack2<DT>(bias[e], bias[e + 1]), b0, b1);                                  // autocast bias
-            unpack2<DT>(pack2<DT>(a2[4 * g4 + e] + b0, a2[4 * g4 + e + 1] + b1), l0, l1);          // o_l in dt
+            float l0, l1;
+            unpack2<DT>(pack2<DT>(a2[4 * g4 + e] + bias[e], a2[4 * g4 + e + 1] + bias[e + 1]), l0, l1);   // o_l in dt
             res[e >> 1] = pack2<DT>(half_bits_to_f32<DT>(ob[e]) + l0, half_bits_to_f32<DT>(ob[e + 1]) + l1);
           }
           *reinterpret_cast<uint2*>(op + d3) = make_uint2(res[0], res[1]);
         }
       }
     }
+    LO_STAMP()
   }
 }
 
@@ -545,20 +559,22 @@ static int sla_linear_out_impl(const void* q, int dtype, const void* kvsum_t, co
   TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_sla_linear_out: L=%lld H=%d", (long long)L, H);
   TD_REQUIRE(o_stride_l % 4 == 0 && o_stride_h % 4 == 0, TD_ERR_UNSUPPORTED, "td_sla_linear_out: strides");
   const int Qb = (int)td_cdiv(L, 128);
-  const int lds = 2 * 128 * 256;
-  const int qpw = td_tuning(TD_TUNE_LIN_QB) > 0 ? td_tuning(TD_TUNE_LIN_QB) : LO_QB_PER_WG;
+  const int lds = 2 * 128 * 256 + 128 * 4;
+  const int tune_ = td_tuning(TD_TUNE_LIN_QB);
+  const int qpw = tune_ > 0 ? tune_ : (tune_ < 0 ? -tune_ : LO_QB_PER_WG);
+  unsigned long long* dbg = tune_ < 0 ? td_dbg_buffer() : nullptr;
   dim3 grid((unsigned)td_cdiv(Qb, qpw), H);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == TD_BF16) {
     static std::atomic<uint64_t> a{0};
     td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<TD_BF16>), lds, a);
     linear_out_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
-        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw);
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw, dbg);
   } else {
     static std::atomic<uint64_t> a{0};
     td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<TD_F16>), lds, a);
     linear_out_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
-        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw);
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw, dbg);
   }
   TD_CHECK_LAUNCH();
   return TD_OK;
