@@ -43,7 +43,7 @@
 #define F_TILE (256 * 128)        // one operand tile per K block, bytes
 #define F_STAGE (2 * F_TILE)      // activations + weights
 #define F_LDS (2 * F_STAGE)       // two stages = 128 KB
-#define F_DUMP 2048               // landing area of the L2-prefetch dwords
+#define F_DUMP 4096               // 2 KB landing area of the L2-prefetch dwords + 2 KB epilogue constants (bias, gate)
 #define F_MAGIC_I 0x4B400000
 #define F_MAGIC_F 12582912.0f
 
@@ -471,6 +471,22 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // buffers are free after the main loop; [64 rows][64 cols + 8 pad] 16-bit, one 64-row half at a time: conflict-free
   // ds_write_b128 / ds_read_b128) and every store instruction writes 8 rows x one full 128-byte line: 6.9 k cycles,
   // -4...-5.5 % per GEMM, bit-identical.
+  // The tile's 256 bias values (widened) and gate values (rounded to the output dtype, a7) go to LDS once: read per row
+  // group with ds_read (lgkmcnt).  As global loads inside the row-group loop (the compiler does not hoist them) each one
+  // carried an s_waitcnt vmcnt(0), and on gfx9 vmcnt counts STORES too: every row group waited for the previous group's
+  // statistics store / the previous half's tile stores to complete.
+  float* ep_bias = reinterpret_cast<float*>(smem + F_LDS + 2048);
+  float* ep_gate = ep_bias + 256;
+  if (tid < 256) {
+    const int64_t n = n0 + tid;
+    float bv = 0.f, gv = 0.f;
+    if (n < N) {
+      if constexpr (HAS_BIAS) bv = half_bits_to_f32<ODT>(bias[n]);
+      if constexpr (RES) { if (gate != nullptr) gv = round_half<ODT>(gate[n]); }
+    }
+    ep_bias[tid] = bv;
+    if constexpr (RES) ep_gate[tid] = gv;
+  }
   __syncthreads();                    // every wave has read its last fragments: the stages may be overwritten
   uint16_t* stg_lds = reinterpret_cast<uint16_t*>(smem) + wave * (64 * 72);
   bool vtile = false;                 // VT: this tile's columns are V -> V^T tiles instead of row-major
@@ -483,13 +499,10 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     uint32_t pk[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int64_t n = n0 + wn * 64 + j * 16 + 8 * (lq & 1) + 4 * hi;
       float bf[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (HAS_BIAS) {
-        if (n > N - 4) n = N - 4;  // tail: clamp the read, the value is never stored
-        const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
-        unpack2<ODT>(bb.x, bf[0], bf[1]);
-        unpack2<ODT>(bb.y, bf[2], bf[3]);
+        const float4 bb = *reinterpret_cast<const float4*>(ep_bias + wn * 64 + j * 16 + 8 * (lq & 1) + 4 * hi);
+        bf[0] = bb.x; bf[1] = bb.y; bf[2] = bb.z; bf[3] = bb.w;
       }
       pk[j][0] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][0], accf[i][j][1], bf[0], bf[1]);
       pk[j][1] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][2], accf[i][j][3], bf[2], bf[3]);
@@ -531,12 +544,12 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
           unpack8<ODT>(xres[i][jp], xf);
           unpack8<ODT>(v, yf);
           if (gate != nullptr) {
-            const float4 g0 = *reinterpret_cast<const float4*>(gate + n), g1 = *reinterpret_cast<const float4*>(gate + n + 4);
+            const float* gp = ep_gate + wn * 64 + jt * 16 + 8 * (lq & 1);       // gate.type_as(x), rounded once (LDS)
+            const float4 g0 = *reinterpret_cast<const float4*>(gp), g1 = *reinterpret_cast<const float4*>(gp + 4);
             const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float gd = round_half<ODT>(g[e]);           // gate.type_as(x)
-              const float t = round_half<ODT>(yf[e] * gd);      // y * gate -> x.dtype
+              const float t = round_half<ODT>(yf[e] * g[e]);    // y * gate -> x.dtype
               xf[e] = xf[e] + t;                                // x + t    -> x.dtype (rounded at pack)
             }
           } else {
