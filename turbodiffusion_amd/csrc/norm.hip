@@ -316,36 +316,76 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
   const int n = H * D;
   float f[NV][8];
   float sq = 0.f;
+  // the row's chunks are requested together (columns past n read column 0 and count as zeros): one HBM round trip per row
+  // instead of one per chunk
+  uint4 raw[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int col = (v * 64 + lane) * 8;
+    raw[v] = *reinterpret_cast<const uint4*>(src + row * ld_src + (col < n ? col : 0));
+  }
+  // every load (weight, cos / sin) is issued BEFORE the first store: on gfx9 stores count in vmcnt, so a load placed after
+  // a store makes its s_waitcnt vmcnt(0) wait for that store's completion — once per 512-column chunk of the row
+  float wv[NV][8];
+  float4 cs[NV], sn[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[v][j] = 1.0f;
+    cs[v] = make_float4(1.f, 1.f, 1.f, 1.f);
+    sn[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (w != nullptr) {      // (uniform branches around straight-line load groups: columns past n read column 0, never used)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * 64 + lane) * 8;
+      load8f(w + (col < n ? col : 0), wv[v]);
+    }
+  }
+  if (cosv != nullptr) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int col = (v * 64 + lane) * 8;
+      const int d0 = (col < n ? col : 0) % D;
+      cs[v] = *reinterpret_cast<const float4*>(cosv + row * (D / 2) + d0 / 2);
+      sn[v] = *reinterpret_cast<const float4*>(sinv + row * (D / 2) + d0 / 2);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int col = (v * 64 + lane) * 8;
+    unpack8<DT>(raw[v], f[v]);
     if (col < n) {
-      RowIO<DT>::load(src, row * ld_src + col, f[v]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) sq += f[v][j] * f[v][j];
     }
   }
   float rstd = 1.0f;
   if (w != nullptr) rstd = 1.0f / sqrtf(wave_sum(sq) / (float)n + eps);
+  // pin the arrival of every load here, before the first store (the compiler would otherwise wait for chunk v's weights
+  // after chunk v-1's store, and that wait would include the store)
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(wv[v][j]));
+    asm volatile("" : "+v"(cs[v].x), "+v"(cs[v].y), "+v"(cs[v].z), "+v"(cs[v].w));
+    asm volatile("" : "+v"(sn[v].x), "+v"(sn[v].y), "+v"(sn[v].z), "+v"(sn[v].w));
+  }
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const int col = (v * 64 + lane) * 8;
     if (col >= n) continue;
     float o[8];
     if (w != nullptr) {
-      float wv[8];
-      load8f(w + col, wv);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = RowIO<DT>::rnd((f[v][j] * rstd) * wv[j]);
+      for (int j = 0; j < 8; ++j) o[j] = RowIO<DT>::rnd((f[v][j] * rstd) * wv[v][j]);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = f[v][j];
     }
     const int head = col / D, d0 = col % D;
     if (cosv != nullptr) {
-      const float4 c = *reinterpret_cast<const float4*>(cosv + row * (D / 2) + d0 / 2);
-      const float4 s = *reinterpret_cast<const float4*>(sinv + row * (D / 2) + d0 / 2);
-      const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+      const float cc[4] = {cs[v].x, cs[v].y, cs[v].z, cs[v].w}, ss[4] = {sn[v].x, sn[v].y, sn[v].z, sn[v].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x0 = o[2 * j], x1 = o[2 * j + 1];
