@@ -30,17 +30,20 @@ int td_gemm_fast_g(void) {
   return (v == 2 || v == 4 || v == 8) ? v : 0;
 }
 
-// profiling aid shared by the GEMM kernels' DBG instantiations: 256 x 64-bit s_memtime stamps in device memory
+// profiling aid shared by the kernels' DBG instantiations: TD_DBG_WORDS x 64-bit s_memtime stamps in device memory (the
+// first 256: per-phase stamps of selected workgroups; from 256 on: {start, end, hardware id} of EVERY workgroup of the
+// phase-stamp GEMM instantiation, 3 words each)
+#define TD_DBG_WORDS 65536
 static unsigned long long* g_dbg_buf = nullptr;
 unsigned long long* td_dbg_buffer(void) {
   if (!g_dbg_buf) {
-    if (hipMalloc(&g_dbg_buf, 256 * 8) != hipSuccess) return nullptr;
-    (void)hipMemset(g_dbg_buf, 0, 256 * 8);
+    if (hipMalloc(&g_dbg_buf, TD_DBG_WORDS * 8) != hipSuccess) return nullptr;
+    (void)hipMemset(g_dbg_buf, 0, TD_DBG_WORDS * 8);
   }
   return g_dbg_buf;
 }
 extern "C" int td_debug_read(unsigned long long* host_dst, int n) {
-  if (n > 256) n = 256;
+  if (n > TD_DBG_WORDS) n = TD_DBG_WORDS;
   unsigned long long* b = td_dbg_buffer();
   if (!b || n < 0) return TD_ERR_LAUNCH;
   return hipMemcpy(host_dst, b, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? TD_OK : TD_ERR_LAUNCH;

@@ -618,6 +618,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       unsigned long long* o = dbg + (blockIdx.x >> 8) * 5;
       o[0] = c_t0; o[1] = c_t1; o[2] = c_t2; o[3] = c_t3; o[4] = c_t4;
     }
+    if (wave == 0 && lane == 0 && blockIdx.x < 21000) {   // every workgroup: {start, end, XCC id << 32 | HW_ID}
+      unsigned long long* o = dbg + 256 + 3 * (unsigned long long)blockIdx.x;
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      o[0] = c_t0; o[1] = c_t4; o[2] = ((unsigned long long)xcc << 32) | hw;
+    }
   }
 }
 
