@@ -1,0 +1,32 @@
+"""-m gpu: the bench.py contract the driver depends on — one JSON line with the agreed keys — on a 2-layer model so that it
+runs in seconds (the full-depth numbers live in profiles/)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_contract_json_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--layers", "2",
+                          "--no-cpu-baseline", "--no-two-in-flight"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in r, key
+    assert r["n_gpus"] == 1 and r["steps"] == 1 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["unit"] == "videos/s" and r["value"] > 0 and r["scaling"] == "weak"
+    assert "workload" in r["config"] and r["config"]["DEBUG_num_layers_override"] == 2
+    roof = r["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert 0 < r["roofline_attention"]["frac"] < 1
+    assert "hipGraph" in r["launch_mode"]
