@@ -158,6 +158,13 @@ class WanModel(nn.Module):
         self._weights_epoch = 0   # bumped whenever derived weight copies are dropped (GraphedModel re-captures on a change)
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_caches())
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle: HIP stream objects and cached derived tensors do not travel."""
+        d = self.__dict__.copy()
+        d["_side_streams"] = {}
+        d["_text_states"] = {}
+        return d
+
     # ------------------------------------------------------------------ derived weight copies
     def invalidate_caches(self):
         """Forget every tensor derived from the weights (the q|k|v / cross k|v concatenations, the all-blocks text K|V
