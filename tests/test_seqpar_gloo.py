@@ -154,3 +154,45 @@ def test_pack_layout_groups_and_alignment():
         assert lay.section(buf, "k").dtype == torch.int8 and lay.section(buf, "kv").shape == (lay.G, lay.hg, 128, 128)
     dense = PackLayout(12, 256, 128, 4, False, True, torch.bfloat16)     # "original": 16-bit K, no scales / pooled / partials
     assert dense.sizes["ks"] == dense.sizes["pk"] == dense.sizes["kv"] == 0 and dense.spec["k"][0] == torch.bfloat16
+
+
+def _reissue_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from turbodiffusion_amd import graph
+        from turbodiffusion_amd.seqpar import _Gather
+        src = torch.full((5,), float(rank))
+        out = torch.empty(world, 5)
+        calls = []
+
+        class Rec:   # a stand-in recorder: what graph.SegmentRecorder does at an eager point, minus the capture
+            def _eager(self, fn):
+                calls.append(fn)
+                return fn()
+        graph._ACTIVE = Rec()
+        h = _Gather(dist.group.WORLD, out, src, True)
+        graph.eager_point(h.issue)
+        h.wait()
+        graph._ACTIVE = None
+        first = out.clone()
+        src.add_(10.0)              # "the previous graph segment" rewrites the send buffer in place ...
+        for fn in calls:            # ... and the replay re-issues the recorded collectives on the same objects
+            fn()
+        if rank == 0:
+            ret["n_eager"] = len(calls)
+            ret["first"] = first[:, 0].tolist()
+            ret["second"] = out[:, 0].tolist()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_recorded_collectives_can_be_reissued_on_the_same_buffers():
+    """The replay contract of graph.SegmentRecorder on the collective side: an all-gather handle's issue() and wait() are
+    recorded as eager points and, called again later, move the CURRENT contents of the same send buffer into the same
+    receive buffer."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reissue_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret["n_eager"] == 2 and ret["first"] == [0.0, 1.0] and ret["second"] == [10.0, 11.0], dict(ret)
