@@ -40,6 +40,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+_T0 = time.perf_counter()
+
+
+def phase(msg):
+    """Progress on stderr (rank 0), stamped with the seconds since start: a slow box and a hang must be
+    distinguishable from the log of a timed-out run (the 720p configurations of round 2, profiles/r02_head_note.txt)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:8.1f} s] {msg}", file=sys.stderr, flush=True)
+
 BASELINE_VIDEOS_PER_S = 1.0 / 1.9  # README.md:32,298 — TurboWan2.1-T2V-1.3B-480P, 1x RTX 5090
 # published TurboDiffusion latencies (s per video, 1x RTX 5090; BASELINE.md) for the other model/resolution pairs
 PUBLISHED_S = {("Wan2.1-1.3B", "480p"): 1.9, ("Wan2.1-14B", "480p"): 9.9, ("Wan2.1-14B", "720p"): 24.0,
@@ -113,17 +122,18 @@ def pmc_traffic(prefixes):
     return (b / n) if n else None
 
 
-def cpu_baseline(cfg, lat_shape, topk):
+def cpu_baseline(cfg, lat_shape, topk, reps=3):
     """Oracle port of the reference's ORIGINAL eager path (config C1: SDPA, plain Linear, eager norms; bit-pinned to the
     real reference by tests/test_oracle_cpu.py) timed on the host cores on a bounded sample of the same workload:
-    the embeddings once (a forward with 0 blocks) and TWO blocks of ONE DiT step at the full token count; only the
-    per-block time is extrapolated (x num_layers x 4 steps), the embeddings are counted as measured."""
+    the embeddings once (a forward with 0 blocks) and ONE block of ONE DiT step at the full token count, ``reps`` times
+    (BASELINE.md §3 asks for repetitions; a whole video on these cores is ~45 min, far beyond a default bench run); only
+    the per-block time (median of the repetitions) is extrapolated (x num_layers x 4 steps)."""
     from oracle import wan_ref as W
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    c2 = dict(cfg, num_layers=2)
-    sd = W.make_state_dict(c2, seed=0, with_proj_l=False)
+    c1 = dict(cfg, num_layers=1)
+    sd = W.make_state_dict(c1, seed=0, with_proj_l=False)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(lat_shape, generator=g)
     ctx = torch.randn(1, 512, cfg.get("text_dim", 4096), generator=g).bfloat16()
@@ -132,18 +142,41 @@ def cpu_baseline(cfg, lat_shape, topk):
     def run(nl):
         t0 = time.time()
         with torch.no_grad():
-            W.wan_forward(sd, c2, x, t, ctx, mode="eager", act_dtype=torch.bfloat16, return_tokens=True, num_layers=nl)
+            W.wan_forward(sd, c1, x, t, ctx, mode="eager", act_dtype=torch.bfloat16, return_tokens=True, num_layers=nl)
         return time.time() - t0
 
     t_emb = run(0)
-    t_2 = run(2)
-    blk = (t_2 - t_emb) / 2
+    blks = []
+    for r in range(reps):
+        blks.append(run(1) - t_emb)
+        phase(f"cpu baseline: block repetition {r + 1} of {reps}: {blks[-1]:.1f} s")
+    blk = sorted(blks)[len(blks) // 2]
     video_s = 4 * (t_emb + cfg["num_layers"] * blk)
     return {"value": 1.0 / video_s, "unit": "videos/s", "cores": cores, "kind": "port",
-            "embeddings_s": t_emb, "block_s": blk,
+            "embeddings_s": t_emb, "block_s": blk, "block_s_repetitions": blks,
             "sample": f"oracle eager bf16 DiT (SDPA + nn.Linear): embeddings {t_emb:.1f} s (measured once, not "
-                      f"extrapolated) + 2 of {cfg['num_layers']} blocks of 1 of 4 steps at full L ({t_2 - t_emb:.1f} s -> "
-                      f"{blk:.1f} s per block), blocks x{cfg['num_layers']}, steps x4"}
+                      f"extrapolated) + 1 of {cfg['num_layers']} blocks of 1 of 4 steps at full L, {reps} repetitions "
+                      f"({', '.join('%.1f' % b for b in blks)} s; median {blk:.1f} s per block), blocks x{cfg['num_layers']}, steps x4"}
+
+
+def box_record(net, cfg, L_tok, dev):
+    """In-run calibration of the box (K.box_calibration): INT8 matrix-pipe rate, HBM read bandwidth, shader clock under a
+    production ffn.2-shaped W8A8 GEMM of this model — so that two driver runs on two boxes can be compared."""
+    from turbodiffusion_amd import kernels as K
+    gemm_fn = None
+    lin = net.blocks[0].ffn[2]
+    if hasattr(lin, "int8_weight"):
+        a = torch.randn(L_tok, cfg["ffn_dim"], device=dev).bfloat16()
+        aq, as_ = K.quant_i8_block128(a)
+        del a
+
+        def gemm_fn():
+            K.gemm_w8a8(aq, as_, lin.int8_weight, lin.scale, torch.bfloat16, bias=lin.bias)
+    rec = K.box_calibration(gemm_fn, dev)
+    rec["note"] = ("measured in this run before the timed region: v_mfma_i32_32x32x32_i8 on all SIMDs (constant operands), "
+                   "4 GiB non-temporal read, shader clock = s_memtime / s_memrealtime x 100 MHz from a one-wave probe "
+                   "running beside the model's ffn.2 GEMM")
+    return rec
 
 
 def main():
@@ -167,6 +200,8 @@ def main():
     ap.add_argument("--sigma-max", type=float, default=0.0, help="0: 80 for T2V, 200 for I2V (the scripts' defaults)")
     ap.add_argument("--layers", type=int, default=0, help="debug: override num_layers (INVALID as a bench number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-box-calibration", action="store_true", help="skip the ~0.1 s in-run calibration of the box "
+                    "(INT8 MFMA rate, HBM read bandwidth, shader clock under the ffn.2 GEMM) reported in `box`")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel eagerly instead of replaying "
                     "one captured hipGraph per DiT forward (sequence-parallel runs are always eager)")
     ap.add_argument("--sp", type=int, default=0, help="sequence-parallel group size of the TIMED region (GPUs sharing "
@@ -180,6 +215,10 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="td_set_tuning knob for A/B runs (integers, include/turbodiffusion_amd.h: TD_TUNE_*)")
     args = ap.parse_args()
+    wd = float(os.environ.get("TD_BENCH_WATCHDOG_S", "0"))
+    if wd > 0:   # every thread's Python stack to stderr if the run is still going after wd seconds (and every wd after)
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, repeat=True, file=sys.stderr, exit=False)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -216,6 +255,7 @@ def main():
     from turbodiffusion_amd.sampler import rcm_sample
 
     wl = WORKLOADS[args.workload]
+    phase(f"library loaded; building {args.model} ({args.workload}) weights on {dev}")
     net, cfg = build_model(args.model, wl, dev, args.topk, args.layers or None)
     net_low = None
     if args.two_experts:
@@ -235,6 +275,14 @@ def main():
     # (the seed only changes the synthetic latents; every rank does identical work)
     init_noise = torch.randn(lat_shape, dtype=torch.float32, device=dev, generator=g)
     text = torch.randn(1, 512, cfg.get("text_dim", 4096), device=dev, generator=g).bfloat16()
+    # a NEW prompt per video (the real workload): every timed video gets its own text-embedding tensor, so the per-prompt
+    # work — text MLP, the all-blocks cross-attention K|V GEMM, K's RMSNorm, the V^T tiles — runs INSIDE the timed region
+    # once per video (the tensors stand in for umT5 outputs and are made before it; TD_BENCH_SAME_TEXT=1 restores round 2's
+    # single text for A/B)
+    n_text = 1 if os.environ.get("TD_BENCH_SAME_TEXT") == "1" else max(args.warmup, 1) + args.steps + 1
+    texts = [text] + [torch.randn(1, 512, cfg.get("text_dim", 4096), device=dev, generator=g).bfloat16()
+                      for _ in range(n_text - 1)]
+    text_i = [0]
     y = None
     if cfg["model_type"] == "i2v":
         y = torch.cat([torch.zeros(1, 4, *lat_shape[2:], device=dev),
@@ -266,7 +314,9 @@ def main():
 
     def one_video(model=None):
         eager = model is not None
-        return rcm_sample(model or run_net, init_noise, text, num_steps=args.num_steps, generator=g, y=y,
+        txt = texts[text_i[0] % len(texts)]
+        text_i[0] += 1
+        return rcm_sample(model or run_net, init_noise, txt, num_steps=args.num_steps, generator=g, y=y,
                           sigma_max=sigma_max, net_low=(net_low if eager else run_low), boundary=0.9)
 
     def sync():
@@ -275,8 +325,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1 if use_graph else 0)):  # (graph capture happens in the first call)
+    box = None
+    if rank == 0 and not args.no_box_calibration:
+        try:
+            box = box_record(net, cfg, L_tok if sp == 1 else -(-L_tok // 128 // sp) * 128, dev)
+            phase(f"box calibration: {box['i8_pops']:.2f} POP/s int8 MFMA, {box['hbm_read_tbps']:.2f} TB/s HBM read, "
+                  f"shader clock {box.get('sclk_mhz_gemm', float('nan')):.0f} MHz under the ffn.2 GEMM ({box['sclk_mhz_idle']:.0f} alone)")
+        except Exception as e:   # a reported extra
+            box = {"error": repr(e)}
+    phase(f"model built ({torch.cuda.memory_allocated() / 2**30:.1f} GiB allocated); warm-up"
+          + (" + hipGraph capture" if use_graph else ""))
+    for wi in range(max(args.warmup, 1 if use_graph else 0)):  # (graph capture happens in the first call)
         out = one_video()
+        torch.cuda.synchronize()
+        phase(f"warm-up video {wi + 1} done ({torch.cuda.memory_reserved() / 2**30:.1f} GiB reserved)")
     timer = K.KernelTimer({"td_gemm_w8a8", "td_attn_i8"})
     if not use_graph:
         K.set_timer(timer)  # HIP events around the dominant kernels, on the launch stream, in the timed region
@@ -287,6 +349,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     K.set_timer(None)
+    phase(f"timed region done: {args.steps} videos in {elapsed:.2f} s")
     eager_elapsed = None
     if use_graph:
         # a replayed graph has no per-launch Python hook: the per-kernel HIP events are taken on one more
@@ -298,6 +361,7 @@ def main():
         sync()
         eager_elapsed = time.perf_counter() - t1
         K.set_timer(None)
+        phase(f"eager video with per-kernel events done ({eager_elapsed:.2f} s)")
     # ---- serving-style extra (N = 1): two independent videos in flight (two graph replays on two streams); the GPU
     #      fills one video's bubbles (GEMM prologues / store phases, barrier waits) with the other's kernels
     two_in_flight = None
@@ -315,10 +379,11 @@ def main():
                 g2, n2, gm, st = ctxs[i]
                 with torch.cuda.stream(st):
                     for _ in range(n):
-                        rcm_sample(gm, n2, text, num_steps=args.num_steps, generator=g2, y=y)
+                        rcm_sample(gm, n2, texts[(i + _) % len(texts)], num_steps=args.num_steps, generator=g2, y=y)
 
             for i in range(2):   # capture + warm-up
                 run2(i, 1)
+                phase(f"two-videos-in-flight: context {i} captured")
             sync()
             t2 = time.perf_counter()
             ths = [threading.Thread(target=run2, args=(i, args.steps)) for i in range(2)]
@@ -327,6 +392,7 @@ def main():
             sync()
             two_in_flight = 2 * args.steps / (time.perf_counter() - t2)
             del ctxs
+            phase("two-videos-in-flight leg done")
         except Exception as e:  # an extra, never fatal
             two_in_flight = repr(e)
 
@@ -379,8 +445,14 @@ def main():
                     "achieved": ach / 1e12, "peak": I8_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / I8_PEAK,
                     "traffic": pmc_traffic(("gemm_w8a8_",)), "traffic_unit": "B/launch (HBM-side fetch+write, PMC)",
                     "algorithmic_bytes": sum(m * k + n * k + 2.0 * m * n for (m, n, k) in gs["metas"]) / gs["launches"],
+                    "traffic_source": "committed rocprofv3 PMC summary of this command (profiles/, latest round) — not "
+                                      "collected in this run",
                     "avg_launch_ms": gs["avg_ms"], "launches": gs["launches"],
-                    "share_of_step": gs["total_ms"] * 1e-3 / (eager_elapsed or elapsed)}
+                    # GEMM time of one video (events, eager video) over the TIMED video (graph replay); the GEMMs run
+                    # back to back on the main stream, so this is the fraction of the step they occupy
+                    "share_of_step": gs["total_ms"] * 1e-3 / per_video}
+            if box and box.get("i8_pops"):
+                roof["frac_of_box"] = ach / (box["i8_pops"] * 1e15)
         roof_attn = None
         if "td_attn_i8" in summ:
             # The sparse attention kernel re-streams K/V per Q block from the L2 / Infinity Cache (PMC: ~0.8 GB of
@@ -404,7 +476,7 @@ def main():
                          "streamed_bytes": by, "streamed_GBps": by / t_l / 1e9,
                          "streamed_note": "K/V tiles re-read per Q block, served by L2 / Infinity Cache — not HBM traffic",
                          "avg_launch_ms": a["avg_ms"], "launches": a["launches"],
-                         "share_of_step": a["total_ms"] * 1e-3 / (eager_elapsed or elapsed)}
+                         "share_of_step": a["total_ms"] * 1e-3 / per_video}
         if roof is None:
             roof = roof_attn
         res = {
@@ -436,6 +508,10 @@ def main():
         }
         if use_graph and getattr(run_net, "sp_capture_error", None):
             res["launch_mode"] = "eager enqueue (segmented hipGraph capture failed: " + run_net.sp_capture_error + ")"
+        if box is not None:
+            res["box"] = box
+        res["config"]["prompts"] = ("a new text embedding per video: the per-prompt work (text MLP, all-blocks cross-attention "
+                                    "K|V, K RMSNorm, V^T tiles) is inside the timed region") if len(texts) > 1 else "one text for all videos"
         if eager_elapsed is not None:
             res["eager_videos_per_s"] = 1.0 / eager_elapsed
         if replicas is not None:

@@ -73,6 +73,13 @@ const char* td_last_error(void);
 int td_set_tuning(int key, int value);
 /* profiling: copy the n (<= 256) 64-bit s_memtime stamps of the last TD_TUNE_GEMM_ABLATE == 9 launch to host */
 int td_debug_read(unsigned long long* host_dst, int n);
+/* measurement support (csrc/calib.hip; bench.py's "box" calibration — no reference counterpart: the reference ships no
+ * benchmark code).  td_calib_mfma_i8: blocks x 256 threads, every wave issues iters x 4 v_mfma_i32_32x32x32_i8 (2*32^3 ops
+ * each); td_calib_hbm_read: one streaming pass of 16-byte non-temporal loads over src[0, bytes); td_calib_clock_probe: one
+ * wave writes {s_memtime start, end, s_memrealtime (100 MHz) start, end} (4 x u64, device) around a wait of ticks_100mhz. */
+int td_calib_mfma_i8(int iters, int blocks, float* sink, td_stream_t stream);
+int td_calib_hbm_read(const void* src, int64_t bytes, void* sink, td_stream_t stream);
+int td_calib_clock_probe(int64_t ticks_100mhz, void* out, td_stream_t stream);
 
 /* ---- a16: per-128x128-block INT8 quantiser (quant_cuda, ops/quant/quant.cu:28-71) ----
  * x [m,n] f16|bf16 -> q [m,n] int8, s [ceil(m/128), ceil(n/128)] f32.

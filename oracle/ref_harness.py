@@ -149,7 +149,7 @@ def make_reference_wan(cfg: dict, seed: int = 0, dtype=None):
 FP32_ISLANDS = ("time_embedding", "time_projection", "head.head", "norm3")
 
 
-def reference_wan_from_sd(cfg: dict, sd: dict, act_dtype=None):
+def reference_wan_from_sd(cfg: dict, sd: dict, act_dtype=None, which: str = "wan2pt1"):
     """Reference WanModel (wan2pt1) holding exactly the weights of ``sd`` (reference key names).
 
     ``act_dtype=torch.bfloat16`` emulates the CUDA run of a bf16 checkpoint on the CPU: CUDA's
@@ -160,7 +160,7 @@ def reference_wan_from_sd(cfg: dict, sd: dict, act_dtype=None):
     bf16 — the arithmetic is then identical.  act_dtype=None keeps a plain fp32 model."""
     import torch
 
-    mod = load("wan2pt1")
+    mod = load(which)      # "wan2pt2": Wan2.2 (I2V conditions through y only, plain text cross-attention, wan2pt2.py:282,581-645)
     ref_cfg = {k: v for k, v in cfg.items() if k in (
         "model_type", "patch_size", "text_len", "in_dim", "dim", "ffn_dim", "freq_dim", "text_dim", "out_dim",
         "num_heads", "num_layers", "qk_norm", "cross_attn_norm", "eps")}

@@ -310,8 +310,8 @@ def test_turbo_diffusion_ops_compat_drives_the_reference_call_sequence(K):
 @pytest.mark.parametrize("m,n,k", [(1300, 1536, 384), (2100, 5120, 256), (1024, 320, 128)])
 @pytest.mark.parametrize("residual", [True, False])
 def test_gemm_row_stats_epilogue(K, m, n, k, residual):
-    """td_gemm_w8a8_stats: the output bits are those of td_gemm_w8a8 / td_gemm_w8a8_residual, and the per-piece (sum, sum
-    of squares) finalised by td_row_stats_finalize give the LayerNorm statistics of the stored rows (vs an fp64 evaluation
+    """td_gemm_w8a8_stats: the output bits are those of td_gemm_w8a8 / td_gemm_w8a8_residual, and the per-piece (mean, M2)
+    merged by td_row_stats_finalize give the LayerNorm statistics of the stored rows (vs an fp64 evaluation
     of the stored 16-bit values) and the RMSNorm statistic td_rms_stats computes."""
     g = torch.Generator().manual_seed(m + n)
     a = act_like(m, k, torch.bfloat16, seed=m + n + k)
@@ -344,6 +344,43 @@ def test_gemm_row_stats_epilogue(K, m, n, k, residual):
         assert (q0 != q1).float().mean().item() < 2e-3 and (q0.int() - q1.int()).abs().max().item() <= 1
         assert (s0 != s1).float().mean().item() < 0.05
         torch.testing.assert_close(s0, s1, rtol=1e-2, atol=0)
+
+
+@pytest.mark.parametrize("offset,spread", [(100.0, 1.0), (-300.0, 4.0), (1000.0, 8.0)])
+@pytest.mark.parametrize("residual", [True, False])
+def test_row_stats_keep_their_digits_on_dc_heavy_rows(K, offset, spread, residual):
+    """Rows whose mean is 100-1000x their spread (what a DC-heavy channel pattern does to a residual stream): a one-pass
+    E[x^2] - mean^2 in fp32 loses 4-6 of its 7 digits there (mean^2 / var = 1e4 ... 1e6) — the STATS epilogue carries
+    per-piece (mean, M2) of shifted values and td_row_stats_finalize merges them Chan-style, so (mean, rstd) must agree
+    with an fp64 evaluation of the stored 16-bit values as tightly as for zero-mean rows (same rtol as
+    test_gemm_row_stats_epilogue), like the reference's two-pass statistics (ops/core.py:293-335)."""
+    m, n, k = 1100, 1536, 256
+    g = torch.Generator().manual_seed(int(abs(offset)))
+    a = act_like(m, k, torch.bfloat16, seed=77)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5 * spread).to(torch.bfloat16)
+    aq, as_ = K.quant_i8_block128(a.to(DEV))
+    wq, ws = K.quant_i8_block128(w.to(DEV))
+    if residual:     # the offset sits in the residual stream, the GEMM adds the spread
+        b = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+        x0 = (offset + spread * torch.randn(m, n, generator=g)).to(torch.bfloat16).to(DEV)
+        out, part = K.gemm_w8a8_stats(aq, as_, wq, ws, b, x=x0, gate=torch.ones(1, n, device=DEV))
+    else:            # the offset comes in through the bias
+        b = torch.full((n,), offset, dtype=torch.bfloat16, device=DEV)
+        out, part = K.gemm_w8a8_stats(aq, as_, wq, ws, b)
+    r64 = out.double()
+    mean, var = r64.mean(-1), r64.var(-1, unbiased=False)
+    assert (mean.abs() / var.sqrt()).min().item() > 30, "the rows are not DC-heavy: the test does not exercise the hazard"
+    st = K.row_stats_finalize(part, n, 1e-6)
+    torch.testing.assert_close(st[:, 0].double(), mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(st[:, 1].double(), 1.0 / torch.sqrt(var + 1e-6), rtol=2e-5, atol=0)
+    # ... and they are the two-pass kernel's statistics to its own rounding: the INT8 codes downstream agree
+    sc, sh = (0.2 * torch.randn(1, n, generator=g)).to(DEV), (0.2 * torch.randn(1, n, generator=g)).to(DEV)
+    q0, s0 = K.layernorm_quant(out, None, None, 1e-6, sc, sh, rows_per_batch=m)
+    q1, s1 = K.layernorm_quant(out, None, None, 1e-6, sc, sh, rows_per_batch=m, stats=st)
+    assert (q0 != q1).float().mean().item() < 2e-3 and (q0.int() - q1.int()).abs().max().item() <= 1
+    rstd = K.row_stats_finalize(part, n, 1e-6, rms=True)
+    torch.testing.assert_close(rstd, K.rms_stats(out, n, 1e-6), rtol=2e-6, atol=0)
+
 
 
 # ---------------------------------------------------------------- V^T tiles from the q|k|v GEMM's epilogue

@@ -1,0 +1,132 @@
+"""-m gpu parity at the BASELINE.json configurations that had no oracle fixture before round 3 (oracle/make_golden_r03.py):
+  c4     Wan2.1-14B / Wan2.2-A14B 720p at the REAL token count L = 75 600 (591 Q blocks, 1182 K blocks, 118 selected, 80-row
+         M tail): quantiser scales + codes bit-exact at [75 600, 5120]; W8A8 GEMM row blocks <= 1 bf16 ulp; Sage scales +
+         codes bit-exact and block map >= 99 % on a 4-head subset; SageSLA rows rel-L2 <= 2e-2
+  c2     configs[1], dense SageAttention INT8-QK at L = 32 760: sampled Q blocks vs the oracle, rel-L2 <= 2e-2
+  steps  4 layers x 4 rCM steps at L = 4096: the DiT forward teacher-forced on the oracle's latents (velocity per step) and
+         the free-running sampler (latent per step); the per-step rel-L2 figures are printed and bounded."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import make_golden_c1 as G
+from oracle import make_golden_r03 as R
+from tests.util import cosine, rel_l2, ulp_diff_bf16
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def K():
+    from turbodiffusion_amd import kernels
+    return kernels
+
+
+def _load(name):
+    path = os.path.join(GOLD, f"r03_{name}.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    return torch.load(path, weights_only=False)
+
+
+def test_c4_operator_level_at_the_real_720p_size(K):
+    g = _load("c4")
+    i = R.c4_inputs(device=DEV)          # the hash inputs, built on the GPU (same bits as the oracle's CPU copy)
+    L, H = i["L"], R.C4["heads"]
+    assert L == 75600 and K.cdiv(L, 128) == 591 and K.cdiv(L, 64) == 1182
+    # ---- a16: block-128 quantiser at [75 600, 5120]: all 591 x 40 scales, every block's codes
+    xq, xs = K.quant_i8_block128(i["act"])
+    assert torch.equal(xs.cpu(), g["quant_scales"]), "quantiser scales must be bit-exact"
+    assert torch.equal(G.block_code_sums(xq, 128, 128).cpu(), g["quant_code_sums"]), "int8 codes must be bit-exact"
+    # ---- a17: W8A8 GEMM at M = 75 600 (80-row tail), N = K = 5120: whole row blocks incl. the tail
+    wq, ws = K.quant_i8_block128(i["wgt"])
+    y = K.gemm_w8a8(xq, xs, wq, ws, torch.bfloat16, bias=i["bias"])
+    rows = R.block_rows(R.C4["gemm_blocks"], L).to(DEV)
+    assert len(rows) == 128 + 128 + 80
+    ulp = ulp_diff_bf16(y[rows], g["gemm_rows"])
+    assert ulp.max().item() <= 1 and (ulp > 0).float().mean().item() < 0.01
+    del xq, y, i["act"]
+    # ---- a13: Sage per-block INT8 of q and k - km on 4 heads at the full L
+    q, k, v = i["q"], i["k"], i["v"]
+    km = g["km"].to(DEV)
+    pq, q8, qs = K.sage_quant_pool(q, None, 128)
+    pk, k8, ks = K.sage_quant_pool(k, km, 64)
+    assert torch.equal(qs.cpu(), g["q_s"]) and torch.equal(ks.cpu(), g["k_s"]), "sage scales must be bit-exact"
+    q_sums = torch.stack([G.block_code_sums(q8[h], 128, 128) for h in range(H)])[..., 0]
+    k_sums = torch.stack([G.block_code_sums(k8[h], 64, 128) for h in range(H)])[..., 0]
+    assert torch.equal(q_sums.cpu(), g["q_code_sums"]) and torch.equal(k_sums.cpu(), g["k_code_sums"]), "sage codes"
+    assert ulp_diff_bf16(K.seq_mean(k), g["km"]).max().item() <= 1
+    # ---- a11: 118 of 1182 blocks per Q block
+    topk = g["topk"]
+    assert topk == 118
+    lut = K.sla_topk(pq, pk, topk)
+    kb = 1182
+    ref_map = torch.from_numpy(np.unpackbits(g["sparse_map_bits"].numpy(), axis=-1)[..., :kb].astype(bool))
+    got = torch.zeros(H, lut.shape[1], kb, dtype=torch.bool).scatter_(-1, lut.cpu().long(), True)
+    assert got.sum(-1).eq(topk).all()
+    agree = (got & ref_map).sum().item() / ref_map.sum().item()
+    assert agree >= 0.99, f"block-map set agreement {agree:.4f}"
+    # ---- a13 + a14: SageSLA (sparse + linear branch) rows of sampled Q blocks, tail block included
+    from turbodiffusion_amd.sla import sparse_linear_attention_hld
+    out = torch.empty(L, H * 128, dtype=torch.bfloat16, device=DEV)
+    sparse_linear_attention_hld(q, k, v.transpose(0, 1).contiguous(), i["wp"], i["bp"], R.C4["topk"], True, out,
+                                128, H * 128, (128, H * 128))
+    got_rows = out[R.block_rows(R.C4["q_blocks"], L).to(DEV)]
+    assert torch.isfinite(got_rows).all()
+    assert cosine(got_rows, g["attn_rows"]) > 0.9995
+    assert rel_l2(got_rows, g["attn_rows"]) < 2e-2, rel_l2(got_rows, g["attn_rows"])
+
+
+def test_c2_dense_sage_attention_at_full_length(K):
+    """BASELINE.json configs[1]: dense SageAttention (INT8 QK^T, FP16 PV, no sparsity, no linear branch) at L = 32 760."""
+    g = _load("c2")
+    i = G.op_inputs("c1")
+    L, H = i["L"], 12
+    q, k, v = i["q"].to(DEV), i["k"].to(DEV), i["v"].to(DEV)
+    from turbodiffusion_amd.sla import sparse_linear_attention_hld
+    out = torch.empty(L, H * 128, dtype=torch.bfloat16, device=DEV)
+    sparse_linear_attention_hld(q, k, v.transpose(0, 1).contiguous(), None, None, 1.0, True, out, 128, H * 128,
+                                (128, H * 128), dense=True)
+    rows = R.block_rows(R.C2["q_blocks"], L).to(DEV)
+    assert len(rows) == 3 * 128 + 120
+    got = out[rows]
+    assert torch.isfinite(got).all()
+    assert cosine(got, g["attn_rows"]) > 0.9995
+    assert rel_l2(got, g["attn_rows"]) < 2e-2, rel_l2(got, g["attn_rows"])
+    # tail block alone (120 valid rows, last K block 56 keys): masked keys must not leak
+    tail = got[-120:]
+    assert rel_l2(tail, g["attn_rows"][-120:]) < 2e-2
+
+
+def test_four_layers_four_steps_against_the_oracle(K, capsys):
+    """"full 4-step latent vs the CPU reference at identical noise: report rel-L2 per step" — here against the
+    oracle's turbo arithmetic (W8A8 + Fast norms + SageSLA), 4 layers deep, L = 4096, both teacher-forced and free-running."""
+    from turbodiffusion_amd.sampler import rcm_sample, rcm_timesteps
+    from turbodiffusion_amd.wan import WanModel
+    g = _load("steps")
+    c, x0, ctx, noises, sd = R.steps_inputs()
+    with torch.device(DEV):
+        net = WanModel(attention_type="sagesla", sla_topk=c["topk"], quant_linear=True, **c["cfg"])
+    net.load_from_float_state_dict({k_: v_.to(DEV) for k_, v_ in sd.items()})
+    net.eval()
+    ctx_d = ctx.to(DEV)
+    ts = rcm_timesteps(4, 80.0)
+    forced = []
+    for s in range(4):     # teacher-forced: the oracle's input latent of step s -> velocity
+        t_in = torch.full((1, 1), float(ts[s].float()) * 1000.0, dtype=torch.float64, device=DEV).bfloat16()
+        v = net(g["x_in"][s].to(DEV), t_in, ctx_d)
+        forced.append(rel_l2(v, g["v"][s].float()))
+        assert cosine(v, g["v"][s].float()) > 0.999
+    states = []
+    out = rcm_sample(net, x0.to(DEV), ctx_d, noises=noises, step_hook=lambda i_, x: states.append(x.float().clone()))
+    free = [rel_l2(st, g["states"][s].float()) for s, st in enumerate(states)]
+    with capsys.disabled():
+        print(f"\n[4 layers x 4 steps, L = 4096] velocity rel-L2 per step (teacher-forced): {[round(f, 4) for f in forced]}; "
+              f"latent rel-L2 per step (free-running): {[round(f, 4) for f in free]}")
+    # 4 blocks deep the block-map's near-ties and the INT8 rounding differences compound (one block: <= 2e-2, test_gpu_c1)
+    assert max(forced) < 4e-2, forced
+    assert max(free) < 4e-2 and rel_l2(out, g["final"]) < 4e-2, (free, rel_l2(out, g["final"]))

@@ -105,3 +105,63 @@ def test_seqpar_segmented_graph_replay_is_bit_identical_to_eager(attention):
     assert ret["differ"] and all(ret["same"]), dict(ret)
     layers = 2
     assert ret["segments"] >= 2 * layers + 1 and ret["eager_points"] >= 2 * layers + 1, dict(ret)
+
+
+def _nccl_worker(rank, world, port, attention, ret):
+    """ONE rank, backend nccl: a 1-rank RCCL communicator on the one GPU of the box is legal.  It executes what gloo cannot:
+    RCCL initialisation, ``all_gather_into_tensor(..., async_op=True)`` on device buffers, ``work.wait()`` (a stream-side
+    wait, not a host join), and the segmented hipGraph replay with real RCCL launches between the segments
+    (seqpar._Gather.issue / _wait, graph.SegmentRecorder)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from oracle import wan_ref as W
+        from tests.test_gpu_wan import make_net
+        from turbodiffusion_amd import seqpar
+        from turbodiffusion_amd.graph import GraphedModel
+        gold = torch.load(GOLD, weights_only=False)
+        cfg = gold["cfg"]
+        sd = W.make_state_dict(cfg, gold["sd_seed"])
+        net = make_net(cfg, sd, attention, True, topk=0.5)
+        g = torch.Generator().manual_seed(17)
+        xs = [torch.randn(1, 16, 5, 16, 24, generator=g).to("cuda").bfloat16() for _ in range(2)]
+        ctx = gold["ctx"].to("cuda").bfloat16()
+        ts = [gold["t"].to("cuda").bfloat16(), (gold["t"] * 0.5).to("cuda").bfloat16()]
+        ref = net(xs[0], ts[0], ctx).clone()
+        seqpar.enable(net, dist.group.WORLD)
+        ret["backend"] = dist.get_backend(dist.group.WORLD)
+        eager = [net(x, t, ctx).clone() for x, t in zip(xs, ts)]
+        gm = GraphedModel(net)
+        outs = [gm(x, t, ctx).clone() for x, t in zip(xs, ts)]
+        outs.append(gm(xs[0], ts[0], ctx).clone())
+        torch.cuda.synchronize()
+        ret["capture_error"] = gm.sp_capture_error
+        if gm.sp_capture_error is None:
+            rec = next(iter(gm._graphs.values()))[0]
+            ret["segments"] = rec.n_segments
+            ret["eager_points"] = len(rec.chain) - rec.n_segments
+        ret["rel"] = rel_l2(eager[0], ref)
+        ret["cos"] = cosine(eager[0], ref)
+        ret["same"] = [bool(torch.equal(outs[0], eager[0])), bool(torch.equal(outs[1], eager[1])),
+                       bool(torch.equal(outs[2], eager[0]))]
+        ret["differ"] = not torch.equal(eager[0], eager[1])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("attention", ["sagesla", "sage"])
+def test_seqpar_over_rccl_one_rank(attention):
+    """The ``nccl`` (= RCCL) branch of seqpar — asynchronous device all-gathers, ``work.wait()``, segmented-graph replay
+    around real RCCL calls — on a 1-rank communicator (all the GPU box can host).  One rank owns every token, so the result
+    must agree with the unsharded forward to the sequence-parallel path's tolerance, and graph replay with eager exactly."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_nccl_worker, args=(1, _free_port(), attention, ret), nprocs=1, join=True)
+    assert ret["backend"] == "nccl", dict(ret)
+    assert ret["rel"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
+    assert ret["capture_error"] is None, dict(ret)      # the segmented capture must work on the real RCCL stack
+    assert ret["differ"] and all(ret["same"]), dict(ret)
+    assert ret["segments"] >= 5 and ret["eager_points"] >= 5, dict(ret)

@@ -67,6 +67,35 @@ def test_oracle_dit_matches_live_reference():
 
 
 @pytest.mark.skipif(not rh.available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("model_type,in_dim", [("i2v", 36), ("t2v", 16)])
+def test_oracle_dit_matches_live_reference_wan2pt2(model_type, in_dim):
+    """Wan2.2 (rcm/networks/wan2pt2.py:251-276 self-attention, :282 the plain text cross-attention for BOTH model types,
+    :581-645 forward with ``y_B_C_T_H_W`` concatenated on channels — in_dim 36 = 16 + 4 mask + 16 image-latent channels,
+    wan2.2_i2v_infer.py:149-152): the oracle's forward against the LIVE reference module, bit for bit."""
+    warnings.filterwarnings("ignore")
+    cfg = dict(dim=256, eps=1e-6, ffn_dim=384, freq_dim=256, in_dim=in_dim, model_type=model_type, num_heads=2,
+               num_layers=2, out_dim=16, text_len=512, text_dim=64)
+    sd = W.make_state_dict(cfg, seed=8)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 16, 2, 8, 10, generator=g)
+    y = None
+    if model_type == "i2v":
+        y = torch.cat([torch.zeros(2, 4, 2, 8, 10), torch.randn(2, 16, 2, 8, 10, generator=g)], 1)
+        y[:, :4, 0] = 1.0
+    t = torch.tensor([[995.025], [852.895]])
+    ctx = torch.randn(2, 512, 64, generator=g)
+    net = rh.reference_wan_from_sd(cfg, sd, torch.bfloat16, which="wan2pt2")
+    with torch.no_grad():
+        ref = net(x.bfloat16(), t.bfloat16(), ctx.bfloat16(), y_B_C_T_H_W=None if y is None else y.bfloat16())
+    out = W.wan_forward(sd, cfg, x, t.bfloat16(), ctx.bfloat16(), y_B_C_T_H_W=None if y is None else y.bfloat16(),
+                        mode="eager")
+    assert torch.equal(out, ref)
+    if y is not None:   # the conditioning channels are really read
+        out0 = W.wan_forward(sd, cfg, x, t.bfloat16(), ctx.bfloat16(), y_B_C_T_H_W=torch.zeros_like(y).bfloat16(), mode="eager")
+        assert not torch.equal(out0, out)
+
+
+@pytest.mark.skipif(not rh.available(), reason="/root/reference not present (GPU box)")
 def test_oracle_rope_and_freqs_match_reference():
     mod = rh.load("wan2pt1")
     emb = mod.VideoRopePosition3DEmb(head_dim=128, len_h=128, len_w=128, len_t=32)

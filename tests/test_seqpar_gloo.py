@@ -196,3 +196,38 @@ def test_recorded_collectives_can_be_reissued_on_the_same_buffers():
     ret = mgr.dict()
     mp.spawn(_reissue_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret["n_eager"] == 2 and ret["first"] == [0.0, 1.0] and ret["second"] == [10.0, 11.0], dict(ret)
+
+
+def _agree_worker(rank, world, port, scenario, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from turbodiffusion_amd.graph import agree_on_capture_outcome
+        # scenario -> (failed, collectives issued) per rank
+        failed, k = {"all_ok": (False, 12), "all_fail_same_point": (True, 5),
+                     "one_rank_fails": (rank == 1, 5 if rank == 1 else 12)}[scenario]
+        try:
+            ret[rank] = ("agreed", agree_on_capture_outcome(dist.group.WORLD, failed, k, timeout_s=30))
+            # a second exchange on the same group must not see the first one's keys
+            ret[10 + rank] = ("agreed", agree_on_capture_outcome(dist.group.WORLD, False, 3, timeout_s=30))
+        except RuntimeError as e:
+            ret[rank] = ("raised", str(e)[:60])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario", ["all_ok", "all_fail_same_point", "one_rank_fails"])
+def test_capture_outcome_is_agreed_through_the_store(scenario):
+    """graph.agree_on_capture_outcome: a failure of the segmented capture that is common to all ranks lets every rank fall
+    back to eager enqueue; a rank-local one makes EVERY rank raise (their collective sequences are misaligned) — decided
+    over the store, not over the communicator in question."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_agree_worker, args=(2, _free_port(), scenario, ret), nprocs=2, join=True)
+    if scenario == "one_rank_fails":
+        assert ret[0][0] == "raised" and ret[1][0] == "raised", dict(ret)
+    else:
+        want = scenario == "all_fail_same_point"
+        assert ret[0] == ("agreed", want) and ret[1] == ("agreed", want), dict(ret)
+        assert ret[10] == ("agreed", False) and ret[11] == ("agreed", False), dict(ret)

@@ -27,6 +27,9 @@ SIGNATURES = {
     "td_last_error": [],
     "td_set_tuning": [_i32, _i32],
     "td_debug_read": [_vp, _i32],
+    "td_calib_mfma_i8": [_i32, _i32, _vp, _vp],
+    "td_calib_hbm_read": [_vp, _i64, _vp, _vp],
+    "td_calib_clock_probe": [_i64, _vp, _vp],
     "td_quant_i8_block128": [_vp, _i32, _vp, _vp, _i64, _i64, _vp],
     "td_gemm_w8a8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _vp],
     "td_gemm_w8a8_quant": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp],

@@ -85,8 +85,8 @@ __device__ __forceinline__ uint32_t f_swz(uint32_t row, uint32_t chunk) {
 //   |fast - exact| <= 2^-24 * (G+1) * 1.5*2^23 * sum_k s_k = 0.75 (G+1) sum_k s_k     (fp32, before the 16-bit cast)
 // i.e. < 4 counts of a K block's integer sum per block for G = 4, against typical |isum| ~ 1e4 (rel. ~1e-4..3e-4, an
 // order below the bf16 rounding of the result).  1.25 VALU per element and K block instead of 2.
-// STATS: the (plain or RES) epilogue also emits, per output row and per 64-column piece of it, (sum, sum of squares) of the
-// 16-bit values it stores — QS is then a float2 workspace [M, ldqs] with ldqs = N / 64 pieces per row.  td_row_stats_finalize
+// STATS: the (plain or RES) epilogue also emits, per output row and per 64-column piece of it, (mean, M2 = sum of squared
+// deviations from that mean) of the 16-bit values it stores — QS is then a float2 workspace [M, ldqs] with ldqs = N / 64 pieces per row.  td_row_stats_finalize
 // turns the pieces into the row statistics of the LayerNorm / RMSNorm that reads this output next, which therefore needs no
 // statistics pass of its own over the [M, N] tensor.
 // VT = 1 | 2 (plain epilogue only): the columns n >= ldqs (a multiple of 256: whole tiles) are V of a fused q|k|v
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int64_t m = m0 + wm * 128 + i * 16 + l16;
-    float st_s = 0.f, st_q = 0.f;   // STATS: this lane's share of the row's 64-column piece
+    float st_s = 0.f, st_q = 0.f, st_c = 0.f;   // STATS: this lane's share of the row's 64-column piece (shifted by st_c)
     uint32_t pk[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -560,11 +560,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         }
       }
       if constexpr (STATS) {
+        float sv[8];
+        unpack8<ODT>(outv, sv);
+        // sums of the values SHIFTED by one sample of the row's piece (the first value of the piece's first lane): a row
+        // whose mean is large against its spread (DC-heavy channels) loses no digits to sum-of-squares cancellation
+        if (jp == 0) st_c = __shfl(sv[0], l16, 64);
         if (m < M && n < N) {
-          float sv[8];
-          unpack8<ODT>(outv, sv);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { st_s += sv[e]; st_q = fmaf(sv[e], sv[e], st_q); }
+          for (int e = 0; e < 8; ++e) { const float d = sv[e] - st_c; st_s += d; st_q = fmaf(d, d, st_q); }
         }
       }
       *reinterpret_cast<uint4*>(stg_lds + ((i & 3) * 16 + l16) * 72 + jt * 16 + 8 * (lq & 1)) = outv;
@@ -604,8 +607,12 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       // the row's 64 columns of this wave tile sit in the 4 lanes l16 + 16*lq: fixed-order butterfly, then one 8-byte store
       st_s += __shfl_xor(st_s, 16, 64); st_q += __shfl_xor(st_q, 16, 64);
       st_s += __shfl_xor(st_s, 32, 64); st_q += __shfl_xor(st_q, 32, 64);
-      if (lq == 0 && m < M && n0 + wn * 64 < N)
-        reinterpret_cast<float2*>(QS)[m * ldqs + ((n0 + wn * 64) >> 6)] = make_float2(st_s, st_q);
+      // the piece's 64 values as (mean, M2 = sum of squared deviations from that mean): S, Q are sums of d = v - c, so
+      // mean = c + S/64 and M2 = Q - S^2/64 with |S/64| of the order of the piece's own spread (c is one of its values)
+      if (lq == 0 && m < M && n0 + wn * 64 < N) {
+        const float ds = st_s * (1.0f / 64.0f);
+        reinterpret_cast<float2*>(QS)[m * ldqs + ((n0 + wn * 64) >> 6)] = make_float2(st_c + ds, fmaxf(fmaf(-ds, st_s, st_q), 0.f));
+      }
     }
   }
   if constexpr (DBG >= 2) {

@@ -186,11 +186,15 @@ __global__ __launch_bounds__(256) void ln_apply_quant_kernel(
   }
 }
 
-// row statistics from the per-piece (sum, sum of squares) a GEMM's STATS epilogue wrote (gemm_w8a8_fi.hip): EIGHT lanes per
-// row (lane j sums pieces j, j+8, ... in order, then a fixed 3-step butterfly: deterministic) — a wave reads 8 rows x 64
-// contiguous bytes per step instead of 64 rows x 8 bytes (the one-thread-per-row form took 5.8 us for 6 MB).
-// mode 0: LayerNorm -> out float2 [m] = (mean, 1/sqrt(var + eps)) with var = E[x^2] - mean^2 (>= 0);
-// mode 1: RMSNorm -> out float [m] = 1/sqrt(E[x^2] + eps).
+// row statistics from the per-piece (mean, M2) a GEMM's STATS epilogue wrote (gemm_w8a8_fi.hip; every piece = 64 values,
+// M2 = sum of squared deviations from the piece's own mean): merged with the pairwise-update formula of Chan et al. —
+//   mean = sum_p mean_p / P,   M2 = sum_p M2_p + 64 * sum_p (mean_p - mean)^2
+// — so nothing is ever formed as E[x^2] - mean^2: the result keeps fp32 accuracy for rows whose mean is large against
+// their spread (the two-pass statistics of the reference, ops/core.py:293-335, have that property; a one-pass
+// (sum, sum of squares) does not).  EIGHT lanes per row (lane j takes pieces j, j+8, ... in order, then a fixed 3-step
+// butterfly: deterministic) — a wave reads 8 rows x 64 contiguous bytes per step.
+// mode 0: LayerNorm -> out float2 [m] = (mean, 1/sqrt(M2/n + eps));
+// mode 1: RMSNorm -> out float [m] = 1/sqrt(E[x^2] + eps), E[x^2] = sum_p (M2_p + 64 mean_p^2) / n (a sum of non-negatives).
 __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* __restrict__ ws, int pieces, float inv_n,
                                                                 float eps, int mode, float* __restrict__ out, int64_t m) {
   const int sub = threadIdx.x & 7;
@@ -201,19 +205,27 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* _
   for (int p = sub; p < pieces; p += 8) {
     const float2 v = ws[row * pieces + p];
     s += v.x;
-    q += v.y;
+    q += (mode == 0) ? v.y : fmaf(64.0f * v.x, v.x, v.y);
   }
 #pragma unroll
   for (int o = 1; o < 8; o <<= 1) {
     s += __shfl_xor(s, o, 64);
     q += __shfl_xor(q, o, 64);
   }
-  if (!ok || sub != 0) return;
   if (mode == 0) {
-    const float mean = s * inv_n;
-    const float var = fmaxf(fmaf(-mean, mean, q * inv_n), 0.f);
+    const float mean = s / (float)pieces;
+    float b = 0.f;                       // between-piece part: 64 * sum (mean_p - mean)^2 (second read: L1/L2-resident)
+    for (int p = sub; p < pieces; p += 8) {
+      const float d = ws[row * pieces + p].x - mean;
+      b = fmaf(d, d, b);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) b += __shfl_xor(b, o, 64);
+    if (!ok || sub != 0) return;
+    const float var = fmaf(64.0f, b, q) * inv_n;
     reinterpret_cast<float2*>(out)[row] = make_float2(mean, 1.0f / sqrtf(var + eps));
   } else {
+    if (!ok || sub != 0) return;
     out[row] = 1.0f / sqrtf(q * inv_n + eps);
   }
 }
@@ -221,7 +233,8 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* _
 extern "C" int td_row_stats_finalize(const float* ws, int pieces, int64_t n, float eps, int mode, float* out, int64_t m,
                                      td_stream_t stream) {
   TD_REQUIRE(ws && out, TD_ERR_INVALID, "td_row_stats_finalize: null pointer");
-  TD_REQUIRE(pieces > 0 && n > 0 && m >= 0 && (mode == 0 || mode == 1), TD_ERR_INVALID, "td_row_stats_finalize: pieces=%d n=%lld mode=%d", pieces, (long long)n, mode);
+  TD_REQUIRE(pieces > 0 && n == (int64_t)pieces * 64 && m >= 0 && (mode == 0 || mode == 1), TD_ERR_INVALID,
+             "td_row_stats_finalize: pieces=%d n=%lld mode=%d (need n == 64 * pieces: every piece is 64 values)", pieces, (long long)n, mode);
   if (m == 0) return TD_OK;
   row_stats_finalize_kernel<<<(unsigned)td_cdiv(m, 32), 256, 0, (hipStream_t)stream>>>(
       reinterpret_cast<const float2*>(ws), pieces, 1.0f / (float)n, eps, mode, out, m);

@@ -51,9 +51,9 @@ class SegmentRecorder:
         self._g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
 
     def _end(self):
-        self._g.capture_end()
-        self.chain.append(("graph", self._g))
-        self._g = None
+        g, self._g = self._g, None
+        g.capture_end()
+        self.chain.append(("graph", g))
 
     def _eager(self, fn):
         self._end()
@@ -74,9 +74,16 @@ class SegmentRecorder:
             _ACTIVE = self
             try:
                 out = fn()
-            finally:
+            except BaseException:
                 _ACTIVE = None
-                self._end()
+                if self._g is not None:      # close the open capture without masking the original error
+                    try:
+                        self._end()
+                    except Exception:
+                        pass
+                raise
+            _ACTIVE = None
+            self._end()
         torch.cuda.current_stream().wait_stream(self.stream)
         return out
 
@@ -92,12 +99,45 @@ class SegmentRecorder:
         return sum(1 for k, _ in self.chain if k == "graph")
 
 
+_AGREE_SEQ = {}   # per group: how many capture outcomes have been exchanged (identical on every rank: same code path)
+
+
+def agree_on_capture_outcome(group, failed: bool, eager_points: int, timeout_s: float = 120.0):
+    """Every rank of ``group`` reports how its segmented capture pass ended — (failed?, collectives issued before the end) —
+    through the process group's key-value STORE, i.e. outside the communicator whose call sequence is in question, and
+    learns the others' reports.  Returns ``failed`` if all ranks agree (a deterministic failure — same code, same shapes,
+    same point — leaves every rank's collective sequence aligned, so a common eager fallback is safe).  A rank-local
+    failure (out of memory, pool exhaustion on one GPU) leaves the ranks' sequences misaligned: the failing rank issued k
+    collectives, the others N, and any further collective would hang or gather mismatched buffers — every rank raises
+    instead, so the job dies with a message rather than hanging."""
+    import datetime
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return failed
+    store = dist.distributed_c10d._get_default_store()
+    ranks = dist.get_process_group_ranks(group)
+    me = dist.get_rank()
+    seq = _AGREE_SEQ[ranks[0]] = _AGREE_SEQ.get(ranks[0], 0) + 1
+    pre = f"td_sp_capture/{ranks[0]}-{len(ranks)}/{seq}/"
+    store.set(pre + str(me), f"{int(failed)},{eager_points}")
+    keys = [pre + str(r) for r in ranks]
+    store.wait(keys, datetime.timedelta(seconds=timeout_s))
+    reports = {r: store.get(pre + str(r)).decode() for r in ranks}
+    if len(set(reports.values())) != 1:
+        raise RuntimeError("segmented hipGraph capture of the sequence-parallel forward ended differently on the ranks of the "
+                           f"group (rank -> failed,collectives issued: {reports}); their collective sequences are misaligned and "
+                           "cannot continue — fix the rank-local failure (memory?) or run with eager enqueue")
+    return failed
+
+
 class GraphedModel(torch.nn.Module):
     def __init__(self, net: torch.nn.Module):
         super().__init__()
         self.net = net
         self._graphs = {}
-        self._text_src = {}   # per graph: identity/version of the text tensor last copied into its static buffer
+        self._text_src = {}   # per graph: (the text tensor last copied into its static buffer — the OBJECT, held so that its
+        #                       address cannot be recycled for another prompt — , its version at that time)
         self._epoch = getattr(net, "_weights_epoch", 0)
         self._sp_eager = False        # set when a segmented capture failed: eager from then on (sp_capture_error says why)
         self.sp_capture_error = None
@@ -105,6 +145,16 @@ class GraphedModel(torch.nn.Module):
     def _key(self, x, t, ctx, y):
         return (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype,
                 None if y is None else (tuple(y.shape), y.dtype))
+
+    def _refresh_text(self, key, sc, crossattn_emb):
+        """Copy the caller's text embedding into the graph's static buffer unless it is the SAME tensor object at the same
+        version as last time (the other steps of one video).  The object is held: a per-request embedding that is freed and
+        re-created gets the same address and version 0 from the caching allocator — comparing (data_ptr, version) alone would
+        skip the copy and render the previous prompt."""
+        src = self._text_src.get(key)
+        if src is None or src[0] is not crossattn_emb or src[1] != crossattn_emb._version:
+            sc.copy_(crossattn_emb)
+            self._text_src[key] = (crossattn_emb, crossattn_emb._version)
 
     @torch.no_grad()
     def forward(self, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, frame_cond_crossattn_emb_B_L_D=None,
@@ -126,16 +176,13 @@ class GraphedModel(torch.nn.Module):
             # eagerly here when the text changed, a no-op (cache hit) for the other steps of a video.  The graph reads the
             # model's persistent text buffers; should the model have re-allocated them (cache eviction), re-capture.
             sc = ent[3]
-            src = (crossattn_emb.data_ptr(), crossattn_emb._version)
-            if self._text_src.get(key) != src:
-                sc.copy_(crossattn_emb)
-                self._text_src[key] = src
-            if self.net.prepare_text(sc)[2].data_ptr() != ent[6]:
+            self._refresh_text(key, sc, crossattn_emb)
+            if self.net.prepare_text(sc)[4] != ent[6]:
                 del self._graphs[key]
                 ent = None
         if ent is None:
             sx, st, sc = x_B_C_T_H_W.clone(), timesteps_B_T.clone(), crossattn_emb.clone()
-            self._text_src[key] = (crossattn_emb.data_ptr(), crossattn_emb._version)
+            self._text_src[key] = (crossattn_emb, crossattn_emb._version)
             sy = None if y_B_C_T_H_W is None else y_B_C_T_H_W.clone()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -146,9 +193,18 @@ class GraphedModel(torch.nn.Module):
             if getattr(self.net, "seq_parallel", None) is not None:
                 # segments between the collectives (identical chain on every rank: the eager points are collective calls)
                 g = SegmentRecorder()
+                err = None
                 try:
                     so = g.capture(lambda: self.net(sx, st, sc, y_B_C_T_H_W=sy))
-                except Exception as e:   # deterministic across ranks (same code, same shapes): every rank lands here
+                except Exception as e:
+                    err = e
+                # the ranks compare outcomes through the store BEFORE anyone issues another collective (a rank-local
+                # failure raises on every rank; a common one falls back to eager enqueue everywhere)
+                sp_group = getattr(getattr(self.net.seq_parallel, "sp", None), "group", None)
+                if sp_group is not None:
+                    agree_on_capture_outcome(sp_group, err is not None, sum(1 for k_, _ in g.chain if k_ == "eager"))
+                if err is not None:
+                    e = err
                     import warnings
                     warnings.warn(f"segmented hipGraph capture of the sequence-parallel forward failed ({e!r}); "
                                   f"this model now enqueues eagerly (slower, same results)")
@@ -160,16 +216,13 @@ class GraphedModel(torch.nn.Module):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     so = self.net(sx, st, sc, y_B_C_T_H_W=sy)
-            text_ptr = self.net.prepare_text(sc)[2].data_ptr() if cache_text else 0
-            ent = (g, sx, st, sc, sy, so, text_ptr)
+            text_gen = self.net.prepare_text(sc)[4] if cache_text else 0   # generation of the persistent text buffers the
+            ent = (g, sx, st, sc, sy, so, text_gen)                         # graph points into (context, every block's K / V^T)
             self._graphs[key] = ent
         g, sx, st, sc, sy, so, _ = ent
         sx.copy_(x_B_C_T_H_W)
         st.copy_(timesteps_B_T)
-        src = (crossattn_emb.data_ptr(), crossattn_emb._version)
-        if self._text_src.get(key) != src:     # a new text (or the same tensor modified in place): refresh the static copy
-            sc.copy_(crossattn_emb)
-            self._text_src[key] = src
+        self._refresh_text(key, sc, crossattn_emb)
         if sy is not None:
             sy.copy_(y_B_C_T_H_W)
         g.replay()

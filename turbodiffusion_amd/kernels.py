@@ -78,6 +78,85 @@ def set_tuning(key: int, value: int):
     call("td_set_tuning", key, value)
 
 
+# ----------------------------------------------------------------------------- measurement support (csrc/calib.hip)
+def box_calibration(gemm_fn=None, device=None):
+    """What this box sustains right now (bench.py's "box" record): the dense INT8 matrix-pipe rate, the streaming HBM read
+    bandwidth, and — when ``gemm_fn`` (a callable that enqueues one production GEMM on the current stream) is given — the
+    shader clock while that GEMM runs, from a one-wave probe on a second stream reading s_memtime against the 100 MHz
+    s_memrealtime.  ~100 ms of GPU time; every number is the best / median of a few repetitions."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    sink = torch.zeros(16, dtype=torch.float32, device=dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)   # noqa: E731
+    out = {}
+    # ---- INT8 MFMA: 256 CUs x 4 workgroups x 4 waves, 4 chains each
+    blocks, iters = 1024, 4096
+    call("td_calib_mfma_i8", 64, blocks, ptr(sink), stream_ptr())       # warm-up (code object load)
+    best = 0.0
+    for _ in range(3):
+        a, b = ev(), ev()
+        a.record()
+        call("td_calib_mfma_i8", iters, blocks, ptr(sink), stream_ptr())
+        b.record()
+        b.synchronize()
+        ops = blocks * 4 * iters * 4 * 2.0 * 32 * 32 * 32
+        best = max(best, ops / (a.elapsed_time(b) * 1e-3))
+    out["i8_pops"] = best / 1e15
+    # ---- HBM read: 4 GiB (16x the Infinity Cache), non-temporal
+    buf = torch.empty(1 << 32, dtype=torch.uint8, device=dev)
+    buf.view(torch.int32).fill_(1)
+    call("td_calib_hbm_read", ptr(buf), buf.numel(), ptr(sink), stream_ptr())
+    best = 0.0
+    for _ in range(3):
+        a, b = ev(), ev()
+        a.record()
+        call("td_calib_hbm_read", ptr(buf), buf.numel(), ptr(sink), stream_ptr())
+        b.record()
+        b.synchronize()
+        best = max(best, buf.numel() / (a.elapsed_time(b) * 1e-3))
+    out["hbm_read_tbps"] = best / 1e12
+    del buf
+    # ---- shader clock: idle-ish (probe alone) and under the production GEMM
+    stamps = torch.zeros(4, dtype=torch.int64, device=dev)
+
+    def probe(ticks):
+        call("td_calib_clock_probe", ticks, ptr(stamps), stream_ptr())
+
+    def mhz():
+        c0, c1, r0, r1 = stamps.tolist()
+        return (c1 - c0) / max(1, r1 - r0) * 100.0
+
+    probe(20000)                       # 200 us
+    torch.cuda.synchronize()
+    out["sclk_mhz_idle"] = mhz()
+    if gemm_fn is not None:
+        for _ in range(3):
+            gemm_fn()                  # warm (and ramp the power state)
+        torch.cuda.synchronize()
+        a, b = ev(), ev()
+        a.record()
+        for _ in range(4):
+            gemm_fn()
+        b.record()
+        b.synchronize()
+        t_gemm_us = a.elapsed_time(b) * 1e3 / 4
+        side = torch.cuda.Stream()
+        vals = []
+        for _ in range(3):
+            main = torch.cuda.current_stream()
+            for _ in range(2):
+                gemm_fn()              # already running when the probe starts
+            side.wait_stream(main)     # (orders the probe behind the ENQUEUE of those two, not behind the six below)
+            with torch.cuda.stream(side):
+                probe(max(2000, int(t_gemm_us * 100 * 3)))      # spans ~3 launches
+            for _ in range(6):
+                gemm_fn()
+            torch.cuda.synchronize()
+            vals.append(mhz())
+        out["sclk_mhz_gemm"] = sorted(vals)[1]
+        out["gemm_probe_us"] = t_gemm_us
+    return out
+
+
 # ----------------------------------------------------------------------------- a16
 def quant_i8_block128(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """x [m,n] f16|bf16 -> (q int8 [m,n], s f32 [ceil(m/128), ceil(n/128)])."""

@@ -154,7 +154,8 @@ class WanModel(nn.Module):
         self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
         self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
-        self._text_states = {}     # data_ptr -> (key, source tensor, context, [per batch entry: [per block: (k, vt)]])
+        self._text_states = {}     # data_ptr -> (key, source tensor, context, [per batch entry: [per block: (k, vt)]], generation)
+        self._text_gen = 0         # bumped whenever a text entry gets NEW persistent buffers (captured graphs point into them)
         self._weights_epoch = 0   # bumped whenever derived weight copies are dropped (GraphedModel re-captures on a change)
         self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_caches())
 
@@ -380,6 +381,9 @@ class WanModel(nn.Module):
         q = None if two else q_fn()
         k = K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
         if self.seq_parallel is not None:
+            if sage and self.sage_pv != "fp16":
+                raise NotImplementedError("sage_pv='fp8' is not built for the sequence-parallel path (the packed K-side exchange "
+                                          "carries fp16 V^T tiles); use sage_pv='fp16' with seqpar.enable")
             quant_out = False
         out = dtype if quant_out else torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
         if self.seq_parallel is not None:
@@ -436,19 +440,23 @@ class WanModel(nn.Module):
         for b in range(B):
             tkv = self._text_kv_all(context[b]) if self.batch_text_kv else None
             per_b.append([self._text_kvt(i, blk, context[b], tkv) for i, blk in enumerate(self.blocks)])
+        gen = None
         if st is not None and st[2].shape == context.shape and len(st[3]) == B:
             st[2].copy_(context)                       # same buffer, new contents: refresh the persistent tensors in place
             for old_b, new_b in zip(st[3], per_b):
                 for (ok, ovt), (nk, nvt) in zip(old_b, new_b):
                     ok.copy_(nk)
                     ovt.copy_(nvt)
-            context, per_b = st[2], st[3]
+            context, per_b, gen = st[2], st[3], st[4]
+        if gen is None:     # new persistent buffers: a graph captured on an earlier generation of this entry must re-capture
+            self._text_gen += 1
+            gen = self._text_gen
         # the entry holds a reference to the source tensor: its address cannot be recycled for another text while cached,
         # so (address, version) identifies the contents.  A handful of entries (one per live text buffer), oldest dropped.
         self._text_states.pop(key[0], None)
-        while len(self._text_states) >= 4:
+        while len(self._text_states) >= 8:
             self._text_states.pop(next(iter(self._text_states)))
-        self._text_states[key[0]] = (key, crossattn_emb, context, per_b)
+        self._text_states[key[0]] = (key, crossattn_emb, context, per_b, gen)
         return self._text_states[key[0]]
 
     def _cross_attention(self, i, blk, xn, context, quant_out=False, text_kv=None, kvt=None):
@@ -569,7 +577,7 @@ class WanModel(nn.Module):
         e0 = F.linear(F.silu(e_B_D), tp[1].weight.float(), tp[1].bias.float()).unflatten(1, (6, self.dim))
         tkv = kvts = None
         if self.cache_text_kv:
-            _, _, context, kvts = self.prepare_text(crossattn_emb)   # once per text (keyed on the tensor's identity + version)
+            context, kvts = self.prepare_text(crossattn_emb)[2:4]   # once per text (keyed on the tensor's identity + version)
         else:
             context = self.text_embedding(crossattn_emb.to(dt)).contiguous()  # [B, Lc, dim]
             if self.batch_text_kv:
