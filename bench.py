@@ -17,9 +17,9 @@ every rank must receive 3 B per token-channel of the other ranks' K/V (C1: 151 M
 one link, 0.25 ms at N = 8 over seven) beside 3.3 ms / N of compute, so this is the LATENCY mode; the THROUGHPUT mode —
 N independent videos, no data-path collective — is measured after the timed region and reported beside it in
 ``replicas`` (never as ``value``).  ``--sp S`` (S < N) makes the timed region run N/S sequence-parallel groups of S
-GPUs; ``--sp 1`` N independent videos.  A collective that fails or never returns fails the run (no masking).  At N = 1
-the line also carries ``two_videos_in_flight_videos_per_s``: the same GPU with two independent videos in flight on two
-streams (a serving-style extra, +3-6 %; never the headline ``value``).  Rank 0 prints ONE JSON line.
+GPUs; ``--sp 1`` N independent videos.  A collective that fails or never returns fails the run (no masking).  With
+``--two-in-flight`` (N = 1) the line also carries ``two_videos_in_flight_videos_per_s``: the same GPU with two independent
+videos in flight on two streams (a serving-style extra, +1-6 %; never the headline ``value``; opt-in, see its help).  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
   turbo    TurboWan2.1-T2V-1.3B-480P as published: SageSLA top-k 0.1 + W8A8 linears + fused norms
@@ -208,8 +208,12 @@ def main():
                     "one video); N/sp groups run independent videos.  Default 0 = N: ONE video sharded over all GPUs")
     ap.add_argument("--no-replica-leg", action="store_true", help="N > 1: skip the throughput-mode measurement (N "
                     "independent videos) that follows the timed region")
-    ap.add_argument("--no-two-in-flight", action="store_true", help="N = 1: skip the extra measurement with two "
-                    "independent videos in flight on two streams (reported beside the headline, never as `value`)")
+    ap.add_argument("--two-in-flight", action="store_true", help="N = 1: after the timed region also measure two independent "
+                    "videos in flight (two host threads, two graph replays on two streams; reported beside the headline, never "
+                    "as `value`).  Opt-in since round 3: with the two-stream fork/join inside BOTH concurrently replayed graphs the "
+                    "GPU queues can deadlock (the 600-s timeouts of the 720p runs of round 2, tools/two_in_flight_hang.py), so the "
+                    "leg captures its graphs with WanModel.two_streams off")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="(accepted for old command lines; the leg is opt-in now)")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("TD_GEMM_VARIANT", "0")),
                     help="W8A8 GEMM kernel selection knob (0 = automatic); all variants are bit-identical")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -354,6 +358,11 @@ def main():
     if use_graph:
         # a replayed graph has no per-launch Python hook: the per-kernel HIP events are taken on one more
         # video of the SAME workload enqueued eagerly right after the timed region (same kernels, same stream)
+        # ... with the token-half split of the block tails OFF for that video: with it two GEMMs share the chip most of the
+        # time and a launch's event-to-event duration would be that of two kernels; the roofline wants one kernel's own time
+        saved_split = [(m_, m_.split_tokens) for m_ in filter(None, (net, net_low))]
+        for m_, _v in saved_split:
+            m_.split_tokens = False
         K.set_timer(timer)
         sync()
         t1 = time.perf_counter()
@@ -361,11 +370,16 @@ def main():
         sync()
         eager_elapsed = time.perf_counter() - t1
         K.set_timer(None)
+        for m_, v_ in saved_split:
+            m_.split_tokens = v_
         phase(f"eager video with per-kernel events done ({eager_elapsed:.2f} s)")
     # ---- serving-style extra (N = 1): two independent videos in flight (two graph replays on two streams); the GPU
     #      fills one video's bubbles (GEMM prologues / store phases, barrier waits) with the other's kernels
     two_in_flight = None
-    if world == 1 and use_graph and not args.no_two_in_flight:
+    if world == 1 and use_graph and args.two_in_flight and not args.no_two_in_flight:
+        saved_two = [(m_, m_.two_streams) for m_ in filter(None, (net, net_low))]
+        for m_, _v in saved_two:   # no cross-stream waits inside concurrently replayed graphs (see --two-in-flight)
+            m_.two_streams = False
         try:
             import threading
             from turbodiffusion_amd.graph import GraphedModel
@@ -395,6 +409,8 @@ def main():
             phase("two-videos-in-flight leg done")
         except Exception as e:  # an extra, never fatal
             two_in_flight = repr(e)
+        for m_, v_ in saved_two:
+            m_.two_streams = v_
 
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -503,7 +519,7 @@ def main():
             "roofline": roof, "roofline_attention": roof_attn,
             "launch_mode": (("hipGraph replay, one graph per DiT forward" if sp == 1 else
                              "hipGraph replay in segments, the all-gathers issued eagerly between them") +
-                            "; kernel events from one eager video after the timed region"
+                            "; kernel events from one eager video (full-size launches, token-half split off) after the timed region"
                             if use_graph else "eager enqueue; kernel events inside the timed region"),
         }
         if use_graph and getattr(run_net, "sp_capture_error", None):

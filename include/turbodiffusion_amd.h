@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define TD_ABI_VERSION 1
+#define TD_ABI_VERSION 2
 
 /* status codes */
 #define TD_OK 0
@@ -125,9 +125,15 @@ int td_rmsnorm(const void* x, int in_dtype, const float* w, void* y, int out_dty
  * xn = cast_out((x-mean)*rstd [*w + b])            (w,b f32 [n] or NULL,NULL)
  * if scale != NULL: y = cast_out(float(xn)*(1+scale[bi]) + shift[bi]) with
  *   bi = row / rows_per_batch, scale/shift f32 [batch, n]   (the two roundings of the reference)
- * x [m,n] in_dtype, y [m,n] out_dtype. Requires n % 8 == 0, n <= 8192. */
+ * x [m,n] in_dtype, y [m,n] out_dtype. Requires n % 8 == 0, n <= 8192.
+ * pad_cols: 0 = the textbook two-pass variance (the CUDA twin layer_norm_cuda, ops/norm/layernorm.hpp:68-77, and the
+ *   eager WanLayerNorm).  The reference's TRITON LayerNorm — what FastLayerNorm.forward / ops.layernorm actually run
+ *   (ops/core.py:380-386 -> :193-242, :293-335) — loads next_power_of_2(n) columns with the masked ones as 0 and sums
+ *   (x - mean)^2 over ALL of them (:213-224, :313-324): var = (sum_valid (x-mean)^2 + pad_cols * mean^2) / n with
+ *   pad_cols = next_power_of_2(n) - n (512 at n = 1536, 3072 at n = 5120).  Found by running those kernels on the
+ *   MI355X (tests/golden/triton_leaves.pt); pass that pad_cols to reproduce the reference's shipped arithmetic. */
 int td_layernorm(const void* x, int in_dtype, const float* w, const float* b, const float* scale,
-                 const float* shift, int64_t rows_per_batch, void* y, int out_dtype, float eps,
+                 const float* shift, int64_t rows_per_batch, void* y, int out_dtype, float eps, int64_t pad_cols,
                  int64_t m, int64_t n, td_stream_t stream);
 
 /* ---- a6 + a7 -> a16 fused: LayerNorm (+ affine, + AdaLN modulate) whose 16-bit result is block-quantised for the
@@ -136,15 +142,17 @@ int td_layernorm(const void* x, int in_dtype, const float* w, const float* b, co
  * mean / rstd between the two passes).  Requires n % 8 == 0, n <= 8192. */
 int td_layernorm_quant(const void* x, int dtype, const float* w, const float* b, const float* scale,
                        const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float* stats_ws, float eps,
-                       int64_t m, int64_t n, td_stream_t stream);
+                       int64_t pad_cols, int64_t m, int64_t n, td_stream_t stream);
 
 /* ---- a15 (+ a7) -> a5 / a6 statistics: row statistics of the NEXT norm from the producing GEMM's epilogue ----
  * td_gemm_w8a8_stats: td_gemm_w8a8 (residual == 0: d_or_x = d with row stride ld) or td_gemm_w8a8_residual (residual != 0:
  *   in place on x, gate f32 [n] or NULL) — same arithmetic, same bits — whose epilogue also writes, per output row and per
- *   64-column piece of it, (sum, sum of squares) of the 16-bit values it stores: stats_ws float2 [m, n/64].
- *   bf16, bias required, k % 128 == 0, n % 64 == 0, ld % 8 == 0.
- * td_row_stats_finalize: the pieces -> mode 0: LayerNorm statistics out float2 [m] = (mean, 1/sqrt(E[x^2] - mean^2 + eps));
- *   mode 1: RMSNorm out float [m] = 1/sqrt(E[x^2] + eps)   (== td_rms_stats up to summation order).
+ *   64-column piece of it, (mean, M2 = sum of squared deviations from that mean) of the 16-bit values it stores:
+ *   stats_ws float2 [m, n/64].  bf16, bias required, k % 128 == 0, n % 64 == 0, ld % 8 == 0.
+ * td_row_stats_finalize: the pieces merged pairwise-update style (never E[x^2] - mean^2: rows with |mean| >> spread keep
+ *   their digits, like the reference's two-pass statistics) -> mode 0: LayerNorm statistics out float2 [m] =
+ *   (mean, 1/sqrt(var + eps)), var = (M2 + pad_cols * mean^2) / n (pad_cols: see td_layernorm);
+ *   mode 1: RMSNorm out float [m] = 1/sqrt(E[x^2] + eps)   (== td_rms_stats up to summation order).  n == 64 * pieces.
  * td_layernorm_quant_stats: td_layernorm_quant's apply + quantise pass with the rows' (mean, rstd) supplied.
  * Together they remove the statistics pass of WanLayerNorm / the cross-attention q RMSNorm over [L, dim]
  * (wan2pt1.py:191-212,404-413): the residual stream is read once per LayerNorm instead of twice. */
@@ -159,8 +167,8 @@ int td_gemm_w8a8_stats(const int8_t* a, const float* a_s, const int8_t* b, const
 int td_gemm_w8a8_vt(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias, void* d,
                     int out_dtype, int64_t m, int64_t n, int64_t k, int64_t ldd, int64_t v_col0, void* vt, int vt_dtype,
                     td_stream_t stream);
-int td_row_stats_finalize(const float* ws, int pieces, int64_t n, float eps, int mode, float* out, int64_t m,
-                          td_stream_t stream);
+int td_row_stats_finalize(const float* ws, int pieces, int64_t n, float eps, int64_t pad_cols, int mode, float* out,
+                          int64_t m, td_stream_t stream);
 int td_layernorm_quant_stats(const void* x, int dtype, const float* w, const float* b, const float* scale,
                              const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, const float* row_stats,
                              int64_t m, int64_t n, td_stream_t stream);

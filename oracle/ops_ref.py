@@ -110,15 +110,28 @@ def rmsnorm_fast(x, w, eps):
     return y.to(x.dtype)
 
 
-def layernorm_fast(x, w, b, eps):
+def layernorm_fast(x, w, b, eps, triton_variance=True):
     """FastLayerNorm.forward (ops/core.py:477-478) -> layernorm (:380-386) -> Triton
     _layer_norm_{param,noparam}_fwd_fused (:193-242, :293-335): two-pass mean/var in
-    fp32, (x-mean)*rstd [*w + b], fp32 out, then ``.to(x.dtype)``."""
+    fp32, (x-mean)*rstd [*w + b], fp32 out, then ``.to(x.dtype)``.
+
+    ``triton_variance``: those kernels load N2 = next_power_of_2(N) columns with the masked ones as 0.0
+    (``tl.load(..., mask=mask[None, :], other=0.0)``, :213 / :313) and form ``_var = (x - mean) * (x - mean)`` over ALL
+    N2 columns (:219-220 / :319-320): every phantom column contributes mean^2, so
+        var = (sum_valid (x-mean)^2 + (N2 - N) * mean^2) / N
+    — not the textbook variance unless N is a power of two or the row mean is 0.  PINNED: this restatement agrees with the
+    reference kernels themselves, executed on the MI355X under Triton-ROCm, to 1e-7 (tests/golden/triton_leaves.pt,
+    tests/test_oracle_cpu.py::test_oracle_norms_match_the_reference_triton_kernels); without the term the difference is
+    1e-3.  False: the textbook form (the CUDA twin ops/norm/layernorm.hpp:68-77)."""
     xf = x.float()
     n = xf.shape[-1]
     mean = xf.sum(-1, keepdim=True) / n
     d = xf - mean
-    var = (d * d).sum(-1, keepdim=True) / n
+    ss = (d * d).sum(-1, keepdim=True)
+    if triton_variance:
+        n2 = 1 << (n - 1).bit_length()
+        ss = ss + (n2 - n) * (mean * mean)
+    var = ss / n
     rstd = 1.0 / torch.sqrt(var + eps)
     y = d * rstd
     if w is not None:

@@ -196,19 +196,24 @@ def test_rmsnorm(K, m, n):
 @pytest.mark.parametrize("m,n", [(7, 1536), (300, 256), (64, 5120)])
 @pytest.mark.parametrize("affine", [False, True])
 @pytest.mark.parametrize("mod", [False, True])
-def test_layernorm_modulate(K, m, n, affine, mod):
+@pytest.mark.parametrize("triton_variance", [True, False])
+def test_layernorm_modulate(K, m, n, affine, mod, triton_variance):
+    """triton_variance: the reference's Triton LayerNorm (variance over next_power_of_2(n) columns, the phantom ones
+    contributing mean^2 — ops/core.py:213-224) vs the textbook one; rows carry an offset so that the two differ."""
     g = torch.Generator().manual_seed(n + m)
-    x = act_like(m, n, torch.bfloat16, seed=n + 1)
+    x = (act_like(m, n, torch.bfloat16, seed=n + 1).float() + 0.375).bfloat16()
     w = (torch.rand(n, generator=g) + 0.5) if affine else None
     b = (torch.randn(n, generator=g) * 0.1) if affine else None
-    ref = O.layernorm_fast(x, w, b, 1e-6)
+    ref = O.layernorm_fast(x, w, b, 1e-6, triton_variance=triton_variance)
+    pad = K.triton_ln_pad_cols(n) if triton_variance else 0
+    assert pad == {1536: 512, 256: 0, 5120: 3072}[n] * int(triton_variance)
     scale = shift = None
     if mod:
         scale = torch.randn(1, n, generator=g) * 0.3
         shift = torch.randn(1, n, generator=g) * 0.3
         ref = O.modulate(ref, scale, shift)
     out = K.layernorm(x.to(DEV), None if w is None else w.to(DEV), None if b is None else b.to(DEV), 1e-6,
-                      None if scale is None else scale.to(DEV), None if shift is None else shift.to(DEV))
+                      None if scale is None else scale.to(DEV), None if shift is None else shift.to(DEV), pad_cols=pad)
     ulp = ulp_diff_bf16(out, ref)
     # modulate amplifies a 1-ulp difference of the rounded norm output by (1+scale): allow 2 there
     assert ulp.max().item() <= (2 if mod else 1), f"max ulp {ulp.max().item()}"
@@ -229,9 +234,10 @@ def test_layernorm_quant_bit_exact(K, m, n, affine, mod, dtype):
     nb = 2 if (mod and m % 2 == 0) else 1
     sc = (0.2 * torch.randn(nb, n, generator=g)).to(DEV) if mod else None
     sh = (0.2 * torch.randn(nb, n, generator=g)).to(DEV) if mod else None
-    y = K.layernorm(x, w, b, 1e-6, sc, sh, rows_per_batch=m // nb if mod else 0)
+    pad = K.triton_ln_pad_cols(n)      # (0 for the power-of-two widths)
+    y = K.layernorm(x, w, b, 1e-6, sc, sh, rows_per_batch=m // nb if mod else 0, pad_cols=pad)
     q_ref, s_ref = K.quant_i8_block128(y)
-    q, s = K.layernorm_quant(x, w, b, 1e-6, sc, sh, rows_per_batch=m // nb if mod else 0)
+    q, s = K.layernorm_quant(x, w, b, 1e-6, sc, sh, rows_per_batch=m // nb if mod else 0, pad_cols=pad)
     assert torch.equal(s, s_ref), "scales"
     assert torch.equal(q, q_ref), f"codes differ at {(q != q_ref).sum().item()} positions"
 
@@ -302,8 +308,8 @@ def test_turbo_diffusion_ops_compat_drives_the_reference_call_sequence(K):
     torch.testing.assert_close(rms_norm_cuda(xf, 1e-6, None, None).cpu(), O.rmsnorm_fast(xf.cpu(), torch.ones(1536), 1e-6), rtol=2e-6, atol=1e-6)
     out = torch.empty_like(xf)
     assert layer_norm_cuda(xf, 1e-6, wn, bn, out) is out
-    torch.testing.assert_close(out.cpu(), O.layernorm_fast(xf.cpu(), wn.cpu(), bn.cpu(), 1e-6), rtol=2e-5, atol=2e-6)
-    torch.testing.assert_close(layer_norm_cuda(xf, 1e-6, None, None, None).cpu(), O.layernorm_fast(xf.cpu(), None, None, 1e-6), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(out.cpu(), O.layernorm_fast(xf.cpu(), wn.cpu(), bn.cpu(), 1e-6, triton_variance=False), rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(layer_norm_cuda(xf, 1e-6, None, None, None).cpu(), O.layernorm_fast(xf.cpu(), None, None, 1e-6, triton_variance=False), rtol=2e-5, atol=2e-6)
 
 
 # ---------------------------------------------------------------- row statistics from the GEMM epilogue
@@ -335,6 +341,14 @@ def test_gemm_row_stats_epilogue(K, m, n, k, residual):
     torch.testing.assert_close(st[:, 1].double(), 1.0 / torch.sqrt(var + 1e-6), rtol=2e-5, atol=0)
     rstd = K.row_stats_finalize(part, n, 1e-6, rms=True)
     torch.testing.assert_close(rstd, K.rms_stats(ref, n, 1e-6), rtol=2e-6, atol=0)
+    # the reference's Triton variance (pad_cols phantom columns contributing mean^2 each, K.triton_ln_pad_cols)
+    pad = K.triton_ln_pad_cols(n)
+    stp = K.row_stats_finalize(part, n, 1e-6, pad_cols=pad)
+    torch.testing.assert_close(stp[:, 1].double(), 1.0 / torch.sqrt(var + pad * mean * mean / n + 1e-6), rtol=2e-5, atol=0)
+    if n <= K.LNQ_MAX_N:
+        qa, sa = K.layernorm_quant(ref, None, None, 1e-6, pad_cols=pad)
+        qb, sb = K.layernorm_quant(ref, None, None, 1e-6, stats=stp)
+        assert (qa != qb).float().mean().item() < 2e-3 and (qa.int() - qb.int()).abs().max().item() <= 1
     # LayerNorm -> INT8 with the supplied statistics against its own statistics pass: same scales / codes except where a
     # last-bit difference of (mean, rstd) moves a value across a rounding boundary
     sc, sh = (0.2 * torch.randn(1, n, generator=g)).to(DEV), (0.2 * torch.randn(1, n, generator=g)).to(DEV)

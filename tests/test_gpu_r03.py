@@ -130,3 +130,71 @@ def test_four_layers_four_steps_against_the_oracle(K, capsys):
     # 4 blocks deep the block-map's near-ties and the INT8 rounding differences compound (one block: <= 2e-2, test_gpu_c1)
     assert max(forced) < 4e-2, forced
     assert max(free) < 4e-2 and rel_l2(out, g["final"]) < 4e-2, (free, rel_l2(out, g["final"]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HIP kernels against what the reference's OWN Triton kernels produced on an MI355X (tests/golden/triton_leaves.pt,
+# oracle/triton_leaves.py): a5 / a6 norms, a11 pooling + block map, a12 block-sparse attention, the SLA module
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def leaves():
+    from oracle.triton_leaves import inputs
+    path = os.path.join(GOLD, "triton_leaves.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    g = torch.load(path, weights_only=False)
+    g["inputs"] = inputs()
+    return g
+
+
+def test_hip_norms_vs_the_reference_triton_kernels(K, leaves):
+    I = leaves["inputs"]
+    xn, xs = I["xn"][:64].to(DEV), I["xs"].to(DEV)
+    w, b, ws, bs = (I[n].to(DEV) for n in ("w", "b", "ws", "bs"))
+    p1536, p384 = K.triton_ln_pad_cols(1536), K.triton_ln_pad_cols(384)
+    assert (p1536, p384) == (512, 128)
+    for got, name in ((K.rmsnorm(xn, w, 1e-6), "rms_n1536"), (K.rmsnorm(xs, ws, 1e-6), "rms_n384"),
+                      (K.layernorm(xn, w, b, 1e-6, pad_cols=p1536), "ln_affine_n1536"),
+                      (K.layernorm(xn, None, None, 1e-6, pad_cols=p1536), "ln_plain_n1536"),
+                      (K.layernorm(xs, ws, bs, 1e-6, pad_cols=p384), "ln_affine_n384"),
+                      (K.layernorm(xs, None, None, 1e-6, pad_cols=p384), "ln_plain_n384")):
+        torch.testing.assert_close(got.cpu(), leaves[name], rtol=2e-6, atol=6e-6, msg=name)
+    # the module-level operators (ops.layernorm / FastLayerNorm use the Triton variance by default)
+    from turbodiffusion_amd import ops
+    xb = xn.bfloat16()
+    for got, name in ((ops.rmsnorm(xb, w, 1e-6), "fast_rms_bf16"), (ops.layernorm(xb, None, None, 1e-6, False), "fast_ln_bf16")):
+        ulp = ulp_diff_bf16(got, leaves[name])
+        assert ulp.max().item() <= 1 and (ulp > 0).float().mean().item() < 0.01, name
+    # and the textbook variance is measurably something else on these rows
+    assert rel_l2(K.layernorm(xn, None, None, 1e-6), leaves["ln_plain_n1536"]) > 1e-4
+
+
+def test_hip_sla_kernels_vs_the_reference_triton_kernels(K, leaves):
+    I = leaves["inputs"]
+    q, k, v = (I[n][0].to(DEV) for n in "qkv")       # [H, L, D]
+    H, L, D = q.shape
+    # a11: block means (compress_kernel): bit for bit
+    pq, _, _ = K.sage_quant_pool(q, None, 128, want_quant=False)
+    pk_raw, _, _ = K.sage_quant_pool(k, None, 64, want_quant=False)
+    assert torch.equal(pq.cpu(), leaves["pool_q128"][0]) and torch.equal(pk_raw.cpu(), leaves["pool_k64"][0])
+    # a11: the block map of get_block_map (its own device topk): the same selected sets
+    km = K.seq_mean(k)
+    pk, _, _ = K.sage_quant_pool(k, km, 64, want_quant=False)
+    lut = K.sla_topk(pq, pk, leaves["topk128"])
+    got = torch.zeros(H, lut.shape[1], 11, dtype=torch.bool).scatter_(-1, lut.cpu().long(), True)
+    assert torch.equal(got, leaves["map128"][0].bool()), "block map differs from the reference's get_block_map"
+    # a12: _attn_fwd over the reference's own LUT (ascending order = the order this kernel visits)
+    vt = K.v_transpose(v.transpose(0, 1).contiguous(), D, H * D, L, H, D, torch.bfloat16)
+    out = torch.empty(H, L, D, dtype=torch.bfloat16, device=DEV)
+    K.attn_16(q, k, vt, leaves["lut128"][0].sort(-1).values.int().to(DEV), out, L * D, D)
+    ref = leaves["attn_o128_sorted"][0]
+    assert cosine(out, ref) > 0.9999 and rel_l2(out, ref) < 5e-3, rel_l2(out, ref)
+    # the whole module against the reference module run on the same chip
+    from turbodiffusion_amd.sla import SparseLinearAttention
+    m = SparseLinearAttention(128, I["topk"], BLKQ=128, BLKK=64).to(DEV)
+    with torch.no_grad():
+        m.proj_l.weight.copy_(I["proj_w"])
+        m.proj_l.bias.copy_(I["proj_b"])
+        o, sp = m(*(I[n].transpose(1, 2).contiguous().to(DEV) for n in "qkv"), return_sparsity=True)
+    assert abs(sp - leaves["sla_sparsity128"]) < 1e-9
+    assert cosine(o, leaves["sla_module128"]) > 0.9995 and rel_l2(o, leaves["sla_module128"]) < 2e-2, rel_l2(o, leaves["sla_module128"])

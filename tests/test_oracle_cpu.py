@@ -166,6 +166,76 @@ def test_oracle_sagesla_matches_live_reference_module(dtype, arch):
     assert sparsity == pytest.approx(int(0.25 * 10) / 10)
 
 
+LEAVES = os.path.join(os.path.dirname(__file__), "golden", "triton_leaves.pt")
+
+
+@pytest.fixture(scope="module")
+def leaves():
+    """What the reference's OWN Triton kernels produced on an MI355X (oracle/triton_leaves.py; inputs from the hash)."""
+    from oracle.triton_leaves import inputs
+    g = torch.load(LEAVES, weights_only=False)
+    g["inputs"] = inputs()
+    return g
+
+
+def test_oracle_norms_match_the_reference_triton_kernels(leaves):
+    """a5 / a6: ops/core.py:96-136 (RMSNorm), :193-242 / :293-335 (LayerNorm, affine and plain) as EXECUTED, N = 1536
+    (N2 = 2048: 512 phantom columns in the LayerNorm variance) and the N <= 512 path.  fp32 outputs to 1e-6 (reduction
+    order), the bf16 Fast-module outputs to one ulp on < 1 % of the values."""
+    I = leaves["inputs"]
+    xn, xs, w, b, ws, bs = I["xn"][:64], I["xs"], I["w"], I["b"], I["ws"], I["bs"]
+    for got, name in ((O.rmsnorm_fast(xn, w, 1e-6), "rms_n1536"), (O.rmsnorm_fast(xs, ws, 1e-6), "rms_n384"),
+                      (O.layernorm_fast(xn, w, b, 1e-6), "ln_affine_n1536"), (O.layernorm_fast(xn, None, None, 1e-6), "ln_plain_n1536"),
+                      (O.layernorm_fast(xs, ws, bs, 1e-6), "ln_affine_n384"), (O.layernorm_fast(xs, None, None, 1e-6), "ln_plain_n384")):
+        torch.testing.assert_close(got, leaves[name], rtol=2e-6, atol=6e-6, msg=name)
+        assert rel_l2(got, leaves[name]) < 3e-7, name
+    # the phantom-column term is what makes them agree: the textbook variance is 1e-3 away on these rows
+    assert rel_l2(O.layernorm_fast(xn, None, None, 1e-6, triton_variance=False), leaves["ln_plain_n1536"]) > 1e-4
+    xb = xn.bfloat16()
+    for got, name in ((O.rmsnorm_fast(xb.float(), w, 1e-6).bfloat16(), "fast_rms_bf16"),
+                      (O.layernorm_fast(xb.float(), None, None, 1e-6).bfloat16(), "fast_ln_bf16")):
+        ulp = (got.view(torch.int16).int() - leaves[name].view(torch.int16).int()).abs()
+        assert ulp.max().item() <= 1 and (ulp > 0).float().mean().item() < 0.01, name
+
+
+def test_oracle_sla_leaves_match_the_reference_triton_kernels(leaves):
+    """a11 / a12: ``compress_kernel`` / ``mean_pool`` (SLA/utils.py:21-52) and ``get_block_map`` (:55-67) bit for bit;
+    ``_attn_fwd`` (SLA/kernel.py:21-82) O equal on > 99.5 % of the values and one bf16 rounding step apart on the rest
+    (fp32 accumulation order inside the matrix instructions); BLKQ 128 and 64, ragged L (40-row tails), the reference's LUT order and
+    ascending order."""
+    I = leaves["inputs"]
+    q, k, v = I["q"], I["k"], I["v"]
+    assert torch.equal(S.mean_pool(q, 128), leaves["pool_q128"])
+    assert torch.equal(S.mean_pool(k, 64), leaves["pool_k64"])
+    assert torch.equal(S.mean_pool(q, 64), leaves["pool_q64"])
+    for blkq in (128, 64):
+        smap, lut, topk = S.get_block_map(q, k, I["topk"], blkq, 64)
+        assert topk == leaves[f"topk{blkq}"] == 3
+        assert torch.equal(smap, leaves[f"map{blkq}"])                       # same selected sets as the device topk
+        for sfx, lut_ref in (("", leaves[f"lut{blkq}"]), ("_sorted", leaves[f"lut{blkq}"].sort(-1).values)):
+            o = S.sla_sparse_attn(q, k, v, lut_ref, blkq, 64)
+            ref = leaves[f"attn_o{blkq}{sfx}"]
+            # one bf16 rounding step of the larger values (outputs are O(1): 2^-8 relative, 2e-3 absolute near zero)
+            torch.testing.assert_close(o.float(), ref.float(), rtol=2 ** -7, atol=2e-3)
+            assert (o != ref).float().mean().item() < 5e-3, (blkq, sfx)
+            assert rel_l2(o, ref) < 2e-4
+
+
+def test_oracle_sla_module_matches_the_reference_module_run_on_the_gpu(leaves):
+    """The whole ``SparseLinearAttention.forward`` (SLA/core.py:83-119) as the reference ran it on the MI355X — its own
+    Triton pooling / attention kernels, device topk, bf16 matmuls of the linear branch, ``proj_l`` under CUDA autocast —
+    against the oracle's module restatement: the only differences are GPU-vs-CPU matmul accumulation orders."""
+    I = leaves["inputs"]
+    q, k, v = (I[n].transpose(1, 2).contiguous() for n in "qkv")          # [B, L, H, D]
+    for blkq in (128, 64):
+        o = S.sla_forward(q, k, v, I["proj_w"], I["proj_b"], I["topk"], blkq, 64, torch.bfloat16)
+        ref = leaves[f"sla_module{blkq}"]
+        assert o.shape == ref.shape
+        assert rel_l2(o, ref) < 5e-3, (blkq, rel_l2(o, ref))
+        assert abs(leaves[f"sla_sparsity{blkq}"] - 3 / 11) < 1e-9
+
+
+
 def test_delta_lut_roundtrip():
     g = torch.Generator().manual_seed(0)
     smap = (torch.rand(1, 2, 5, 17, generator=g) < 0.3).to(torch.int8)
@@ -397,3 +467,26 @@ def test_checkpoint_converter_key_contract():
     assert mapped == own, (sorted(mapped - own)[:4], sorted(own - mapped)[:4])
     assert not any("proj_l" in k and k.endswith("int8_weight") for k in mapped)
     assert not C.is_quantized(sd) and C.is_quantized({"blocks.0.ffn.0.int8_weight": None})
+
+
+def test_gemm_refuses_operands_beyond_32_bit_offsets():
+    """The 256x256 GEMM kernels address A and B through 32-bit offsets: m*k or n*k >= 2^32 must be an error status at the
+    C-ABI (checked before anything is dereferenced — no GPU needed), never a wrapped address.  C4's ffn.2 at B = 1 is
+    1.05e9 (fine); five samples of it are not."""
+    import ctypes
+    from turbodiffusion_amd import _lib as L
+    lib = L.load()
+    p = ctypes.c_void_p(4096)
+    big_m, n, k = 5 * 75600, 5120, 13824
+    assert big_m * k >= 2 ** 32
+    for name, args in (
+            ("td_gemm_w8a8", (p, p, p, p, None, p, L.TD_BF16, 0, big_m, n, k, n, None)),
+            ("td_gemm_w8a8_quant", (p, p, p, p, None, p, p, L.TD_BF16, 0, big_m, n, k, None)),
+            ("td_gemm_w8a8_residual", (p, p, p, p, None, p, None, L.TD_BF16, big_m, n, k, n, None)),
+            ("td_gemm_w8a8_stats", (p, p, p, p, p, p, None, 1, L.TD_BF16, big_m, n, k, n, p, None)),
+            ("td_gemm_w8a8_vt", (p, p, p, p, p, p, L.TD_BF16, big_m, 15360, k, 15360, 10240, p, L.TD_F16, None))):
+        rc = getattr(lib, name)(*args)
+        assert rc != 0 and b"2^32" in lib.td_last_error(), (name, rc, lib.td_last_error())
+    # the same shapes one sample at a time pass this check (they fail later only for want of a GPU, which we do not reach:
+    # m = 0 returns TD_OK before any launch)
+    assert lib.td_gemm_w8a8(p, p, p, p, None, p, L.TD_BF16, 0, 0, n, k, n, None) == 0

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("TD_LIB_PATH") or os.path.join(_HERE, "libturbodiffusi
 
 TD_F16, TD_BF16, TD_F32 = 0, 1, 2
 TD_EPI_NONE, TD_EPI_GELU_TANH = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -35,8 +35,8 @@ SIGNATURES = {
     "td_gemm_w8a8_quant": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _vp],
     "td_gemm_w8a8_residual": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp],
     "td_rmsnorm": [_vp, _i32, _vp, _vp, _i32, _f32, _i64, _i64, _vp],
-    "td_layernorm": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _i64, _i64, _vp],
-    "td_layernorm_quant": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _i64, _i64, _vp],
+    "td_layernorm": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _i32, _f32, _i64, _i64, _i64, _vp],
+    "td_layernorm_quant": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32, _i64, _i64, _i64, _vp],
     "td_gated_residual": [_vp, _vp, _vp, _i64, _i32, _i64, _i64, _vp],
     "td_qk_norm_rope": [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _f32, _i64, _i32, _i32, _vp],
     "td_v_transpose": [_vp, _i32, _i64, _i64, _vp, _i32, _i64, _i32, _i32, _vp],
@@ -50,7 +50,7 @@ SIGNATURES = {
     "td_attn_i8_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
     "td_gemm_w8a8_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _vp, _vp],
     "td_gemm_w8a8_vt": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _vp, _i32, _vp],
-    "td_row_stats_finalize": [_vp, _i32, _i64, _f32, _i32, _vp, _i64, _vp],
+    "td_row_stats_finalize": [_vp, _i32, _i64, _f32, _i64, _i32, _vp, _i64, _vp],
     "td_layernorm_quant_stats": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
     "td_attn_i8_sp": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _i64,
                       _vp, _vp, _vp, _vp],

@@ -87,5 +87,5 @@ def layer_norm_cuda(Input: torch.Tensor, eps: float, W: Optional[torch.Tensor] =
     if w is not None and b is None:
         b = torch.zeros(n, dtype=torch.float32, device=Input.device)
     call("td_layernorm", ptr(Input), dt_code(torch.float32), ptr(w), ptr(b), None, None, 0, ptr(Output),
-         dt_code(torch.float32), float(eps), m, n, stream_ptr())
+         dt_code(torch.float32), float(eps), 0, m, n, stream_ptr())   # pad_cols 0: the CUDA twin's textbook variance
     return Output

@@ -182,6 +182,14 @@ static int launch_gemm(const int8_t* a, const float* a_s, const int8_t* b, const
   return TD_OK;
 }
 
+// The 256x256 LDS-DMA kernels address the int8 operands through 32-bit buffer offsets (gemm_w8a8_fi.hip: ga / gb, the
+// descriptor's num_records): m*k and n*k must stay below 2^32 bytes.  B = 1 configurations are far below (C4 ffn.2:
+// 75 600 x 13 824 = 1.05e9); a batch of five of them is not — an ERROR here, never a silent wrap-around.
+#define TD_REQUIRE_GEMM_EXTENT(who, m, n, k)                                                                      \
+  TD_REQUIRE((m) * (k) < ((int64_t)1 << 32) && (n) * (k) < ((int64_t)1 << 32), TD_ERR_UNSUPPORTED,                \
+             "%s: m*k = %lld or n*k = %lld reaches 2^32 bytes (32-bit operand offsets): split the rows", who,     \
+             (long long)((m) * (k)), (long long)((n) * (k)))
+
 extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                             const void* bias, void* d, int out_dtype, int epilogue, int64_t m,
                             int64_t n, int64_t k, int64_t ldd, td_stream_t stream) {
@@ -197,6 +205,7 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
   TD_REQUIRE(ldd >= n && ldd % 4 == 0, TD_ERR_INVALID, "td_gemm_w8a8: bad ldd=%lld", (long long)ldd);
   TD_REQUIRE(epilogue == TD_EPI_NONE || epilogue == TD_EPI_GELU_TANH, TD_ERR_UNSUPPORTED,
              "td_gemm_w8a8: epilogue %d", epilogue);
+  TD_REQUIRE_GEMM_EXTENT("td_gemm_w8a8", m, n, k);
   if (m == 0 || n == 0) return TD_OK;
   hipStream_t st = (hipStream_t)stream;
   const int variant = td_tuning(TD_TUNE_GEMM_VARIANT);
@@ -235,6 +244,7 @@ extern "C" int td_gemm_w8a8_quant(const int8_t* a, const float* a_s, const int8_
   TD_REQUIRE(n % 16 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_quant: n=%lld must be a multiple of 16", (long long)n);
   TD_REQUIRE(epilogue == TD_EPI_NONE || epilogue == TD_EPI_GELU_TANH, TD_ERR_UNSUPPORTED,
              "td_gemm_w8a8_quant: epilogue %d", epilogue);
+  TD_REQUIRE_GEMM_EXTENT("td_gemm_w8a8_quant", m, n, k);
   if (m == 0 || n == 0) return TD_OK;
   if (td_tuning(TD_TUNE_GEMM_VARIANT) == 5)
     return td_gemm_w8a8_m32_q(a, a_s, b, b_s, bias, d_q, d_s, act_dtype, epilogue, m, n, k, (hipStream_t)stream);
@@ -251,6 +261,7 @@ extern "C" int td_gemm_w8a8_residual(const int8_t* a, const float* a_s, const in
              "td_gemm_w8a8_residual: k=%lld must be a positive multiple of 128", (long long)k);
   TD_REQUIRE(n % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_residual: n=%lld must be a multiple of 8", (long long)n);
   TD_REQUIRE(ldx >= n && ldx % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_residual: bad ldx=%lld", (long long)ldx);
+  TD_REQUIRE_GEMM_EXTENT("td_gemm_w8a8_residual", m, n, k);
   if (m == 0 || n == 0) return TD_OK;
   if (td_tuning(TD_TUNE_GEMM_VARIANT) == 5)
     return td_gemm_w8a8_m32_res(a, a_s, b, b_s, bias, x, gate, dtype, m, n, k, ldx, (hipStream_t)stream);
@@ -259,7 +270,7 @@ extern "C" int td_gemm_w8a8_residual(const int8_t* a, const float* a_s, const in
 
 
 // a15 (+ a7) -> a5 / a6 statistics: td_gemm_w8a8 (x == NULL form: d, ldd) or td_gemm_w8a8_residual (residual != 0: in
-// place on x) whose epilogue also writes, per output row and 64-column piece, (sum, sum of squares) of the stored 16-bit
+// place on x) whose epilogue also writes, per output row and 64-column piece, (mean, M2) of the stored 16-bit
 // values: stats_ws float2 [m, n/64] for td_row_stats_finalize.  bf16, bias required, n % 64 == 0, m >= 1024.
 extern "C" int td_gemm_w8a8_stats(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s, const void* bias,
                                   void* d_or_x, const float* gate, int residual, int dtype, int64_t m, int64_t n,
@@ -269,6 +280,7 @@ extern "C" int td_gemm_w8a8_stats(const int8_t* a, const float* a_s, const int8_
   TD_REQUIRE(k % 128 == 0 && k > 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_stats: k=%lld must be a positive multiple of 128", (long long)k);
   TD_REQUIRE(n % 64 == 0 && n > 0 && m > 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_stats: n=%lld must be a positive multiple of 64", (long long)n);
   TD_REQUIRE(ld >= n && ld % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_stats: bad ld=%lld", (long long)ld);
+  TD_REQUIRE_GEMM_EXTENT("td_gemm_w8a8_stats", m, n, k);
   return td_gemm_w8a8_fi_stats(a, a_s, b, b_s, bias, d_or_x, gate, residual, m, n, k, ld, stats_ws, (hipStream_t)stream);
 }
 
@@ -286,6 +298,7 @@ extern "C" int td_gemm_w8a8_vt(const int8_t* a, const float* a_s, const int8_t* 
   TD_REQUIRE(m > 0 && n > 0 && n % 256 == 0 && v_col0 % 256 == 0 && v_col0 >= 0 && v_col0 < n, TD_ERR_UNSUPPORTED,
              "td_gemm_w8a8_vt: n=%lld v_col0=%lld must be multiples of 256 with v_col0 < n", (long long)n, (long long)v_col0);
   TD_REQUIRE(ldd >= n && ldd % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_vt: bad ldd=%lld", (long long)ldd);
+  TD_REQUIRE_GEMM_EXTENT("td_gemm_w8a8_vt", m, n, k);
   return td_gemm_w8a8_fi_vt(a, a_s, b, b_s, bias, d, out_dtype, m, n, k, ldd, v_col0, vt, vt_dtype == TD_F16 && out_dtype != TD_F16,
                             (hipStream_t)stream);
 }

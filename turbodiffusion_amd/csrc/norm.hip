@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const void* __restrict__
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         int64_t rows_per_batch, void* __restrict__ y,
-                                                        float eps, int64_t m, int n) {
+                                                        float eps, float pad_cols, int64_t m, int n) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const void* __restrict__
       }
     }
   }
-  const float var = wave_sum(sq) / (float)n;
+  // pad_cols > 0 (LayerNorm only): the reference's Triton kernel sums (x - mean)^2 over next_power_of_2(n) columns with
+  // the masked columns loaded as 0 (ops/core.py:213-224, 313-324) — each phantom column adds mean^2 to the sum
+  const float var = fmaf(pad_cols, mean * mean, wave_sum(sq)) / (float)n;
   const float rstd = 1.0f / sqrtf(var + eps);
   const int64_t bi = (scale != nullptr) ? row / rows_per_batch : 0;
 #pragma unroll
@@ -128,13 +130,13 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const void* __restrict__
 
 template <int IDT, int ODT, int MODE>
 static int launch_norm(const void* x, const float* w, const float* b, const float* scale,
-                       const float* shift, int64_t rpb, void* y, float eps, int64_t m, int64_t n,
+                       const float* shift, int64_t rpb, void* y, float eps, float pad_cols, int64_t m, int64_t n,
                        hipStream_t st) {
   const int nv = (int)td_cdiv(n, 512);
   dim3 grid((unsigned)td_cdiv(m, 4));
 #define TD_NORM_NV(NV_)                                                                         \
   norm_rows_kernel<NV_, IDT, ODT, MODE><<<grid, 256, 0, st>>>(x, w, b, scale, shift, rpb, y, eps, \
-                                                              m, (int)n)
+                                                              pad_cols, m, (int)n)
   if (nv <= 1) TD_NORM_NV(1);
   else if (nv <= 2) TD_NORM_NV(2);
   else if (nv <= 3) TD_NORM_NV(3);
@@ -151,7 +153,7 @@ static int launch_norm(const void* x, const float* w, const float* b, const floa
 template <int MODE>
 static int dispatch_norm(const char* who, const void* x, int idt, const float* w, const float* b,
                          const float* scale, const float* shift, int64_t rpb, void* y, int odt,
-                         float eps, int64_t m, int64_t n, hipStream_t st) {
+                         float eps, float pad_cols, int64_t m, int64_t n, hipStream_t st) {
   TD_REQUIRE(x && y, TD_ERR_INVALID, "%s: null pointer", who);
   TD_REQUIRE(m >= 0 && n > 0, TD_ERR_INVALID, "%s: bad size", who);
   TD_REQUIRE(n % 8 == 0 && n <= 8192, TD_ERR_UNSUPPORTED, "%s: n=%lld (need n%%8==0, n<=8192)", who,
@@ -160,17 +162,17 @@ static int dispatch_norm(const char* who, const void* x, int idt, const float* w
   TD_REQUIRE(scale == nullptr || rpb > 0, TD_ERR_INVALID, "%s: rows_per_batch", who);
   if (m == 0) return TD_OK;
   if (idt == TD_BF16 && odt == TD_BF16)
-    return launch_norm<TD_BF16, TD_BF16, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
+    return launch_norm<TD_BF16, TD_BF16, MODE>(x, w, b, scale, shift, rpb, y, eps, pad_cols, m, n, st);
   if (idt == TD_F16 && odt == TD_F16)
-    return launch_norm<TD_F16, TD_F16, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
+    return launch_norm<TD_F16, TD_F16, MODE>(x, w, b, scale, shift, rpb, y, eps, pad_cols, m, n, st);
   if (idt == TD_F32 && odt == TD_F32)
-    return launch_norm<TD_F32, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
+    return launch_norm<TD_F32, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, pad_cols, m, n, st);
   if (idt == TD_F32 && odt == TD_BF16)
-    return launch_norm<TD_F32, TD_BF16, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
+    return launch_norm<TD_F32, TD_BF16, MODE>(x, w, b, scale, shift, rpb, y, eps, pad_cols, m, n, st);
   if (idt == TD_BF16 && odt == TD_F32)  // the head: fp32 modulate of the bf16-rounded norm (wan2pt1.py:453)
-    return launch_norm<TD_BF16, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
+    return launch_norm<TD_BF16, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, pad_cols, m, n, st);
   if (idt == TD_F16 && odt == TD_F32)
-    return launch_norm<TD_F16, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, m, n, st);
+    return launch_norm<TD_F16, TD_F32, MODE>(x, w, b, scale, shift, rpb, y, eps, pad_cols, m, n, st);
   td_set_error("%s: unsupported dtype pair in=%d out=%d", who, idt, odt);
   return TD_ERR_UNSUPPORTED;
 }
@@ -178,15 +180,16 @@ static int dispatch_norm(const char* who, const void* x, int idt, const float* w
 extern "C" int td_rmsnorm(const void* x, int in_dtype, const float* w, void* y, int out_dtype,
                           float eps, int64_t m, int64_t n, td_stream_t stream) {
   TD_REQUIRE(w, TD_ERR_INVALID, "td_rmsnorm: null weight");
-  return dispatch_norm<0>("td_rmsnorm", x, in_dtype, w, nullptr, nullptr, nullptr, 0, y, out_dtype, eps,
+  return dispatch_norm<0>("td_rmsnorm", x, in_dtype, w, nullptr, nullptr, nullptr, 0, y, out_dtype, eps, 0.f,
                           m, n, (hipStream_t)stream);
 }
 
 extern "C" int td_layernorm(const void* x, int in_dtype, const float* w, const float* b,
                             const float* scale, const float* shift, int64_t rows_per_batch, void* y,
-                            int out_dtype, float eps, int64_t m, int64_t n, td_stream_t stream) {
+                            int out_dtype, float eps, int64_t pad_cols, int64_t m, int64_t n, td_stream_t stream) {
+  TD_REQUIRE(pad_cols >= 0 && pad_cols <= 8192, TD_ERR_INVALID, "td_layernorm: pad_cols=%lld", (long long)pad_cols);
   return dispatch_norm<1>("td_layernorm", x, in_dtype, w, b, scale, shift, rows_per_batch, y, out_dtype,
-                          eps, m, n, (hipStream_t)stream);
+                          eps, (float)pad_cols, m, n, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ __device__ __forceinline__ void load8f(const float* p, float* f) {
 
 template <int NV, int DT>
 __global__ __launch_bounds__(256) void ln_stats_kernel(const uint16_t* __restrict__ x, float2* __restrict__ stats,
-                                                       float eps, int64_t m, int n) {
+                                                       float eps, float pad_cols, int64_t m, int n) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= m) return;
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void ln_stats_kernel(const uint16_t* __restric
       }
     }
   }
-  const float var = wave_sum(sq) / (float)n;
+  const float var = fmaf(pad_cols, mean * mean, wave_sum(sq)) / (float)n;   // pad_cols: see norm_rows_kernel (norm.hip)
   const float rstd = 1.0f / sqrtf(var + eps);
   if (lane == 0) stats[row] = make_float2(mean, rstd);
 }
@@ -196,7 +196,8 @@ __global__ __launch_bounds__(256) void ln_apply_quant_kernel(
 // mode 0: LayerNorm -> out float2 [m] = (mean, 1/sqrt(M2/n + eps));
 // mode 1: RMSNorm -> out float [m] = 1/sqrt(E[x^2] + eps), E[x^2] = sum_p (M2_p + 64 mean_p^2) / n (a sum of non-negatives).
 __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* __restrict__ ws, int pieces, float inv_n,
-                                                                float eps, int mode, float* __restrict__ out, int64_t m) {
+                                                                float eps, float pad_cols, int mode,
+                                                                float* __restrict__ out, int64_t m) {
   const int sub = threadIdx.x & 7;
   int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
   const bool ok = row < m;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* _
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) b += __shfl_xor(b, o, 64);
     if (!ok || sub != 0) return;
-    const float var = fmaf(64.0f, b, q) * inv_n;
+    const float var = fmaf(pad_cols, mean * mean, fmaf(64.0f, b, q)) * inv_n;   // pad_cols: see norm_rows_kernel (norm.hip)
     reinterpret_cast<float2*>(out)[row] = make_float2(mean, 1.0f / sqrtf(var + eps));
   } else {
     if (!ok || sub != 0) return;
@@ -230,21 +231,22 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* _
   }
 }
 
-extern "C" int td_row_stats_finalize(const float* ws, int pieces, int64_t n, float eps, int mode, float* out, int64_t m,
-                                     td_stream_t stream) {
+extern "C" int td_row_stats_finalize(const float* ws, int pieces, int64_t n, float eps, int64_t pad_cols, int mode,
+                                     float* out, int64_t m, td_stream_t stream) {
+  TD_REQUIRE(pad_cols >= 0 && pad_cols <= 8192, TD_ERR_INVALID, "td_row_stats_finalize: pad_cols=%lld", (long long)pad_cols);
   TD_REQUIRE(ws && out, TD_ERR_INVALID, "td_row_stats_finalize: null pointer");
   TD_REQUIRE(pieces > 0 && n == (int64_t)pieces * 64 && m >= 0 && (mode == 0 || mode == 1), TD_ERR_INVALID,
              "td_row_stats_finalize: pieces=%d n=%lld mode=%d (need n == 64 * pieces: every piece is 64 values)", pieces, (long long)n, mode);
   if (m == 0) return TD_OK;
   row_stats_finalize_kernel<<<(unsigned)td_cdiv(m, 32), 256, 0, (hipStream_t)stream>>>(
-      reinterpret_cast<const float2*>(ws), pieces, 1.0f / (float)n, eps, mode, out, m);
+      reinterpret_cast<const float2*>(ws), pieces, 1.0f / (float)n, eps, (float)pad_cols, mode, out, m);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
 
 static int ln_quant_impl(const void* x, int dtype, const float* w, const float* b, const float* scale,
                          const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float* stats_ws,
-                         float eps, int64_t m, int64_t n, td_stream_t stream, bool have_stats) {
+                         float eps, float pad_cols, int64_t m, int64_t n, td_stream_t stream, bool have_stats) {
   TD_REQUIRE(x && q && qs && stats_ws, TD_ERR_INVALID, "td_layernorm_quant: null pointer");
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_layernorm_quant: dtype %d (need f16|bf16)", dtype);
   TD_REQUIRE(m >= 0 && n > 0, TD_ERR_INVALID, "td_layernorm_quant: bad size");
@@ -264,8 +266,8 @@ static int ln_quant_impl(const void* x, int dtype, const float* w, const float* 
   dim3 g1((unsigned)td_cdiv(m, 4));
 #define TD_LNS(NV_)                                                                          \
   {                                                                                          \
-    if (dtype == TD_BF16) ln_stats_kernel<NV_, TD_BF16><<<g1, 256, 0, st>>>(xp, sp, eps, m, (int)n); \
-    else ln_stats_kernel<NV_, TD_F16><<<g1, 256, 0, st>>>(xp, sp, eps, m, (int)n);           \
+    if (dtype == TD_BF16) ln_stats_kernel<NV_, TD_BF16><<<g1, 256, 0, st>>>(xp, sp, eps, pad_cols, m, (int)n); \
+    else ln_stats_kernel<NV_, TD_F16><<<g1, 256, 0, st>>>(xp, sp, eps, pad_cols, m, (int)n); \
   }
   if (!have_stats) {
   if (nv <= 1) TD_LNS(1) else if (nv <= 2) TD_LNS(2) else if (nv <= 3) TD_LNS(3) else if (nv <= 4) TD_LNS(4)
@@ -296,8 +298,10 @@ static int ln_quant_impl(const void* x, int dtype, const float* w, const float* 
 
 extern "C" int td_layernorm_quant(const void* x, int dtype, const float* w, const float* b, const float* scale,
                                   const float* shift, int64_t rows_per_batch, int8_t* q, float* qs, float* stats_ws,
-                                  float eps, int64_t m, int64_t n, td_stream_t stream) {
-  return ln_quant_impl(x, dtype, w, b, scale, shift, rows_per_batch, q, qs, stats_ws, eps, m, n, stream, false);
+                                  float eps, int64_t pad_cols, int64_t m, int64_t n, td_stream_t stream) {
+  TD_REQUIRE(pad_cols >= 0 && pad_cols <= 8192, TD_ERR_INVALID, "td_layernorm_quant: pad_cols=%lld", (long long)pad_cols);
+  return ln_quant_impl(x, dtype, w, b, scale, shift, rows_per_batch, q, qs, stats_ws, eps, (float)pad_cols, m, n, stream,
+                       false);
 }
 
 // the apply + quantise pass alone, with the rows' (mean, rstd) supplied (float2 [m], e.g. from td_row_stats_finalize of
@@ -305,6 +309,6 @@ extern "C" int td_layernorm_quant(const void* x, int dtype, const float* w, cons
 extern "C" int td_layernorm_quant_stats(const void* x, int dtype, const float* w, const float* b, const float* scale,
                                         const float* shift, int64_t rows_per_batch, int8_t* q, float* qs,
                                         const float* row_stats, int64_t m, int64_t n, td_stream_t stream) {
-  return ln_quant_impl(x, dtype, w, b, scale, shift, rows_per_batch, q, qs, const_cast<float*>(row_stats), 0.f, m, n,
+  return ln_quant_impl(x, dtype, w, b, scale, shift, rows_per_batch, q, qs, const_cast<float*>(row_stats), 0.f, 0.f, m, n,
                        stream, true);
 }

@@ -226,8 +226,15 @@ def rmsnorm(x, w, eps, out_dtype=None):
     return y.reshape(x.shape)
 
 
-def layernorm(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, out_dtype=None):
-    """LayerNorm over the last dim; optional fused AdaLN modulate (scale/shift f32 [B, n])."""
+def triton_ln_pad_cols(n: int) -> int:
+    """next_power_of_2(n) - n: the phantom columns the reference's Triton LayerNorm sums (x - mean)^2 over (they load as 0,
+    ops/core.py:213-224, 313-324): 512 at n = 1536, 3072 at n = 5120, 0 for a power of two.  Pass it as ``pad_cols`` to
+    reproduce FastLayerNorm / ops.layernorm exactly; 0 is the textbook variance (eager WanLayerNorm, layer_norm_cuda)."""
+    return (1 << max(0, (int(n) - 1).bit_length())) - int(n)
+
+
+def layernorm(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, out_dtype=None, pad_cols=0):
+    """LayerNorm over the last dim; optional fused AdaLN modulate (scale/shift f32 [B, n]).  pad_cols: triton_ln_pad_cols."""
     require_gpu(x, w, b, scale, shift)
     assert x.is_contiguous(), "Input must be contiguous"
     n = x.shape[-1]
@@ -244,7 +251,7 @@ def layernorm(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, out_dtype=
             assert x2.shape[0] % scale.shape[0] == 0
             rows_per_batch = x2.shape[0] // scale.shape[0]
     call("td_layernorm", ptr(x2), dt_code(x.dtype), ptr(w), ptr(b), ptr(scale), ptr(shift), rows_per_batch,
-         ptr(y), dt_code(out_dtype), float(eps), x2.shape[0], n, stream_ptr())
+         ptr(y), dt_code(out_dtype), float(eps), int(pad_cols), x2.shape[0], n, stream_ptr())
     return y.reshape(x.shape)
 
 
@@ -270,17 +277,19 @@ def gemm_w8a8_residual_(x, a_q, a_s, b_q, b_s, bias=None, gate=None):
     return x
 
 
-def gemm_w8a8_stats(a_q, a_s, b_q, b_s, bias, x=None, gate=None, out_dtype=torch.bfloat16):
+def gemm_w8a8_stats(a_q, a_s, b_q, b_s, bias, x=None, gate=None, out_dtype=torch.bfloat16, ws=None):
     """gemm_w8a8 (x is None: returns (y, ws)) or gemm_w8a8_residual_ (in place on x: returns (x, ws)) whose epilogue also
-    writes the row-statistics partials ws f32 [m, n/64, 2] = per 64-column piece (sum, sum of squares) of the stored values
-    — same output bits as the plain calls."""
+    writes the row-statistics partials ws f32 [m, n/64, 2] = per 64-column piece (mean, M2) of the stored values
+    — same output bits as the plain calls.  ws: a preallocated (row slice of a) partials tensor to write into."""
     require_gpu(a_q, a_s, b_q, b_s, bias, x, gate)
     m, k = a_q.shape
     n = b_q.shape[0]
     assert a_q.dtype == torch.int8 and b_q.dtype == torch.int8 and b_q.shape[1] == k and n % 64 == 0 and bias is not None
     assert a_q.is_contiguous() and b_q.is_contiguous() and bias.dtype == torch.bfloat16 and bias.is_contiguous()
     _f32c(a_s, "a_s"), _f32c(b_s, "b_s")
-    ws = torch.empty((m, n // 64, 2), dtype=torch.float32, device=a_q.device)
+    if ws is None:
+        ws = torch.empty((m, n // 64, 2), dtype=torch.float32, device=a_q.device)
+    assert ws.shape == (m, n // 64, 2) and ws.dtype == torch.float32 and ws.is_contiguous()
     if x is None:
         y = torch.empty((m, n), dtype=out_dtype, device=a_q.device)
         tgt, ld, res = y, n, 0
@@ -312,22 +321,25 @@ def gemm_w8a8_vt(a_q, a_s, b_q, b_s, bias, v_col0, vt_dtype, out_dtype=torch.bfl
     return d, vt
 
 
-def row_stats_finalize(ws, n, eps, rms=False):
-    """ws f32 [m, pieces, 2] -> LayerNorm (mean, rstd) f32 [m, 2], or (rms=True) the RMSNorm rstd f32 [m]."""
+def row_stats_finalize(ws, n, eps, rms=False, pad_cols=0):
+    """ws f32 [m, pieces, 2] (per 64-column piece: mean, M2) -> LayerNorm (mean, rstd) f32 [m, 2], or (rms=True) the
+    RMSNorm rstd f32 [m].  pad_cols: triton_ln_pad_cols (LayerNorm only)."""
     require_gpu(ws)
     m, pieces, _ = ws.shape
     out = torch.empty((m,) if rms else (m, 2), dtype=torch.float32, device=ws.device)
-    call("td_row_stats_finalize", ptr(ws), pieces, n, float(eps), 1 if rms else 0, ptr(out), m, stream_ptr())
+    call("td_row_stats_finalize", ptr(ws), pieces, n, float(eps), 0 if rms else int(pad_cols), 1 if rms else 0, ptr(out), m,
+         stream_ptr())
     return out
 
 
 LNQ_MAX_N = 8192
 
 
-def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, stats=None):
+def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, stats=None, pad_cols=0):
     """LayerNorm (+ affine, + AdaLN modulate) fused with the per-128x128-block INT8 quantiser of the consuming
     Int8Linear: returns (q int8 [m,n], s f32 [ceil(m/128), ceil(n/128)]) == quant_i8_block128(layernorm(...)).
-    stats: the rows' (mean, rstd) f32 [m, 2] when the producer of x already supplied them (row_stats_finalize)."""
+    stats: the rows' (mean, rstd) f32 [m, 2] when the producer of x already supplied them (row_stats_finalize — pad_cols
+    then went into THAT call).  pad_cols: triton_ln_pad_cols."""
     require_gpu(x, w, b, scale, shift)
     assert x.is_contiguous() and x.dim() == 2, "Input must be a contiguous 2-D tensor"
     m, n = x.shape
@@ -336,7 +348,8 @@ def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, stat
         assert m % nb == 0
         rows_per_batch = m // nb
     if n > LNQ_MAX_N or n % 8 or (scale is not None and rows_per_batch < 128):
-        return quant_i8_block128(layernorm(x, w, b, eps, scale, shift, rows_per_batch))
+        assert stats is None
+        return quant_i8_block128(layernorm(x, w, b, eps, scale, shift, rows_per_batch, pad_cols=pad_cols))
     if w is not None:
         w = w.float().contiguous()
         b = b.float().contiguous() if b is not None else None
@@ -352,7 +365,7 @@ def layernorm_quant(x, w, b, eps, scale=None, shift=None, rows_per_batch=0, stat
         return q, s
     ws = torch.empty((m, 2), dtype=torch.float32, device=x.device)   # rows' (mean, rstd) between the two passes
     call("td_layernorm_quant", ptr(x), dt_code(x.dtype), ptr(w), ptr(b), ptr(scale), ptr(shift), rows_per_batch,
-         ptr(q), ptr(s), ptr(ws), float(eps), m, n, stream_ptr())
+         ptr(q), ptr(s), ptr(ws), float(eps), int(pad_cols), m, n, stream_ptr())
     return q, s
 
 

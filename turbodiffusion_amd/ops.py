@@ -44,13 +44,17 @@ def rmsnorm(x, w, eps):
     return K.rmsnorm(x, w, eps)
 
 
-def layernorm(x, w, b, eps, elementwise_affine=True):
-    """ops/core.py:380-386."""
+def layernorm(x, w, b, eps, elementwise_affine=True, triton_variance=True):
+    """ops/core.py:380-386 -> the Triton kernels :193-242 / :293-335.  Those sum (x - mean)^2 over next_power_of_2(n)
+    columns with the masked ones loaded as 0, i.e. var = (sum (x-mean)^2 + (N2 - n) mean^2) / n — reproduced here by
+    default (``triton_variance``; pinned to the reference's own kernels run on the MI355X, tests/golden/triton_leaves.pt).
+    ``triton_variance=False`` gives the textbook LayerNorm of the eager WanLayerNorm / layer_norm_cuda."""
+    pad = K.triton_ln_pad_cols(x.shape[-1]) if triton_variance else 0
     if elementwise_affine:
         assert w is not None and b is not None
-        return K.layernorm(x.contiguous(), w, b, eps)
+        return K.layernorm(x.contiguous(), w, b, eps, pad_cols=pad)
     assert w is None and b is None
-    return K.layernorm(x.contiguous(), None, None, eps)
+    return K.layernorm(x.contiguous(), None, None, eps, pad_cols=pad)
 
 
 def cdiv(a: int, b: int):
@@ -142,8 +146,10 @@ class FastLayerNorm(nn.Module):
             self.register_parameter("weight", None)
             self.register_parameter("bias", None)
 
+    triton_variance = True   # False: the textbook variance (see ``layernorm``)
+
     def forward(self, x):
-        return layernorm(x, self.weight, self.bias, self.eps, self.elementwise_affine)
+        return layernorm(x, self.weight, self.bias, self.eps, self.elementwise_affine, self.triton_variance)
 
     @classmethod
     def from_layernorm(cls, original_layernorm):

@@ -120,7 +120,7 @@ class WanModel(nn.Module):
     def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
                  freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, qk_norm=True,
                  cross_attn_norm=True, eps=1e-6, attention_type="sagesla", sla_topk=0.1, quant_linear=True,
-                 dtype=torch.bfloat16, **_unused):
+                 dtype=torch.bfloat16, default_norm=None, **_unused):
         super().__init__()
         assert model_type in ("t2v", "i2v") and qk_norm
         assert attention_type in ATTENTION_TYPES
@@ -131,6 +131,13 @@ class WanModel(nn.Module):
         self.text_dim, self.out_dim, self.num_heads, self.num_layers = text_dim, out_dim, num_heads, num_layers
         self.eps, self.attention_type, self.sla_topk, self.quant_linear = eps, attention_type, sla_topk, quant_linear
         self.dtype = dtype
+        # The reference's ``--default_norm`` (wan2.1_t2v_infer.py:53; ``replace_norm = not default_norm``, modify_model.py:
+        # 56-81): True = the eager WanLayerNorm arithmetic in the blocks (textbook variance); False = FastLayerNorm, whose
+        # Triton kernel sums (x - mean)^2 over next_power_of_2(dim) columns (ops/core.py:213-224; K.triton_ln_pad_cols) —
+        # reproduced so that this model returns what the reference's accelerated path returns.  None: False whenever an
+        # accelerated operator is selected, True for the plain eager-equivalent configuration (original attention, bf16
+        # linears).  The head's norm is never replaced by the reference (only ``model.blocks`` is walked).
+        self.default_norm = (attention_type == "original" and not quant_linear) if default_norm is None else bool(default_norm)
         self.patch_embedding = nn.Linear(in_dim * math.prod(patch_size), dim, dtype=dtype)
         self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim, dtype=dtype), nn.GELU(approximate="tanh"),
                                             nn.Linear(dim, dim, dtype=dtype))
@@ -151,6 +158,7 @@ class WanModel(nn.Module):
         self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
         self.fuse_vt = True         # self-attention V leaves the q|k|v GEMM as the attention kernel's V^T tiles (K.gemm_w8a8_vt)
         self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
+        self.split_tokens = True    # everything after self-attention is token-local: two token halves on two streams (_block)
         self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
         self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
@@ -249,7 +257,7 @@ class WanModel(nn.Module):
             yq, ys = y if isinstance(y, tuple) else K.quant_i8_block128(y)
             if stats:
                 _, ws = K.gemm_w8a8_stats(yq, ys, mod.int8_weight, mod.scale, mod.bias, x=x2, gate=gate)
-                return K.row_stats_finalize(ws, x2.shape[1], self.eps)
+                return K.row_stats_finalize(ws, x2.shape[1], self.eps, pad_cols=self._ln_pad)
             K.gemm_w8a8_residual_(x2, yq, ys, mod.int8_weight, mod.scale, bias=mod.bias, gate=gate)
             return None
         K.gated_residual_(x2, self._lin(mod, y), gate)
@@ -262,7 +270,7 @@ class WanModel(nn.Module):
             hq, hs = K.gemm_w8a8_quant(xq, xs, lin1.int8_weight, lin1.scale, x2.dtype, bias=lin1.bias, gelu_tanh=True)
             if stats:
                 _, ws = K.gemm_w8a8_stats(hq, hs, lin2.int8_weight, lin2.scale, lin2.bias, x=x2, gate=gate)
-                return K.row_stats_finalize(ws, x2.shape[1], self.eps)
+                return K.row_stats_finalize(ws, x2.shape[1], self.eps, pad_cols=self._ln_pad)
             K.gemm_w8a8_residual_(x2, hq, hs, lin2.int8_weight, lin2.scale, bias=lin2.bias, gate=gate)
             return None
         f2 = self._ffn_q(lin1, lin2, h[0], h[1], x2.dtype) if isinstance(h, tuple) else self._ffn(lin1, lin2, h)
@@ -482,10 +490,60 @@ class WanModel(nn.Module):
         q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
         return K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
 
+    @property
+    def _ln_pad(self):
+        """pad_cols of the blocks' LayerNorms (see ``default_norm``)."""
+        return 0 if self.default_norm else K.triton_ln_pad_cols(self.dim)
+
     def _stats_ok(self, rows):
         """Row statistics from the GEMM epilogues: W8A8 bf16 model, fused norm->INT8 path, rows worth a 256x256-tile GEMM."""
         return (self.fuse_row_stats and self.fuse_norm_quant and self.quant_linear and self.dtype == torch.bfloat16
                 and self.dim % 64 == 0 and self.dim <= K.LNQ_MAX_N and rows >= 1024)
+
+    def _split_rows(self, L_loc):
+        """Row at which the token-local tail of a block is cut in two (0 = do not split): a multiple of 256 — the GEMM tile,
+        hence also of the 128-row quantiser / Q blocks — so that each half computes exactly the bits of the whole."""
+        if not (self.split_tokens and self.seq_parallel is None and L_loc >= 4096):
+            return 0
+        return (K.cdiv(L_loc, 256) // 2) * 256
+
+    def _tail_half(self, i, blk, x2h, yh, ec, context, kvt, ws_h, rows_per_batch):
+        """o projection -> cross-attention -> FFN of ONE row range (a view of the residual stream, updated in place): the
+        W8A8 / fused-norm / row-statistics path of ``_block`` on those rows.  ws_h: this range's slice of the FFN output's
+        row-statistics partials (the next block's norm1 finalises them for all rows at once)."""
+        pad = self._ln_pad
+        st3 = self._residual_lin_(x2h, blk.self_attn.o, yh, ec[2], stats=True)
+        xn = K.layernorm_quant(x2h, blk.norm3.weight, blk.norm3.bias, self.eps, stats=st3, pad_cols=pad)
+        c = self._cross_attention(i, blk, xn, context, quant_out=True, kvt=kvt)
+        st2 = self._residual_lin_(x2h, blk.cross_attn.o, c, None, stats=True)
+        h2 = K.layernorm_quant(x2h, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=rows_per_batch, stats=st2,
+                               pad_cols=pad)
+        lin1, lin2 = blk.ffn[0], blk.ffn[2]
+        hq, hs = K.gemm_w8a8_quant(h2[0], h2[1], lin1.int8_weight, lin1.scale, x2h.dtype, bias=lin1.bias, gelu_tanh=True)
+        K.gemm_w8a8_stats(hq, hs, lin2.int8_weight, lin2.scale, lin2.bias, x=x2h, gate=ec[5], ws=ws_h)
+
+    def _tail_two_halves(self, i, blk, x2, y, ec, context, kvt, ms):
+        """After self-attention a block is token-local (o projection, cross-attention against the 512 text keys, FFN; SURVEY
+        §8e): rows [0, ms) run on the current stream, rows [ms, L) on the model's second stream, fork / join with events
+        (graph edges under capture).  One video then keeps two kernels in flight most of the time — the launch ramps, store
+        tails and HBM-bound norm passes of one half run under the other half's GEMMs (what a second video in flight used to
+        fill: +5.7 % in round 2's ``two_videos_in_flight`` leg).  Same kernels on row ranges cut at a tile boundary: bit-identical.
+        Allocation safety without record_stream: tensors made on the second stream are used there only; ``y``, ``x2`` and
+        ``ws`` belong to the current stream and outlive the join."""
+        L_loc, dim = x2.shape
+        yq, ys = y
+        ws = torch.empty((L_loc, dim // 64, 2), dtype=torch.float32, device=x2.device)
+        main, side = torch.cuda.current_stream(), self._side()
+        e_fork = torch.cuda.Event()
+        e_fork.record(main)
+        side.wait_event(e_fork)
+        with torch.cuda.stream(side):
+            self._tail_half(i, blk, x2[ms:], (yq[ms:], ys[ms // 128:]), ec, context, kvt, ws[ms:], L_loc)
+            e_join = torch.cuda.Event()
+            e_join.record(side)
+        self._tail_half(i, blk, x2[:ms], (yq[:ms], ys[:ms // 128]), ec, context, kvt, ws[:ms], L_loc)
+        main.wait_event(e_join)
+        return K.row_stats_finalize(ws, dim, self.eps, pad_cols=self._ln_pad)
 
     def _block(self, i, blk, x, e_B_6_D, cos, sin, context, tkv=None, kvts=None):
         """x: [B, L_loc, dim] (updated in place); e fp32 [B, 6, dim] = this block's modulation + e0 (wan2pt1.py:400,
@@ -499,25 +557,33 @@ class WanModel(nn.Module):
         # [32760, 1536] on MI355X against 36 + 25 us for the two operators)
         fuse = self.fuse_norm_quant and self.quant_linear and dim <= K.LNQ_MAX_N
         rows = [slice(b * L_loc, (b + 1) * L_loc) for b in range(B)]
+        pad = self._ln_pad
         # ---- self attention ----
         fstats = fuse and B == 1 and self._stats_ok(L_loc)   # LayerNorm statistics ride on the GEMM that produced x
         st1, self._carry_stats = getattr(self, "_carry_stats", None), None
         if fuse:
             hs_ = [K.layernorm_quant(x2[r], None, None, self.eps, scale=ec[1][b:b + 1], shift=ec[0][b:b + 1],
-                                     rows_per_batch=L_loc, stats=st1 if fstats else None) for b, r in enumerate(rows)]
+                                     rows_per_batch=L_loc, stats=st1 if fstats else None, pad_cols=pad)
+                   for b, r in enumerate(rows)]
         else:
-            h = K.layernorm(x2, None, None, self.eps, scale=ec[1], shift=ec[0], rows_per_batch=L_loc)
+            h = K.layernorm(x2, None, None, self.eps, scale=ec[1], shift=ec[0], rows_per_batch=L_loc, pad_cols=pad)
             hs_ = [h[r] for r in rows]
         qo = self.quant_linear and B == 1 and self.seq_parallel is None  # attention epilogue quantises for the o proj
         ys = [self._self_attention(i, blk, hb, cos, sin, L_loc, dt, quant_out=qo) for hb in hs_]
         y = ys[0] if B == 1 else torch.cat(ys, 0)
+        ms = self._split_rows(L_loc) if (fstats and qo and isinstance(blk.norm3, FastLayerNorm) and isinstance(y, tuple)
+                                         and isinstance(blk.ffn[0], Int8Linear)) else 0
+        if ms:
+            self._carry_stats = self._tail_two_halves(i, blk, x2, y, ec, context[0], None if kvts is None else kvts[0][i], ms)
+            return x
         st3 = self._residual_lin_(x2, blk.self_attn.o, y, ec[2], stats=fstats)
         # ---- cross attention ----
         if isinstance(blk.norm3, FastLayerNorm):
             if fuse:
-                xns = [K.layernorm_quant(x2[r], blk.norm3.weight, blk.norm3.bias, self.eps, stats=st3) for r in rows]
+                xns = [K.layernorm_quant(x2[r], blk.norm3.weight, blk.norm3.bias, self.eps, stats=st3, pad_cols=pad)
+                       for r in rows]
             else:
-                xn = K.layernorm(x2, blk.norm3.weight, blk.norm3.bias, self.eps)
+                xn = K.layernorm(x2, blk.norm3.weight, blk.norm3.bias, self.eps, pad_cols=pad)
                 xns = [xn[r] for r in rows]
         else:
             xns = [x2[r] for r in rows]
@@ -528,9 +594,10 @@ class WanModel(nn.Module):
         st2 = self._residual_lin_(x2, blk.cross_attn.o, c, None, stats=fstats)
         # ---- FFN ----
         if fuse:
-            h2 = K.layernorm_quant(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc, stats=st2)
+            h2 = K.layernorm_quant(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc, stats=st2,
+                                   pad_cols=pad)
         else:
-            h2 = K.layernorm(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc)
+            h2 = K.layernorm(x2, None, None, self.eps, scale=ec[4], shift=ec[3], rows_per_batch=L_loc, pad_cols=pad)
         self._carry_stats = self._ffn_residual_(x2, blk.ffn[0], blk.ffn[2], h2, ec[5], stats=fstats)   # -> next block's norm1
         return x
 
