@@ -19,7 +19,8 @@ N independent videos, no data-path collective — is measured after the timed re
 ``replicas`` (never as ``value``).  ``--sp S`` (S < N) makes the timed region run N/S sequence-parallel groups of S
 GPUs; ``--sp 1`` N independent videos.  A collective that fails or never returns fails the run (no masking).  With
 ``--two-in-flight`` (N = 1) the line also carries ``two_videos_in_flight_videos_per_s``: the same GPU with two independent
-videos in flight on two streams (a serving-style extra, +1-6 %; never the headline ``value``; opt-in, see its help).  Rank 0 prints ONE JSON line.
+videos in flight on two streams, enqueued step by step from one host thread (a serving-style extra; never the headline
+``value``; opt-in, see its help).  Rank 0 prints ONE JSON line.
 
 Workloads (BASELINE.json configs):
   turbo    TurboWan2.1-T2V-1.3B-480P as published: SageSLA top-k 0.1 + W8A8 linears + fused norms
@@ -209,10 +210,10 @@ def main():
     ap.add_argument("--no-replica-leg", action="store_true", help="N > 1: skip the throughput-mode measurement (N "
                     "independent videos) that follows the timed region")
     ap.add_argument("--two-in-flight", action="store_true", help="N = 1: after the timed region also measure two independent "
-                    "videos in flight (two host threads, two graph replays on two streams; reported beside the headline, never "
-                    "as `value`).  Opt-in since round 3: with the two-stream fork/join inside BOTH concurrently replayed graphs the "
-                    "GPU queues can deadlock (the 600-s timeouts of the 720p runs of round 2, tools/two_in_flight_hang.py), so the "
-                    "leg captures its graphs with WanModel.two_streams off")
+                    "videos in flight on two streams, interleaved step by step from one host thread (reported beside the "
+                    "headline, never as `value`).  Opt-in since round 3: the round-2 form — two host THREADS replaying hipGraphs "
+                    "concurrently — hung intermittently at the 14B sizes (the 600-s timeouts of the 720p runs, "
+                    "profiles/r03_720p_timeout_root_cause.txt), and a hang here would cost the whole bench line")
     ap.add_argument("--no-two-in-flight", action="store_true", help="(accepted for old command lines; the leg is opt-in now)")
     ap.add_argument("--gemm-variant", type=int, default=int(os.environ.get("TD_GEMM_VARIANT", "0")),
                     help="W8A8 GEMM kernel selection knob (0 = automatic); all variants are bit-identical")
@@ -377,40 +378,40 @@ def main():
     #      fills one video's bubbles (GEMM prologues / store phases, barrier waits) with the other's kernels
     two_in_flight = None
     if world == 1 and use_graph and args.two_in_flight and not args.no_two_in_flight:
-        saved_two = [(m_, m_.two_streams) for m_ in filter(None, (net, net_low))]
-        for m_, _v in saved_two:   # no cross-stream waits inside concurrently replayed graphs (see --two-in-flight)
-            m_.two_streams = False
         try:
-            import threading
             from turbodiffusion_amd.graph import GraphedModel
+            from turbodiffusion_amd.sampler import rcm_sample_iter
             ctxs = []
             for sd in (11, 12):
                 g2 = torch.Generator(device=dev).manual_seed(sd)
                 n2 = torch.randn(lat_shape, dtype=torch.float32, device=dev, generator=g2)
-                ctxs.append((g2, n2, GraphedModel(net), torch.cuda.Stream()))
+                ctxs.append((g2, n2, GraphedModel(net), None if net_low is None else GraphedModel(net_low), torch.cuda.Stream()))
 
-            def run2(i, n):
-                g2, n2, gm, st = ctxs[i]
-                with torch.cuda.stream(st):
-                    for _ in range(n):
-                        rcm_sample(gm, n2, texts[(i + _) % len(texts)], num_steps=args.num_steps, generator=g2, y=y)
+            def run2(n):
+                """n rounds of two videos, interleaved step by step from THIS thread: video i's step is enqueued on its
+                own stream (graph replay + sampler update are asynchronous), then the other video's."""
+                for r in range(n):
+                    its = []
+                    for i, (g2, n2, gm, gml, st) in enumerate(ctxs):
+                        with torch.cuda.stream(st):
+                            its.append(rcm_sample_iter(gm, n2, texts[(2 * r + i) % len(texts)], num_steps=args.num_steps,
+                                                       generator=g2, y=y, sigma_max=sigma_max, net_low=gml, boundary=0.9))
+                    for _ in range(args.num_steps):
+                        for i, it_ in enumerate(its):
+                            with torch.cuda.stream(ctxs[i][4]):
+                                next(it_)
 
-            for i in range(2):   # capture + warm-up
-                run2(i, 1)
-                phase(f"two-videos-in-flight: context {i} captured")
+            run2(1)     # capture + warm-up
             sync()
+            phase("two-videos-in-flight: both contexts captured")
             t2 = time.perf_counter()
-            ths = [threading.Thread(target=run2, args=(i, args.steps)) for i in range(2)]
-            [t.start() for t in ths]
-            [t.join() for t in ths]
+            run2(args.steps)
             sync()
             two_in_flight = 2 * args.steps / (time.perf_counter() - t2)
             del ctxs
             phase("two-videos-in-flight leg done")
         except Exception as e:  # an extra, never fatal
             two_in_flight = repr(e)
-        for m_, v_ in saved_two:
-            m_.two_streams = v_
 
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)

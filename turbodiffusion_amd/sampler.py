@@ -29,7 +29,38 @@ def expert_schedule(num_steps: int = 4, sigma_max: float = 200.0, boundary: floa
     return out
 
 
-@torch.no_grad()
+def rcm_sample_iter(net: Callable, init_noise: torch.Tensor, crossattn_emb: torch.Tensor, num_steps: int = 4,
+                    sigma_max: float = 80.0, generator: Optional[torch.Generator] = None,
+                    noises: Optional[List[torch.Tensor]] = None, y: Optional[torch.Tensor] = None,
+                    net_low: Optional[Callable] = None, boundary: float = 0.9, ode: bool = False,
+                    dtype=torch.bfloat16):
+    """The loop of ``rcm_sample`` as a generator: yields (step index, fp64 latent) after every sampler step, so that a
+    caller can interleave several videos from ONE host thread (each resumed under its own stream).  Arguments as there."""
+    dev = init_noise.device
+    t_host = rcm_timesteps(num_steps, sigma_max)             # fp64, host: no device sync anywhere in the loop
+    t_steps = t_host.tolist()
+    with torch.no_grad():
+        x = init_noise.to(torch.float64) * t_steps[0]
+    kw = {} if y is None else {"y_B_C_T_H_W": y.to(dtype)}
+    switched = False
+    for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
+        with torch.no_grad():
+            switched = switched or (net_low is not None and t_cur < boundary)   # once low, stays low (:191-197)
+            model = net_low if switched else net
+            # (t_cur.float() * ones * 1000).to(dtype): the fp32 rounding of t_cur, times 1000 in fp64, cast  (:199)
+            t_in = torch.full((x.size(0), 1), float(t_host[i].float()) * 1000.0, dtype=torch.float64, device=dev).to(dtype)
+            v = model(x_B_C_T_H_W=x.to(dtype), timesteps_B_T=t_in, crossattn_emb=crossattn_emb, **kw).to(torch.float64)
+            if ode:
+                x = x - (t_cur - t_next) * v
+            else:
+                if noises is not None:
+                    eps = noises[i].to(dev)
+                else:
+                    eps = torch.randn(*x.shape, dtype=torch.float32, device=dev, generator=generator)
+                x = (1 - t_next) * (x - t_cur * v) + t_next * eps
+        yield i, x
+
+
 def rcm_sample(net: Callable, init_noise: torch.Tensor, crossattn_emb: torch.Tensor, num_steps: int = 4,
                sigma_max: float = 80.0, generator: Optional[torch.Generator] = None,
                noises: Optional[List[torch.Tensor]] = None, y: Optional[torch.Tensor] = None,
@@ -40,26 +71,9 @@ def rcm_sample(net: Callable, init_noise: torch.Tensor, crossattn_emb: torch.Ten
     ``noises`` (list of per-step N(0,1) tensors) overrides the generator — used by the parity tests so
     CPU oracle and GPU runs see identical noise.  ``net_low``/``boundary``: Wan2.2 expert switch
     (use ``net`` while t_cur >= boundary, ``net_low`` after: wan2.2_i2v_infer.py:191-197)."""
-    dev = init_noise.device
-    t_host = rcm_timesteps(num_steps, sigma_max)             # fp64, host: no device sync anywhere in the loop
-    t_steps = t_host.tolist()
-    x = init_noise.to(torch.float64) * t_steps[0]
-    kw = {} if y is None else {"y_B_C_T_H_W": y.to(dtype)}
-    switched = False
-    for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
-        switched = switched or (net_low is not None and t_cur < boundary)   # once low, stays low (:191-197)
-        model = net_low if switched else net
-        # (t_cur.float() * ones * 1000).to(dtype): the fp32 rounding of t_cur, times 1000 in fp64, cast  (:199)
-        t_in = torch.full((x.size(0), 1), float(t_host[i].float()) * 1000.0, dtype=torch.float64, device=dev).to(dtype)
-        v = model(x_B_C_T_H_W=x.to(dtype), timesteps_B_T=t_in, crossattn_emb=crossattn_emb, **kw).to(torch.float64)
-        if ode:
-            x = x - (t_cur - t_next) * v
-        else:
-            if noises is not None:
-                eps = noises[i].to(dev)
-            else:
-                eps = torch.randn(*x.shape, dtype=torch.float32, device=dev, generator=generator)
-            x = (1 - t_next) * (x - t_cur * v) + t_next * eps
+    x = None
+    for i, x in rcm_sample_iter(net, init_noise, crossattn_emb, num_steps, sigma_max, generator, noises, y, net_low,
+                                boundary, ode, dtype):
         if step_hook is not None:
             step_hook(i, x)
     return x.float()
