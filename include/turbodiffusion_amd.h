@@ -73,6 +73,34 @@ const char* td_last_error(void);
 int td_set_tuning(int key, int value);
 /* profiling: copy the n (<= 256) 64-bit s_memtime stamps of the last TD_TUNE_GEMM_ABLATE == 9 launch to host */
 int td_debug_read(unsigned long long* host_dst, int n);
+/* ---- f3: the two ends of the forward outside the blocks (csrc/embed_head.hip) ----
+ * td_patch_embed: patchify "b c (t kt) (h kh) (w kw) -> b (t h w) (c kt kh kw)" + patch_embedding Linear
+ *   (rcm/networks/wan2pt1.py:653-661; wan2pt2.py:644-645: y concatenated on channels = the second source x2 / c2).
+ *   x [B, c1, T, Hin, Win], x2 [B, c2, T, Hin, Win] or NULL (c2 = 0), w [dim, (c1+c2)*4], bias [dim], all `dtype`
+ *   (f16|bf16); y [B, rows, dim] = tokens [row0, row0 + rows) of every batch entry (a sequence-parallel rank's shard);
+ *   fp32 accumulate, bias added in fp32, one rounding.  Patch (1, 2, 2); (c1+c2) % 4 == 0, <= 64; dim % 8 == 0.
+ * td_head: Head.forward (wan2pt1.py:444-454) + unpatchify (:710-721): eager LayerNorm of x [B, rows, dim] (fp32 two-pass,
+ *   rounded to `dtype`), fp32 modulate with scale / shift f32 [B, dim] (= e[1], e[0]), fp32 Linear w [out_dim*4, dim],
+ *   bias [out_dim*4]; out f32 [B, out_dim, T, 2*Hh, 2*Ww] (unpatchify != 0; needs all tokens) or [B, rows, out_dim*4]. */
+int td_patch_embed(const void* x, int64_t c1, const void* x2, int64_t c2, int dtype, int64_t B, int64_t T, int64_t Hin,
+                   int64_t Win, const void* w, const void* bias, void* y, int64_t dim, int64_t row0, int64_t rows,
+                   td_stream_t stream);
+int td_head(const void* x, int dtype, const float* scale, const float* shift, const float* w, const float* bias, float eps,
+            float* out, int unpatchify, int64_t B, int64_t rows, int64_t dim, int64_t out_dim, int64_t T, int64_t Hh,
+            int64_t Ww, int64_t row0, td_stream_t stream);
+
+/* time embedding (wan2pt1.py:144-153, 671-674) and the AdaLN vectors of all blocks:
+ * td_time_sinusoid: t [B] (`dtype`, the bf16-rounded timesteps) -> out f32 [B, freq_dim] = cat(cos, sin)(t * 10000^(-j/half)), fp64;
+ * td_gemv_f32: out f32 [B, N] = act(x f32 [B, K]) @ float(w [N, K])^T + float(bias [N]), act = SiLU when silu_input
+ *   (the three Linears of time_embedding / time_projection in their fp32 island; w, bias 16-bit `dtype`); B <= 64;
+ * td_bcast_add: out f32 [A, B, R, D] = m [A, R, D] + e [B, RE, D] (RE == R or 1): (modulation + e0) of every block at once
+ *   (wan2pt1.py:400) and the head's (modulation + e) (:452). */
+int td_time_sinusoid(const void* t, int dtype, float* out, int64_t B, int64_t freq_dim, td_stream_t stream);
+int td_gemv_f32(const float* x, const void* w, const void* bias, int dtype, int silu_input, float* out, int64_t B, int64_t N,
+                int64_t K, td_stream_t stream);
+int td_bcast_add(const float* m, const float* e, float* out, int64_t A, int64_t B, int64_t R, int64_t RE, int64_t D,
+                 td_stream_t stream);
+
 /* measurement support (csrc/calib.hip; bench.py's "box" calibration — no reference counterpart: the reference ships no
  * benchmark code).  td_calib_mfma_i8: blocks x 256 threads, every wave issues iters x 4 v_mfma_i32_32x32x32_i8 (2*32^3 ops
  * each); td_calib_hbm_read: one streaming pass of 16-byte non-temporal loads over src[0, bytes); td_calib_clock_probe: one

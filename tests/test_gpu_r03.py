@@ -198,3 +198,99 @@ def test_hip_sla_kernels_vs_the_reference_triton_kernels(K, leaves):
         o, sp = m(*(I[n].transpose(1, 2).contiguous().to(DEV) for n in "qkv"), return_sparsity=True)
     assert abs(sp - leaves["sla_sparsity128"]) < 1e-9
     assert cosine(o, leaves["sla_module128"]) > 0.9995 and rel_l2(o, leaves["sla_module128"]) < 2e-2, rel_l2(o, leaves["sla_module128"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# f3: patchify + patch_embedding, time MLPs, AdaLN vectors, head + unpatchify in HIP (csrc/embed_head.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c1,c2,dim,dtype", [(16, 0, 1536, torch.bfloat16), (16, 20, 512, torch.bfloat16), (16, 0, 264, torch.float16)])
+def test_patch_embed_vs_fp64(K, c1, c2, dim, dtype):
+    """wan2pt1.py:653-661 (wan2pt2.py:644-645 with y): one rounding of the exact sum + bias; ragged token tiles, a row
+    range (a sequence-parallel shard), two sources instead of torch.cat."""
+    g = torch.Generator().manual_seed(c1 + c2 + dim)
+    B, T, Hin, Win = 2, 3, 10, 26                     # L = 3 * 5 * 13 = 195 tokens: 3 full tiles + 3 rows
+    x = torch.randn(B, c1, T, Hin, Win, generator=g).to(dtype).to(DEV)
+    y = torch.randn(B, c2, T, Hin, Win, generator=g).to(dtype).to(DEV) if c2 else None
+    C = c1 + c2
+    w = (torch.randn(dim, C * 4, generator=g) / (C * 4) ** 0.5).to(dtype).to(DEV)
+    b = (torch.randn(dim, generator=g) * 0.1).to(dtype).to(DEV)
+    xx = x if y is None else torch.cat([x, y], 1)
+    tok = xx.view(B, C, T, 1, Hin // 2, 2, Win // 2, 2).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, -1, C * 4)
+    exact = tok.double() @ w.double().t() + b.double()
+    ref = exact.to(dtype)
+    out = K.patch_embed(x, y, w, b)
+    assert out.shape == ref.shape
+    one_ulp = ref.float().abs() * (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) + 1e-6
+    assert ((out.float() - exact.float()).abs() <= one_ulp).all()
+    assert (out != ref).float().mean().item() < 1e-3          # (double roundings at ties of the fp32 sum only)
+    part = K.patch_embed(x, y, w, b, row0=64, rows=100)
+    assert torch.equal(part, out[:, 64:164])
+    # and the library path it replaces agrees to its own rounding
+    lib = torch.nn.functional.linear(tok, w, b)
+    assert (out != lib).float().mean().item() < 0.02 and (out.float() - lib.float()).abs().max() <= 2 * one_ulp.max()
+
+
+def test_time_embedding_and_adaln_vectors_vs_torch(K):
+    from turbodiffusion_amd.wan import sinusoidal_embedding_1d
+    g = torch.Generator().manual_seed(3)
+    dim, freq = 1536, 256
+    t = torch.tensor([987.654, 608.979, 0.0]).bfloat16().to(DEV)
+    e = K.time_sinusoid(t, freq)
+    torch.testing.assert_close(e, sinusoidal_embedding_1d(freq, t).float(), rtol=0, atol=2e-7)
+    w = (torch.randn(dim, freq, generator=g) * 0.05).bfloat16().to(DEV)
+    b = (torch.randn(dim, generator=g) * 0.02).bfloat16().to(DEV)
+    y = K.gemv_f32(e, w, b)
+    torch.testing.assert_close(y, torch.nn.functional.linear(e, w.float(), b.float()), rtol=1e-5, atol=1e-5)
+    w2 = (torch.randn(6 * dim, dim, generator=g) * 0.02).bfloat16().to(DEV)
+    b2 = (torch.randn(6 * dim, generator=g) * 0.02).bfloat16().to(DEV)
+    y2 = K.gemv_f32(y, w2, b2, silu_input=True)
+    ref2 = torch.nn.functional.linear(torch.nn.functional.silu(y).double(), w2.double(), b2.double()).float()
+    torch.testing.assert_close(y2, ref2, rtol=1e-5, atol=2e-6)
+    m = torch.randn(5, 6, dim, generator=g).to(DEV)
+    e0 = y2.unflatten(1, (6, dim))
+    assert torch.equal(K.bcast_add(m, e0), m.unsqueeze(1) + e0.unsqueeze(0))
+    hm = torch.randn(1, 2, dim, generator=g).to(DEV)
+    assert torch.equal(K.bcast_add(hm, y.view(3, 1, dim))[0], hm + y.unsqueeze(1))
+
+
+@pytest.mark.parametrize("dim,dtype,L_grid", [(1536, torch.bfloat16, (3, 5, 13)), (5120, torch.bfloat16, (2, 4, 9)), (256, torch.float16, (1, 8, 8))])
+def test_head_vs_the_operator_sequence(K, dim, dtype, L_grid):
+    """Head.forward + unpatchify (wan2pt1.py:444-454, 710-721) in one kernel against td_layernorm (fp32 out, eager
+    variance) -> fp32 Linear -> permute: fp32 results to summation order."""
+    g = torch.Generator().manual_seed(dim)
+    T, Hh, Ww = L_grid
+    L, B, od = T * Hh * Ww, 2, 16
+    x = (torch.randn(B, L, dim, generator=g) * 2 + 0.3).to(dtype).to(DEV)
+    sc, sh = (0.3 * torch.randn(B, dim, generator=g)).to(DEV), (0.3 * torch.randn(B, dim, generator=g)).to(DEV)
+    w = (torch.randn(od * 4, dim, generator=g) / dim ** 0.5).to(DEV)
+    b = (0.1 * torch.randn(od * 4, generator=g)).to(DEV)
+    hn = K.layernorm(x.view(B * L, dim), None, None, 1e-6, scale=sc, shift=sh, rows_per_batch=L, out_dtype=torch.float32)
+    ref = (hn.double() @ w.double().t() + b.double()).float().view(B, L, od * 4)
+    tok = K.head(x, sc, sh, w, b, 1e-6, od, T, Hh, Ww, unpatchify=False)
+    torch.testing.assert_close(tok, ref, rtol=2e-5, atol=2e-5)
+    vid = K.head(x, sc, sh, w, b, 1e-6, od, T, Hh, Ww, unpatchify=True)
+    ref_vid = ref.view(B, T, Hh, Ww, 1, 2, 2, od).permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(B, od, T, 2 * Hh, 2 * Ww)
+    torch.testing.assert_close(vid, ref_vid, rtol=2e-5, atol=2e-5)
+
+
+def test_forward_with_hip_embeddings_and_head_matches_the_library_path():
+    """WanModel.fuse_embed_head on / off on the dense bf16 configuration (no block-map near-ties to amplify a last-bit
+    difference of the embedding): the outputs agree to bf16 rounding noise; T2V and the I2V channel concatenation."""
+    from oracle import wan_ref as W
+    from tests.test_gpu_wan import make_net
+    gold = torch.load(os.path.join(GOLD, "wan_tiny.pt"), weights_only=False)
+    for in_dim, mt in ((16, "t2v"), (36, "i2v")):
+        cfg = dict(gold["cfg"], in_dim=in_dim, model_type=mt)
+        sd = W.make_state_dict(cfg, 21)
+        net = make_net(cfg, sd, "original", False)
+        g = torch.Generator().manual_seed(4)
+        x = torch.randn(2, 16, 3, 16, 24, generator=g).to(DEV).bfloat16()
+        y = torch.randn(2, 20, 3, 16, 24, generator=g).to(DEV).bfloat16() if mt == "i2v" else None
+        t = torch.tensor([[933.781], [608.979]], device=DEV).bfloat16()
+        ctx = gold["ctx"].to(DEV).bfloat16().expand(2, -1, -1).contiguous()
+        assert net.fuse_embed_head
+        a = net(x, t, ctx, y_B_C_T_H_W=y)
+        net.fuse_embed_head = False
+        b = net(x, t, ctx, y_B_C_T_H_W=y)
+        assert a.shape == b.shape == (2, 16, 3, 16, 24) and torch.isfinite(a).all()
+        assert rel_l2(a, b) < 5e-3, rel_l2(a, b)

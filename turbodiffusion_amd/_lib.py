@@ -27,6 +27,11 @@ SIGNATURES = {
     "td_last_error": [],
     "td_set_tuning": [_i32, _i32],
     "td_debug_read": [_vp, _i32],
+    "td_patch_embed": [_vp, _i64, _vp, _i64, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp],
+    "td_head": [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
+    "td_time_sinusoid": [_vp, _i32, _vp, _i64, _i64, _vp],
+    "td_gemv_f32": [_vp, _vp, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp],
+    "td_bcast_add": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
     "td_calib_mfma_i8": [_i32, _i32, _vp, _vp],
     "td_calib_hbm_read": [_vp, _i64, _vp, _vp],
     "td_calib_clock_probe": [_i64, _vp, _vp],

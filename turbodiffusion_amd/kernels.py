@@ -78,6 +78,79 @@ def set_tuning(key: int, value: int):
     call("td_set_tuning", key, value)
 
 
+# ----------------------------------------------------------------------------- f3: embeddings and head (csrc/embed_head.hip)
+def patch_embed(x, y, w, bias, row0=0, rows=None):
+    """patchify (1, 2, 2) + patch_embedding Linear: x [B, C1, T, Hin, Win] (+ y [B, C2, T, Hin, Win] concatenated on channels,
+    or None), w [dim, (C1+C2)*4], bias [dim], all the same 16-bit dtype -> tokens [B, rows, dim] (rows [row0, row0+rows) of
+    every batch entry; default all)."""
+    require_gpu(x, y, w, bias)
+    assert x.dim() == 5 and x.is_contiguous() and w.is_contiguous() and bias.is_contiguous()
+    assert x.dtype == w.dtype == bias.dtype and x.dtype in (torch.bfloat16, torch.float16)
+    B, c1, T, Hin, Win = x.shape
+    c2 = 0
+    if y is not None:
+        assert y.is_contiguous() and y.dtype == x.dtype and y.shape[0] == B and tuple(y.shape[2:]) == (T, Hin, Win)
+        c2 = y.shape[1]
+    dim = w.shape[0]
+    assert w.shape[1] == (c1 + c2) * 4 and bias.shape == (dim,)
+    L_ = T * (Hin // 2) * (Win // 2)
+    rows = L_ - row0 if rows is None else rows
+    out = torch.empty((B, rows, dim), dtype=x.dtype, device=x.device)
+    call("td_patch_embed", ptr(x), c1, ptr(y), c2, dt_code(x.dtype), B, T, Hin, Win, ptr(w), ptr(bias), ptr(out), dim, row0, rows,
+         stream_ptr())
+    return out
+
+
+def head(x, scale, shift, w, bias, eps, out_dim, T, Hh, Ww, unpatchify=True, row0=0):
+    """Head.forward + unpatchify: x [B, rows, dim] 16-bit, scale / shift f32 [B, dim] (e[1], e[0]), w f32 [out_dim*4, dim],
+    bias f32 [out_dim*4] -> f32 [B, out_dim, T, 2*Hh, 2*Ww] (unpatchify; needs all tokens) or [B, rows, out_dim*4]."""
+    require_gpu(x, scale, shift, w, bias)
+    assert x.dim() == 3 and x.is_contiguous()
+    B, rows, dim = x.shape
+    scale, shift = _f32c(scale, "scale"), _f32c(shift, "shift")
+    w, bias = _f32c(w, "head weight"), _f32c(bias, "head bias")
+    assert scale.shape == (B, dim) and shift.shape == (B, dim) and w.shape == (out_dim * 4, dim) and bias.shape == (out_dim * 4,)
+    if unpatchify:
+        out = torch.empty((B, out_dim, T, 2 * Hh, 2 * Ww), dtype=torch.float32, device=x.device)
+    else:
+        out = torch.empty((B, rows, out_dim * 4), dtype=torch.float32, device=x.device)
+    call("td_head", ptr(x), dt_code(x.dtype), ptr(scale), ptr(shift), ptr(w), ptr(bias), float(eps), ptr(out), 1 if unpatchify else 0,
+         B, rows, dim, out_dim, T, Hh, Ww, row0, stream_ptr())
+    return out
+
+
+def time_sinusoid(t, freq_dim):
+    """t [B] 16-bit -> f32 [B, freq_dim] (sinusoidal_embedding_1d in fp64, wan2pt1.py:144-153)."""
+    require_gpu(t)
+    assert t.dim() == 1 and t.is_contiguous() and t.dtype in (torch.bfloat16, torch.float16)
+    out = torch.empty((t.shape[0], freq_dim), dtype=torch.float32, device=t.device)
+    call("td_time_sinusoid", ptr(t), dt_code(t.dtype), ptr(out), t.shape[0], freq_dim, stream_ptr())
+    return out
+
+
+def gemv_f32(x, w, bias, silu_input=False):
+    """f32 [B, N] = act(x f32 [B, K]) @ float(w [N, K])^T + float(bias); 16-bit w / bias; act = SiLU when silu_input."""
+    require_gpu(x, w, bias)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and w.is_contiguous() and bias.is_contiguous()
+    assert w.dtype == bias.dtype and w.dtype in (torch.bfloat16, torch.float16) and w.shape[1] == x.shape[1]
+    out = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=x.device)
+    call("td_gemv_f32", ptr(x), ptr(w), ptr(bias), dt_code(w.dtype), 1 if silu_input else 0, ptr(out), x.shape[0], w.shape[0],
+         x.shape[1], stream_ptr())
+    return out
+
+
+def bcast_add(m, e):
+    """m f32 [A, R, D] + e f32 [B, RE, D] (RE == R or 1) -> f32 [A, B, R, D]."""
+    require_gpu(m, e)
+    m, e = _f32c(m, "m"), _f32c(e, "e")
+    A, R, D = m.shape
+    B, RE, D2 = e.shape
+    assert D2 == D and RE in (R, 1)
+    out = torch.empty((A, B, R, D), dtype=torch.float32, device=m.device)
+    call("td_bcast_add", ptr(m), ptr(e), ptr(out), A, B, R, RE, D, stream_ptr())
+    return out
+
+
 # ----------------------------------------------------------------------------- measurement support (csrc/calib.hip)
 def box_calibration(gemm_fn=None, device=None):
     """What this box sustains right now (bench.py's "box" record): the dense INT8 matrix-pipe rate, the streaming HBM read

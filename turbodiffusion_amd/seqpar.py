@@ -246,6 +246,10 @@ class _ModelAdapter:
     def gather_tokens(self, out, L):
         return self.sp.gather_tokens(out, L)
 
+    def shard_range(self, L):
+        """This rank's token range [start, stop) of L tokens (the fused patch-embedding kernel reads only those)."""
+        return self.sp.plan(L)
+
     def self_attention(self, model, fused, q, k, qkv, out):
         dim, D = model.dim, 128
         return self.sp.self_attention(q, k, qkv[:, 2 * dim:], (D, 3 * dim), out, D, dim, model.attention_type,

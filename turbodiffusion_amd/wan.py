@@ -158,6 +158,7 @@ class WanModel(nn.Module):
         self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
         self.fuse_vt = True         # self-attention V leaves the q|k|v GEMM as the attention kernel's V^T tiles (K.gemm_w8a8_vt)
         self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
+        self.fuse_embed_head = True  # patchify+patch_embedding, time MLPs, AdaLN vectors, head+unpatchify in HIP (embed_head.hip)
         self.split_tokens = True    # everything after self-attention is token-local: two token halves on two streams (_block)
         self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
@@ -620,28 +621,49 @@ class WanModel(nn.Module):
                                       "Wan2.2-A14B I2V conditions through y_B_C_T_H_W only")
         assert timesteps_B_T.shape[1] == 1
         t_B = timesteps_B_T[:, 0]
-        if y_B_C_T_H_W is not None:
-            x_B_C_T_H_W = torch.cat([x_B_C_T_H_W, y_B_C_T_H_W], dim=1)
         kt, kh, kw = self.patch_size
-        B, C, T_in, H_in, W_in = x_B_C_T_H_W.shape
+        B, C1, T_in, H_in, W_in = x_B_C_T_H_W.shape
+        C = C1 + (0 if y_B_C_T_H_W is None else y_B_C_T_H_W.shape[1])
         assert T_in % kt == 0 and H_in % kh == 0 and W_in % kw == 0
         T, H, W = T_in // kt, H_in // kh, W_in // kw
         L_ = T * H * W
         dt = self.dtype
-        # patchify "b c (t kt) (h kh) (w kw) -> b (t h w) (c kt kh kw)"   (wan2pt1.py:653-660)
-        x = x_B_C_T_H_W.to(dt).view(B, C, T, kt, H, kh, W, kw).permute(0, 2, 4, 6, 1, 3, 5, 7)
-        x = x.reshape(B, L_, C * kt * kh * kw)
-        cos, sin = self._rope(T, H, W, x.device)
+        cos, sin = self._rope(T, H, W, x_B_C_T_H_W.device)
         sp = self.seq_parallel
-        if sp is not None:
-            x, cos, sin = sp.shard_tokens(x, cos, sin)
-        x = self.patch_embedding(x).contiguous()  # [B, L_loc, dim]
-        # time embeddings in fp32 (the reference's autocast(float32) island, wan2pt1.py:671-674)
-        te, tp = self.time_embedding, self.time_projection
-        e = sinusoidal_embedding_1d(self.freq_dim, t_B).float()
-        e = F.linear(e, te[0].weight.float(), te[0].bias.float())
-        e_B_D = F.linear(F.silu(e), te[2].weight.float(), te[2].bias.float())
-        e0 = F.linear(F.silu(e_B_D), tp[1].weight.float(), tp[1].bias.float()).unflatten(1, (6, self.dim))
+        # f3 in HIP (csrc/embed_head.hip): patchify + patch_embedding, the time MLPs, the AdaLN vectors, head + unpatchify —
+        # no library GEMM and no torch elementwise kernel inside a captured forward
+        fe = (self.fuse_embed_head and (kt, kh, kw) == (1, 2, 2) and C % 4 == 0 and C <= 64 and dt in (torch.bfloat16, torch.float16)
+              and self.patch_embedding.weight.dtype == dt and timesteps_B_T.dtype in (torch.bfloat16, torch.float16)
+              and self.dim % 8 == 0 and self.out_dim * 4 <= 64)
+        row0 = 0
+        if fe:
+            if sp is not None:
+                row0, stop = sp.shard_range(L_)
+                cos, sin = cos[row0:stop].contiguous(), sin[row0:stop].contiguous()
+            else:
+                stop = L_
+            x = K.patch_embed(x_B_C_T_H_W.to(dt).contiguous(), None if y_B_C_T_H_W is None else y_B_C_T_H_W.to(dt).contiguous(),
+                              self.patch_embedding.weight, self.patch_embedding.bias, row0, stop - row0)   # [B, L_loc, dim]
+            # time embeddings in fp32 (the reference's autocast(float32) island, wan2pt1.py:671-674)
+            te, tp = self.time_embedding, self.time_projection
+            e = K.gemv_f32(K.time_sinusoid(t_B.contiguous(), self.freq_dim), te[0].weight, te[0].bias)
+            e_B_D = K.gemv_f32(e, te[2].weight, te[2].bias, silu_input=True)
+            e0 = K.gemv_f32(e_B_D, tp[1].weight, tp[1].bias, silu_input=True).unflatten(1, (6, self.dim))
+        else:
+            if y_B_C_T_H_W is not None:
+                x_B_C_T_H_W = torch.cat([x_B_C_T_H_W, y_B_C_T_H_W], dim=1)
+            # patchify "b c (t kt) (h kh) (w kw) -> b (t h w) (c kt kh kw)"   (wan2pt1.py:653-660)
+            x = x_B_C_T_H_W.to(dt).view(B, C, T, kt, H, kh, W, kw).permute(0, 2, 4, 6, 1, 3, 5, 7)
+            x = x.reshape(B, L_, C * kt * kh * kw)
+            if sp is not None:
+                x, cos, sin = sp.shard_tokens(x, cos, sin)
+            x = self.patch_embedding(x).contiguous()  # [B, L_loc, dim]
+            # time embeddings in fp32 (the reference's autocast(float32) island, wan2pt1.py:671-674)
+            te, tp = self.time_embedding, self.time_projection
+            e = sinusoidal_embedding_1d(self.freq_dim, t_B).float()
+            e = F.linear(e, te[0].weight.float(), te[0].bias.float())
+            e_B_D = F.linear(F.silu(e), te[2].weight.float(), te[2].bias.float())
+            e0 = F.linear(F.silu(e_B_D), tp[1].weight.float(), tp[1].bias.float()).unflatten(1, (6, self.dim))
         tkv = kvts = None
         if self.cache_text_kv:
             context, kvts = self.prepare_text(crossattn_emb)[2:4]   # once per text (keyed on the tensor's identity + version)
@@ -656,7 +678,10 @@ class WanModel(nn.Module):
         mods = self._fused.get("mods")
         if mods is None or mods[1] != ver:
             mods = self._fused["mods"] = (torch.stack([blk.modulation.detach().float() for blk in self.blocks], 0), ver)
-        e_all = mods[0] + e0.unsqueeze(0)                    # fp32 [nblk, B, 6, dim]
+        if fe:
+            e_all = K.bcast_add(mods[0].view(len(self.blocks), 6, self.dim), e0.contiguous())   # fp32 [nblk, B, 6, dim]
+        else:
+            e_all = mods[0] + e0.unsqueeze(0)                    # fp32 [nblk, B, 6, dim]
         self._carry_stats = None
         tap = getattr(self, "_tap_tokens", None)   # tools/drift.py: list that receives the tokens after every block
         for i, blk in enumerate(self.blocks):
@@ -666,13 +691,26 @@ class WanModel(nn.Module):
         if return_tokens:
             return x if sp is None else sp.gather_tokens(x, L_)
         # head (wan2pt1.py:444-454): fp32 modulate of the (bf16) norm, fp32 Linear
-        em = (self.head.modulation.float() + e_B_D.unsqueeze(1))  # [B, 2, dim]
         L_loc = x.shape[1]
-        hn = K.layernorm(x.view(B * L_loc, self.dim), None, None, self.eps, scale=em[:, 1].contiguous(),
-                         shift=em[:, 0].contiguous(), rows_per_batch=L_loc, out_dtype=torch.float32)
-        out = F.linear(hn, self.head.head.weight.float(), self.head.head.bias.float()).view(B, L_loc, -1)
-        if sp is not None:
+        if fe:
+            hw = self._fused.get("head")
+            if hw is None:   # the fp32 island's up-cast of the (bf16) head parameters, made once
+                hw = self._fused["head"] = (self.head.head.weight.detach().float().contiguous(),
+                                           self.head.head.bias.detach().float().contiguous(),
+                                           self.head.modulation.detach().float().contiguous().view(1, 2, self.dim))
+            em = K.bcast_add(hw[2], e_B_D.view(B, 1, self.dim))[0]    # [B, 2, dim] = modulation + e
+            out = K.head(x, em[:, 1].contiguous(), em[:, 0].contiguous(), hw[0], hw[1], self.eps, self.out_dim, T, H, W,
+                         unpatchify=sp is None, row0=row0)
+            if sp is None:
+                return out
             out = sp.gather_tokens(out, L_)
+        else:
+            em = (self.head.modulation.float() + e_B_D.unsqueeze(1))  # [B, 2, dim]
+            hn = K.layernorm(x.view(B * L_loc, self.dim), None, None, self.eps, scale=em[:, 1].contiguous(),
+                             shift=em[:, 0].contiguous(), rows_per_batch=L_loc, out_dtype=torch.float32)
+            out = F.linear(hn, self.head.head.weight.float(), self.head.head.bias.float()).view(B, L_loc, -1)
+            if sp is not None:
+                out = sp.gather_tokens(out, L_)
         # unpatchify "b (t h w) (kt kh kw d) -> b d (t kt) (h kh) (w kw)"   (wan2pt1.py:710-721)
         out = out.view(B, T, H, W, kt, kh, kw, self.out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
         return out.reshape(B, self.out_dim, T * kt, H * kh, W * kw)
