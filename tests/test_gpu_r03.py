@@ -267,10 +267,13 @@ def test_head_vs_the_operator_sequence(K, dim, dtype, L_grid):
     hn = K.layernorm(x.view(B * L, dim), None, None, 1e-6, scale=sc, shift=sh, rows_per_batch=L, out_dtype=torch.float32)
     ref = (hn.double() @ w.double().t() + b.double()).float().view(B, L, od * 4)
     tok = K.head(x, sc, sh, w, b, 1e-6, od, T, Hh, Ww, unpatchify=False)
-    torch.testing.assert_close(tok, ref, rtol=2e-5, atol=2e-5)
+    # fp32 sums to their order; a normalised value that lands on a rounding tie of the 16-bit cast may fall the other way
+    # (one fp16 ulp of one of the `dim` addends of a row's outputs: 1e-4 absolute) — bounded, and rare
+    torch.testing.assert_close(tok, ref, rtol=2e-5, atol=3e-4)
+    assert ((tok - ref).abs() > 2e-5).float().mean().item() < 0.01
     vid = K.head(x, sc, sh, w, b, 1e-6, od, T, Hh, Ww, unpatchify=True)
-    ref_vid = ref.view(B, T, Hh, Ww, 1, 2, 2, od).permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(B, od, T, 2 * Hh, 2 * Ww)
-    torch.testing.assert_close(vid, ref_vid, rtol=2e-5, atol=2e-5)
+    got_tok = vid.view(B, od, T, 1, Hh, 2, Ww, 2).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(B, L, od * 4)
+    assert torch.equal(got_tok, tok), "unpatchify is a pure permutation of the token-major result"
 
 
 def test_forward_with_hip_embeddings_and_head_matches_the_library_path():
@@ -294,3 +297,26 @@ def test_forward_with_hip_embeddings_and_head_matches_the_library_path():
         b = net(x, t, ctx, y_B_C_T_H_W=y)
         assert a.shape == b.shape == (2, 16, 3, 16, 24) and torch.isfinite(a).all()
         assert rel_l2(a, b) < 5e-3, rel_l2(a, b)
+
+
+def test_twelve_layers_deep_against_the_oracle(K, capsys):
+    """Drift over depth against the ORACLE's statement of the turbo arithmetic (not against a dense-bf16 run): 12 blocks,
+    W8A8 + Fast norms (the reference's Triton LayerNorm variance) + SageSLA top-k 0.25 at L = 4096.  Block-map near-ties and
+    INT8 rounding differences compound with depth (one block <= 2e-2, four blocks x four steps <= 4e-2)."""
+    from turbodiffusion_amd.wan import WanModel
+    g = _load("deep")
+    c, x, t, ctx, sd = R.deep_inputs()
+    with torch.device(DEV):
+        net = WanModel(attention_type="sagesla", sla_topk=c["topk"], quant_linear=True, **c["cfg"])
+    net.load_from_float_state_dict({k_: v_.to(DEV) for k_, v_ in sd.items()})
+    del sd
+    net.eval()
+    xd, td, cd = x.to(DEV).bfloat16(), t.to(DEV), ctx.to(DEV)
+    tok = net(xd, td, cd, _return_tokens=True)[0][g["rows"].to(DEV)]
+    v = net(xd, td, cd)
+    r_tok, r_v = rel_l2(tok, g["tok_rows"]), rel_l2(v, g["v"].float())
+    with capsys.disabled():
+        print(f"\n[12 layers deep, L = 4096] rel-L2 vs the oracle: tokens after the last block {r_tok:.4f}, velocity {r_v:.4f}")
+    assert torch.isfinite(v).all()
+    assert r_tok < 6e-2 and cosine(tok, g["tok_rows"]) > 0.998, r_tok
+    assert r_v < 6e-2 and cosine(v, g["v"].float()) > 0.998, r_v

@@ -202,11 +202,22 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* _
   int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
   const bool ok = row < m;
   if (!ok) row = m - 1;
+  // a lane's pieces (sub, sub + 8, ...: at most RSF_MAX of them — n <= 8192) stay in registers: ONE pass over the
+  // workspace, all loads in flight together; the second (between-piece) sum runs on the registers
+  constexpr int RSF_MAX = 16;
+  float2 v[RSF_MAX];
+#pragma unroll
+  for (int i = 0; i < RSF_MAX; ++i) {
+    const int p = sub + 8 * i;
+    v[i] = (p < pieces) ? ws[row * pieces + p] : make_float2(0.f, 0.f);
+  }
   float s = 0.f, q = 0.f;
-  for (int p = sub; p < pieces; p += 8) {
-    const float2 v = ws[row * pieces + p];
-    s += v.x;
-    q += (mode == 0) ? v.y : fmaf(64.0f * v.x, v.x, v.y);
+#pragma unroll
+  for (int i = 0; i < RSF_MAX; ++i) {
+    if (sub + 8 * i < pieces) {
+      s += v[i].x;
+      q += (mode == 0) ? v[i].y : fmaf(64.0f * v[i].x, v[i].x, v[i].y);
+    }
   }
 #pragma unroll
   for (int o = 1; o < 8; o <<= 1) {
@@ -215,10 +226,13 @@ __global__ __launch_bounds__(256) void row_stats_finalize_kernel(const float2* _
   }
   if (mode == 0) {
     const float mean = s / (float)pieces;
-    float b = 0.f;                       // between-piece part: 64 * sum (mean_p - mean)^2 (second read: L1/L2-resident)
-    for (int p = sub; p < pieces; p += 8) {
-      const float d = ws[row * pieces + p].x - mean;
-      b = fmaf(d, d, b);
+    float b = 0.f;                       // between-piece part: 64 * sum (mean_p - mean)^2
+#pragma unroll
+    for (int i = 0; i < RSF_MAX; ++i) {
+      if (sub + 8 * i < pieces) {
+        const float d = v[i].x - mean;
+        b = fmaf(d, d, b);
+      }
     }
 #pragma unroll
     for (int o = 1; o < 8; o <<= 1) b += __shfl_xor(b, o, 64);
@@ -235,7 +249,7 @@ extern "C" int td_row_stats_finalize(const float* ws, int pieces, int64_t n, flo
                                      float* out, int64_t m, td_stream_t stream) {
   TD_REQUIRE(pad_cols >= 0 && pad_cols <= 8192, TD_ERR_INVALID, "td_row_stats_finalize: pad_cols=%lld", (long long)pad_cols);
   TD_REQUIRE(ws && out, TD_ERR_INVALID, "td_row_stats_finalize: null pointer");
-  TD_REQUIRE(pieces > 0 && n == (int64_t)pieces * 64 && m >= 0 && (mode == 0 || mode == 1), TD_ERR_INVALID,
+  TD_REQUIRE(pieces > 0 && pieces <= 128 && n == (int64_t)pieces * 64 && m >= 0 && (mode == 0 || mode == 1), TD_ERR_INVALID,
              "td_row_stats_finalize: pieces=%d n=%lld mode=%d (need n == 64 * pieces: every piece is 64 values)", pieces, (long long)n, mode);
   if (m == 0) return TD_OK;
   row_stats_finalize_kernel<<<(unsigned)td_cdiv(m, 32), 256, 0, (hipStream_t)stream>>>(
