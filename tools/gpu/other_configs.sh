@@ -7,7 +7,7 @@ i=0
 for a in "--workload c2" "--workload c3" "--model Wan2.1-14B --res 720p" "--model Wan2.2-A14B --res 720p --two-experts" "--model Wan2.1-14B --res 480p" "--sage-pv fp8" "--gemm-fast 4" "--gemm-fast 4 --sage-pv fp8"; do
   i=$((i+1)); log=gpurun_out/cfg_${T}_$i.log     # one log per configuration (a timeout must stay diagnosable)
   t0=$(date +%s)
-  timeout 600 python bench.py $a --steps 1 --warmup 1 --no-cpu-baseline > $log 2>&1; rc=$?
+  TD_BENCH_WATCHDOG_S=200 timeout 600 python bench.py $a --steps 2 --warmup 1 --no-cpu-baseline > $log 2>&1; rc=$?
   echo "[$a] exit $rc after $(( $(date +%s) - t0 )) s" >> $log
   grep '^{' $log >> gpurun_out/other_configs_$T.jsonl || { echo "FAILED (exit $rc): $a"; tail -5 $log; }
 done
