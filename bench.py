@@ -308,7 +308,8 @@ def main():
     for kv in filter(None, os.environ.get("TD_BENCH_MODEL_FLAGS", "").split(",")):   # A/B runs: fuse_* attributes of WanModel
         key, val = kv.split("=")
         assert hasattr(net, key), key
-        setattr(net, key, bool(int(val)) if val.isdigit() else val)
+        for m_ in filter(None, (net, net_low)):
+            setattr(m_, key, bool(int(val)) if val.isdigit() else val)
     # sp > 1: the forward is a chain of graph segments with the RCCL all-gathers re-issued eagerly between them (graph.py)
     use_graph = not args.no_graph
     run_net, run_low = net, net_low

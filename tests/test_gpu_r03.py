@@ -4,7 +4,10 @@
          codes bit-exact and block map >= 99 % on a 4-head subset; SageSLA rows rel-L2 <= 2e-2
   c2     configs[1], dense SageAttention INT8-QK at L = 32 760: sampled Q blocks vs the oracle, rel-L2 <= 2e-2
   steps  4 layers x 4 rCM steps at L = 4096: the DiT forward teacher-forced on the oracle's latents (velocity per step) and
-         the free-running sampler (latent per step); the per-step rel-L2 figures are printed and bounded."""
+         the free-running sampler (latent per step); the per-step rel-L2 figures are printed and bounded (<= 2e-2)
+  deep   12 layers, one forward at L = 4096: tokens after the last block and velocity vs the oracle (<= 3e-2)
+  leaves the HIP kernels against what the reference's own Triton kernels produced on an MI355X (triton_leaves.pt)
+  f3     patch embedding / time MLPs / head kernels against fp64 and the operator sequences they replace"""
 import os
 
 import numpy as np
@@ -127,9 +130,10 @@ def test_four_layers_four_steps_against_the_oracle(K, capsys):
     with capsys.disabled():
         print(f"\n[4 layers x 4 steps, L = 4096] velocity rel-L2 per step (teacher-forced): {[round(f, 4) for f in forced]}; "
               f"latent rel-L2 per step (free-running): {[round(f, 4) for f in free]}")
-    # 4 blocks deep the block-map's near-ties and the INT8 rounding differences compound (one block: <= 2e-2, test_gpu_c1)
-    assert max(forced) < 4e-2, forced
-    assert max(free) < 4e-2 and rel_l2(out, g["final"]) < 4e-2, (free, rel_l2(out, g["final"]))
+    # measured on the MI355X (profiles/r03_pytest_gpu.txt): velocity 0.0067-0.0069 per step, latent 0.0017 -> 0.0044 over the
+    # four steps; the bound is the single-block tolerance (2e-2, test_gpu_c1) — block-map near-ties may move it between boxes
+    assert max(forced) < 2e-2, forced
+    assert max(free) < 2e-2 and rel_l2(out, g["final"]) < 2e-2, (free, rel_l2(out, g["final"]))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -302,7 +306,7 @@ def test_forward_with_hip_embeddings_and_head_matches_the_library_path():
 def test_twelve_layers_deep_against_the_oracle(K, capsys):
     """Drift over depth against the ORACLE's statement of the turbo arithmetic (not against a dense-bf16 run): 12 blocks,
     W8A8 + Fast norms (the reference's Triton LayerNorm variance) + SageSLA top-k 0.25 at L = 4096.  Block-map near-ties and
-    INT8 rounding differences compound with depth (one block <= 2e-2, four blocks x four steps <= 4e-2)."""
+    INT8 rounding differences compound with depth."""
     from turbodiffusion_amd.wan import WanModel
     g = _load("deep")
     c, x, t, ctx, sd = R.deep_inputs()
@@ -318,5 +322,6 @@ def test_twelve_layers_deep_against_the_oracle(K, capsys):
     with capsys.disabled():
         print(f"\n[12 layers deep, L = 4096] rel-L2 vs the oracle: tokens after the last block {r_tok:.4f}, velocity {r_v:.4f}")
     assert torch.isfinite(v).all()
-    assert r_tok < 6e-2 and cosine(tok, g["tok_rows"]) > 0.998, r_tok
-    assert r_v < 6e-2 and cosine(v, g["v"].float()) > 0.998, r_v
+    # measured: 0.0094 / 0.0092 (profiles/r03_pytest_gpu.txt); bound 3e-2
+    assert r_tok < 3e-2 and cosine(tok, g["tok_rows"]) > 0.999, r_tok
+    assert r_v < 3e-2 and cosine(v, g["v"].float()) > 0.999, r_v

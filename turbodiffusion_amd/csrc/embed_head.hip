@@ -153,7 +153,10 @@ extern "C" int td_patch_embed(const void* x, int64_t c1, const void* x2, int64_t
 // registers); phase 2: K chunks of 128 through LDS, 4 waves as 2 (token halves) x 2 (output halves).
 // ------------------------------------------------------------------------------------------------------------------
 #define HD_KC 128
-#define HD_KS 129   // LDS row stride in words: conflict-free ds_read_b32 of 32 rows at one k
+#define HD_KS 132   // LDS row stride in words (16-byte aligned rows; 132 % 32 = 4: eight rows cover the 32 banks with 16 B each)
+// Within a row of a chunk the 128 k are stored EVEN k first, then ODD k (position of k = (k & 1) * 64 + k / 2): the fp32 MFMA
+// 32x32x2 gives lane (row, hi) the operand k = kk + hi of step kk, so the operands of four consecutive steps kk = 8m .. 8m+6
+// are the 16 contiguous bytes at hi * 64 + 4m — one ds_read_b128 per operand and four MFMAs instead of one ds_read_b32 each.
 
 template <int DT, int NV>
 __global__ __launch_bounds__(256) void head_kernel(const uint16_t* __restrict__ x, const float* __restrict__ scale,
@@ -236,8 +239,8 @@ __global__ __launch_bounds__(256) void head_kernel(const uint16_t* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) hv[j] = 0.f;
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) hn_s[row * HD_KS + c8 * 8 + j] = hv[j];
+      *reinterpret_cast<float4*>(hn_s + row * HD_KS + c8 * 4) = make_float4(hv[0], hv[2], hv[4], hv[6]);        // even k
+      *reinterpret_cast<float4*>(hn_s + row * HD_KS + 64 + c8 * 4) = make_float4(hv[1], hv[3], hv[5], hv[7]);   // odd k
     }
     // W chunk: P rows x 128 columns (rows >= P: zero)
     for (int q = tid; q < 64 * (HD_KC / 4); q += 256) {
@@ -245,15 +248,18 @@ __global__ __launch_bounds__(256) void head_kernel(const uint16_t* __restrict__ 
       const int col = k0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < P && col < dim) v = *reinterpret_cast<const float4*>(w + (int64_t)row * dim + col);
-      float* d = w_s + row * HD_KS + c4 * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      *reinterpret_cast<float2*>(w_s + row * HD_KS + c4 * 2) = make_float2(v.x, v.z);
+      *reinterpret_cast<float2*>(w_s + row * HD_KS + 64 + c4 * 2) = make_float2(v.y, v.w);
     }
     __syncthreads();
-#pragma unroll 8
-    for (int kk = 0; kk < HD_KC; kk += 2) {
-      const float a = w_s[(jh * 32 + li) * HD_KS + kk + hi];
-      const float bq = hn_s[(tg * 32 + li) * HD_KS + kk + hi];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+#pragma unroll 4
+    for (int m4 = 0; m4 < HD_KC / 8; ++m4) {
+      const float4 a = *reinterpret_cast<const float4*>(w_s + (jh * 32 + li) * HD_KS + hi * 64 + 4 * m4);
+      const float4 bq = *reinterpret_cast<const float4*>(hn_s + (tg * 32 + li) * HD_KS + hi * 64 + 4 * m4);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, acc, 0, 0, 0);
     }
     __syncthreads();
   }
