@@ -21,6 +21,13 @@ Parity pinning status:
     only its Triton / SpargeAttn / CUDA leaves replaced
     (``ref_harness.patched_sla``; ``tests/golden/sla_tiny.pt`` carries the
     reference-produced tensors to the GPU box).
+  * The reference's TRITON leaves — ``_attn_fwd`` (SLA/kernel.py:21-82), ``compress_kernel`` / ``mean_pool`` and
+    ``get_block_map`` (SLA/utils.py:21-67), ``rmsnorm`` / ``layernorm`` (ops/core.py:96-136, 193-335), and the whole
+    unpatched ``SparseLinearAttention`` module — were EXECUTED on an MI355X (``oracle/triton_leaves.py``: stage, gpurun,
+    unstage; Triton 3.6 builds them for gfx950 unmodified) and their outputs are the fixture
+    ``tests/golden/triton_leaves.pt``: pooling and block map agree bit for bit, attention to one bf16 rounding step on
+    0.05 % of the values, RMSNorm to 3e-7, and LayerNorm once the oracle learnt that the reference sums (x - mean)^2 over
+    next_power_of_2(N) columns (``ops_ref.layernorm_fast``).  The Wan2.2 network (``wan2pt2``) is pinned live as well.
   * Block-128 INT8 quantiser and W8A8 GEMM (CUDA sources, not buildable here —
     need nvcc + the un-vendored CUTLASS submodule): restated from the source
     lines cited; the reference ships no test vectors for them.
