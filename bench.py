@@ -315,8 +315,6 @@ def main():
     run_net, run_low = net, net_low
     if use_graph:
         from turbodiffusion_amd.graph import GraphedModel
-        if os.environ.get("TD_BENCH_GRAPH_TEXT") == "0":     # A/B: enqueue every new prompt's text side eagerly
-            GraphedModel.graph_text = False
         run_net = GraphedModel(net)
         run_low = None if net_low is None else GraphedModel(net_low)
 

@@ -139,7 +139,6 @@ class GraphedModel(torch.nn.Module):
         self._text_src = {}   # per graph: (the text tensor last copied into its static buffer — the OBJECT, held so that its
         #                       address cannot be recycled for another prompt — , its version at that time)
         self._epoch = getattr(net, "_weights_epoch", 0)
-        self._text_graphs = {}        # per forward graph: the captured refresh of the model's persistent text buffers from `sc`
         self._sp_eager = False        # set when a segmented capture failed: eager from then on (sp_capture_error says why)
         self.sp_capture_error = None
 
@@ -157,29 +156,6 @@ class GraphedModel(torch.nn.Module):
             sc.copy_(crossattn_emb)
             self._text_src[key] = (crossattn_emb, crossattn_emb._version)
 
-    def _prepare_text(self, key, sc):
-        """``net.prepare_text(sc)`` with the recomputation for a NEW prompt replayed as a hipGraph: the text side is ≈ 150
-        small launches (text MLP, the all-blocks K|V GEMM, per block K RMSNorm + V^T tiles + the copies into the persistent
-        buffers) whose eager enqueue costs ≈ 2 ms of host time per prompt — more than their GPU time.  The first miss of an
-        entry runs eagerly (it allocates the persistent buffers); later misses replay the captured refresh, which reads the
-        static text buffer ``sc`` and writes those same buffers (the forward graph's pointers stay valid)."""
-        net = self.net
-        st = net._text_states.get(sc.data_ptr())
-        if st is None or (st[0][1] == sc._version and st[0][2:] == (tuple(sc.shape), sc.dtype)) \
-                or st[2].shape[0] != sc.shape[0] or getattr(net, "seq_parallel", None) is not None or not self.graph_text:
-            return net.prepare_text(sc)          # hit, first miss, or a case left eager
-        tg = self._text_graphs.get(key)
-        if tg is None:
-            torch.cuda.synchronize()
-            tg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(tg):
-                net.refresh_text_inplace(st, sc)
-            self._text_graphs[key] = tg
-        tg.replay()
-        return net.rekey_text(st, sc)
-
-    graph_text = True   # False: every new prompt's text side is enqueued eagerly (A/B, bisection)
-
     @torch.no_grad()
     def forward(self, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, frame_cond_crossattn_emb_B_L_D=None,
                 y_B_C_T_H_W: Optional[torch.Tensor] = None, **kwargs):
@@ -191,7 +167,6 @@ class GraphedModel(torch.nn.Module):
         if epoch != self._epoch:   # derived weight copies were dropped: captured graphs hold pointers into freed tensors
             self._graphs.clear()
             self._text_src.clear()
-            self._text_graphs.clear()
             self._epoch = epoch
         key = self._key(x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W)
         ent = self._graphs.get(key)
@@ -202,9 +177,8 @@ class GraphedModel(torch.nn.Module):
             # model's persistent text buffers; should the model have re-allocated them (cache eviction), re-capture.
             sc = ent[3]
             self._refresh_text(key, sc, crossattn_emb)
-            if self._prepare_text(key, sc)[4] != ent[6]:
+            if self.net.prepare_text(sc)[4] != ent[6]:
                 del self._graphs[key]
-                self._text_graphs.pop(key, None)
                 ent = None
         if ent is None:
             sx, st, sc = x_B_C_T_H_W.clone(), timesteps_B_T.clone(), crossattn_emb.clone()

@@ -443,10 +443,19 @@ class WanModel(nn.Module):
         st = self._text_states.get(key[0])
         if st is not None and st[0] == key:
             return st
-        context, per_b = self._compute_text(crossattn_emb)
+        context = self.text_embedding(crossattn_emb.to(self.dtype)).contiguous()  # [B, Lc, dim]
+        B = context.shape[0]
+        per_b = []
+        for b in range(B):
+            tkv = self._text_kv_all(context[b]) if self.batch_text_kv else None
+            per_b.append([self._text_kvt(i, blk, context[b], tkv) for i, blk in enumerate(self.blocks)])
         gen = None
-        if st is not None and st[2].shape == context.shape and len(st[3]) == context.shape[0]:
-            self._store_text(st, context, per_b)       # same buffers, new contents: refresh the persistent tensors in place
+        if st is not None and st[2].shape == context.shape and len(st[3]) == B:
+            st[2].copy_(context)                       # same buffer, new contents: refresh the persistent tensors in place
+            for old_b, new_b in zip(st[3], per_b):
+                for (ok, ovt), (nk, nvt) in zip(old_b, new_b):
+                    ok.copy_(nk)
+                    ovt.copy_(nvt)
             context, per_b, gen = st[2], st[3], st[4]
         if gen is None:     # new persistent buffers: a graph captured on an earlier generation of this entry must re-capture
             self._text_gen += 1
@@ -457,40 +466,6 @@ class WanModel(nn.Module):
         while len(self._text_states) >= 8:
             self._text_states.pop(next(iter(self._text_states)))
         self._text_states[key[0]] = (key, crossattn_emb, context, per_b, gen)
-        return self._text_states[key[0]]
-
-    def _compute_text(self, crossattn_emb):
-        """The device work of ``prepare_text``: text MLP -> context [B, Lc, dim]; per batch entry and block the cross-attention
-        K (RMSNorm'ed, head-major) and V^T tiles."""
-        context = self.text_embedding(crossattn_emb.to(self.dtype)).contiguous()  # [B, Lc, dim]
-        per_b = []
-        for b in range(context.shape[0]):
-            tkv = self._text_kv_all(context[b]) if self.batch_text_kv else None
-            per_b.append([self._text_kvt(i, blk, context[b], tkv) for i, blk in enumerate(self.blocks)])
-        return context, per_b
-
-    @staticmethod
-    def _store_text(st, context, per_b):
-        st[2].copy_(context)
-        for old_b, new_b in zip(st[3], per_b):
-            for (ok, ovt), (nk, nvt) in zip(old_b, new_b):
-                ok.copy_(nk)
-                ovt.copy_(nvt)
-
-    @torch.no_grad()
-    def refresh_text_inplace(self, st, crossattn_emb):
-        """Recompute the text side of cache entry ``st`` (as returned by ``prepare_text``) from ``crossattn_emb`` into ITS
-        persistent buffers — device work only, no allocation that outlives the call, no bookkeeping: what ``GraphedModel``
-        captures once and replays for every new prompt (≈ 150 small launches become one graph launch).  The caller
-        re-keys the entry with ``rekey_text``."""
-        context, per_b = self._compute_text(crossattn_emb)
-        self._store_text(st, context, per_b)
-
-    def rekey_text(self, st, crossattn_emb):
-        """Mark cache entry ``st`` as holding the text side of ``crossattn_emb`` at its current version."""
-        key = (crossattn_emb.data_ptr(), crossattn_emb._version, tuple(crossattn_emb.shape), crossattn_emb.dtype)
-        self._text_states.pop(st[0][0], None)
-        self._text_states[key[0]] = (key, crossattn_emb, st[2], st[3], st[4])
         return self._text_states[key[0]]
 
     def _cross_attention(self, i, blk, xn, context, quant_out=False, text_kv=None, kvt=None):
