@@ -30,3 +30,15 @@ def test_bench_prints_one_contract_json_line():
     assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert 0 < r["roofline_attention"]["frac"] < 1
     assert "hipGraph" in r["launch_mode"]
+
+
+def test_bench_two_in_flight_extra_runs_single_threaded():
+    """The opt-in serving-style extra (two videos interleaved step by step from ONE host thread, sampler.rcm_sample_iter): it
+    must finish and report a positive rate beside — never as — the headline value (round 2's two-thread form hung at 14B sizes)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--layers", "2",
+                          "--no-cpu-baseline", "--no-box-calibration", "--two-in-flight"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert isinstance(r["two_videos_in_flight_videos_per_s"], float) and r["two_videos_in_flight_videos_per_s"] > 0
+    assert r["value"] > 0 and "box" not in r
