@@ -109,12 +109,7 @@ template <> struct Mma16<TD_BF16> {
 // room for THREE tile buffers and for explicit fragment prefetch: all 8 K fragments of a tile are requested before the
 // first QK MFMA (the 168-register build reuses one fragment register: ds_read -> wait -> MFMA, eight times), and the V
 // fragments of d-block c+1 are requested before the MFMAs of d-block c.
-// OCC2 == 2 (experiment, TD_TUNE_ATTN_OCC = 3): two workgroups per CU, tiles staged through VGPRs instead of LDS-DMA — the
-// next tile's six 1-KB pieces per wave are plain buffer loads (24 VGPRs in flight during the whole iteration) written to the
-// other LDS buffer with ds_write_b128 right before the iteration's barrier.  Rationale: an LDS-DMA piece costs the SIMD's
-// issue port 60-185 cycles (round-1 mix microbenchmark), six of them ~ 30 % of a tile's issue budget; a buffer load + a
-// ds_write_b128 cost ~ 30.  K fragments are still requested ahead of the QK^T MFMAs; the V fragments are load-use.
-template <bool QK_I8, int PDT, int ODT, bool PV8 = false, int OCC2 = 0, bool STAMP = false>
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false>
 // lut_all / ks_all / qs_all repeat p.lut / p.k_s / p.q_s as __restrict__ kernel arguments: only then are the per-iteration
 // LUT entry and K scale SCALAR loads (s_load, lgkmcnt).  As vector loads they drag an s_waitcnt vmcnt(0) into the loop,
 // which waits for every K/V tile in flight and undoes the fetch-ahead.
@@ -179,8 +174,7 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
   // A K/V tile fetch is a scattered 24-32 KB read (the LUT picks the blocks).  The INT8 kernel keeps THREE tiles in
   // LDS (72 KB, two workgroups per CU) and fetches two iterations ahead; no staging VGPRs, no ds_write.  The LDS
   // image of a DMA piece is lane-linear, so the bank swizzle of the read side is applied to the global address.
-  constexpr bool VSTG = (OCC2 == 2);
-  constexpr int NBUF = (OCC2 == 1) ? 3 : 2;
+  constexpr int NBUF = OCC2 ? 3 : 2;
   constexpr int KPIECES = KT::BYTES / 1024 / 4;  // per wave: 2 (int8 K) or 4 (16-bit K); V^T: 4
   constexpr int VPIECES = PV8 ? 2 : 4;
   constexpr int NPIECES = KPIECES + VPIECES;
@@ -232,36 +226,6 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
                                                voffs[t], vsoff_ + (uint32_t)wb_ * VTB, 0, 0);          \
   }
 #define TWAIT(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory");
-  typedef unsigned int v4u_t __attribute__((ext_vector_type(4)));
-  v4u_t stg[NPIECES];   // VSTG: the next tile's pieces of this wave, in flight during the iteration
-#define VLOAD(kb_)                                                                                     \
-  {                                                                                                    \
-    int wb_ = (kb_);                                                                                   \
-    uint32_t ksoff_ = 0u, vsoff_ = 0u;                                                                 \
-    if (p.kbp > 0) {                                                                                   \
-      const int r_ = (kb_) / p.kbp;                                                                    \
-      wb_ = (kb_) - r_ * p.kbp;                                                                        \
-      ksoff_ = (uint32_t)(r_ * p.k_rs);                                                                \
-      vsoff_ = (uint32_t)(r_ * p.v_rs);                                                                \
-    }                                                                                                  \
-    const int64_t lastrow_ = p.Lk - 1 - (int64_t)(kb_) * 64;                                           \
-    _Pragma("unroll") for (int t = 0; t < KPIECES; ++t) {                                              \
-      int64_t kr_ = krow[t];                                                                           \
-      if (kr_ > lastrow_) kr_ = lastrow_;                                                              \
-      const uint32_t vo_ = (uint32_t)((int64_t)wb_ * 64 + kr_) * K_ROWB + kchunk[t];                   \
-      stg[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, vo_, ksoff_, 0);                          \
-    }                                                                                                  \
-    _Pragma("unroll") for (int t = 0; t < VPIECES; ++t)                                                \
-      stg[KPIECES + t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, voffs[t], vsoff_ + (uint32_t)wb_ * VTB, 0); \
-  }
-#define VSTORE(buf_)                                                                                   \
-  {                                                                                                    \
-    char* base_ = smem + (buf_) * BUF;                                                                 \
-    _Pragma("unroll") for (int t = 0; t < KPIECES; ++t)                                                \
-      *reinterpret_cast<v4u_t*>(base_ + (wave_u + 4 * t) * 1024 + lane * 16) = stg[t];                 \
-    _Pragma("unroll") for (int t = 0; t < VPIECES; ++t)                                                \
-      *reinterpret_cast<v4u_t*>(base_ + KT::BYTES + (wave_u + 4 * t) * 1024 + lane * 16) = stg[KPIECES + t]; \
-  }
 
   v16f oacc[4];
 #pragma unroll
@@ -275,17 +239,12 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
   if constexpr (QK_I8) asm volatile("" : "+v"(magic16));  // loop-invariant C operand of the first MFMA of every chain
 
   // the Q fragments (plain loads) are older than every DMA piece, so the vmcnt waits below cover them too
-  if constexpr (VSTG) {
-    VLOAD(has_lut ? lut[0] : 0)
-    VSTORE(0)
-  } else {
   TISSUE(has_lut ? lut[0] : 0, 0)
   if (NBUF == 3 && nsel > 1) {
     TISSUE(has_lut ? lut[1] : 1, 1)
     if constexpr (NPIECES == 6) TWAIT(6) else TWAIT(8)
   } else {
     TWAIT(0)
-  }
   }
   __syncthreads();
 
@@ -296,7 +255,7 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
     // fetch NBUF-1 tiles ahead into the buffer whose last readers passed the barrier at the end of iteration it-1
     if (it + NBUF - 1 < nsel) {
       const int nb_ = has_lut ? lut[it + NBUF - 1] : it + NBUF - 1;
-      if constexpr (VSTG) VLOAD(nb_) else TISSUE(nb_, (it + NBUF - 1) % NBUF)
+      TISSUE(nb_, (it + NBUF - 1) % NBUF)
     }
     const char* kt = smem + cur * BUF;
     const char* vtile = kt + KT::BYTES;
@@ -429,7 +388,7 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
       pf[ks] = pack8<PDT>(&s[g][8 * t]);
     }
     // ---- O^T += V^T . P^T ----
-    if constexpr (OCC2 == 1) {
+    if constexpr (OCC2) {
       frag16 vfr[2][4];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) vfr[0][ks] = *reinterpret_cast<const frag16*>(vtile + vt_off(li, 2 * ks + hi));
@@ -460,14 +419,10 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
     }
     }
     // tile it+1 must have landed (this wave's pieces; the barrier makes it everyone's); tile it+2 may stay in flight
-    if constexpr (VSTG) {
-      if (it + 1 < nsel) VSTORE((it + 1) % NBUF)   // (the compiler waits for the loads; nobody reads that buffer in this iteration)
-    } else {
     if (NBUF == 3 && it + 2 < nsel) {
       if constexpr (NPIECES == 6) TWAIT(6) else TWAIT(8)
     } else {
       TWAIT(0)
-    }
     }
     __syncthreads();
   }
@@ -575,22 +530,21 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
   }
 }
 
-template <bool QK_I8, int PDT, int ODT, bool PV8 = false, int OCC2 = 0, bool STAMP = false>
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false>
 static int launch_attn(const AttnParams& p_in, hipStream_t st) {
   AttnParams p = p_in;
   p.dbg = nullptr;
   if constexpr (QK_I8 && !PV8 && !OCC2 && !STAMP) {
-    if (td_tuning(TD_TUNE_ATTN_OCC) == 2) return launch_attn<QK_I8, PDT, ODT, PV8, 1>(p, st);
-    if (td_tuning(TD_TUNE_ATTN_OCC) == 3) return launch_attn<QK_I8, PDT, ODT, PV8, 2>(p, st);
+    if (td_tuning(TD_TUNE_ATTN_OCC) == 2) return launch_attn<QK_I8, PDT, ODT, PV8, true>(p, st);
   }
   if constexpr (!PV8 && !OCC2 && !STAMP && ODT == TD_BF16 && (QK_I8 || PDT == TD_BF16)) {
     // profiling instantiations of the two kernels the model runs (bf16 outputs)
-    if (td_tuning(TD_TUNE_ATTN_OCC) == 9) return launch_attn<QK_I8, PDT, ODT, PV8, 0, true>(p, st);
+    if (td_tuning(TD_TUNE_ATTN_OCC) == 9) return launch_attn<QK_I8, PDT, ODT, PV8, false, true>(p, st);
   }
   if constexpr (STAMP) p.dbg = td_dbg_buffer();
   auto kern = attn_kernel<QK_I8, PDT, ODT, PV8, OCC2, STAMP>;
   // two (three: OCC2) tile buffers, and at least the 128 x 272-byte staging area of the epilogue's transpose
-  constexpr int lds_tiles = (OCC2 == 1 ? 3 : 2) * (KTile<QK_I8>::BYTES + (PV8 ? VT8_BYTES : VT_BYTES));
+  constexpr int lds_tiles = (OCC2 ? 3 : 2) * (KTile<QK_I8>::BYTES + (PV8 ? VT8_BYTES : VT_BYTES));
   constexpr int lds = lds_tiles > 128 * 272 ? lds_tiles : 128 * 272;
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, attr_mask);
