@@ -418,3 +418,43 @@ def test_gemm_vt_epilogue_is_gemm_plus_v_transpose(K, m, dim, k, dt, vt_dt):
     assert torch.equal(d[:, :2 * dim], ref[:, :2 * dim])
     assert vt.shape == vt_ref.shape and vt.dtype == vt_dt
     assert torch.equal(vt.view(torch.int16), vt_ref.view(torch.int16))
+
+
+# ---------------------------------------------------------------- small problems: the fused epilogues on the 128x128 kernel
+@pytest.mark.parametrize("m,n,k", [(4096, 1536, 1536), (4000, 1536, 384), (2100, 512, 256), (4096, 1536, 8960)])
+def test_small_problem_gemm_epilogues_match_the_256_tile_kernel(K, m, n, k):
+    """Problems that leave more than half of the CUs without a 256x256 tile (the per-rank shapes of an 8-way sequence split:
+    M = 4096, N = 1536 -> 96 tiles) run the fused epilogues on the 128x128 kernel (csrc/gemm_w8a8.hip: G_RES, G_STATS, G_QOUT).
+    Residual and quantiser epilogues: bit-identical to the 256x256 kernel's (TD_TUNE_GEMM_VARIANT = 4 forces that one);
+    row statistics: the same (mean, rstd) to rounding."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = act_like(m, k, torch.bfloat16, seed=m + k)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(n, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    gate = (torch.randn(1, n, generator=g) * 0.5).to(DEV)
+    x0 = (torch.randn(m, n, generator=g) * 2 + 0.3).to(torch.bfloat16).to(DEV)
+    aq, as_ = K.quant_i8_block128(a.to(DEV))
+    wq, ws = K.quant_i8_block128(w.to(DEV))
+    outs = {}
+    for variant in (4, 0):          # 4: the 256x256 kernel; 0: automatic (-> 128x128 for these shapes)
+        K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
+        try:
+            r = {"plain": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True),
+                 "res": K.gemm_w8a8_residual_(x0.clone(), aq, as_, wq, ws, bias=b, gate=gate),
+                 "res_nogate": K.gemm_w8a8_residual_(x0.clone(), aq, as_, wq, ws, bias=b, gate=None)}
+            r["stats_x"], part = K.gemm_w8a8_stats(aq, as_, wq, ws, b, x=x0.clone(), gate=gate)
+            r["stats"] = K.row_stats_finalize(part, n, 1e-6, pad_cols=K.triton_ln_pad_cols(n))
+            r["stats_y"], part2 = K.gemm_w8a8_stats(aq, as_, wq, ws, b)
+            r["rms"] = K.row_stats_finalize(part2, n, 1e-6, rms=True)
+            if n % 128 == 0:
+                r["q"], r["qs"] = K.gemm_w8a8_quant(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True)
+        finally:
+            K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
+        outs[variant] = r
+    big, small = outs[4], outs[0]
+    for key in ("plain", "res", "res_nogate", "stats_x", "stats_y") + (("q", "qs") if n % 128 == 0 else ()):
+        assert torch.equal(big[key], small[key]), key
+    torch.testing.assert_close(small["stats"], big["stats"], rtol=2e-5, atol=1e-6)
+    torch.testing.assert_close(small["rms"], big["rms"], rtol=2e-6, atol=0)
+    r64 = small["stats_x"].double()
+    torch.testing.assert_close(small["stats"][:, 0].double(), r64.mean(-1), rtol=1e-5, atol=1e-6)

@@ -35,11 +35,25 @@ __device__ __forceinline__ uint32_t g_swz(uint32_t row, uint32_t slot) {
 }
 
 
-template <int ODT, int EPI, bool HAS_BIAS>
+// MODE (the fused epilogues of the 256x256 kernel, gemm_w8a8_fi.hip, for problems too small to fill the chip with 256x256 tiles
+// — the per-rank shapes of an 8-way sequence split: 96 tiles at M = 4096, N = 1536):
+//   G_PLAIN   store the 16-bit result
+//   G_RES     gated residual in place: D = D + cast(cast(y) * cast(gate))   (gate == nullptr: plain add) — bit-identical to the
+//             256x256 kernel's RES epilogue
+//   +G_STATS  (with G_PLAIN or G_RES) per row and 64-column piece (mean, M2) of the stored values -> QS float2 [M, N/64]
+//             (shifted sums as in gemm_w8a8_fi.hip; another summation order: equal to rounding, not bit for bit)
+//   G_QOUT    block-quantise the result for the next W8A8 GEMM: D = int8 [M, ldd], QS = scales [ceil(M/128), ldqs]; the
+//             workgroup's 128x128 tile IS one quantisation block — bit-identical to the 256x256 kernel's QOUT epilogue
+#define G_PLAIN 0
+#define G_RES 1
+#define G_STATS 2
+#define G_QOUT 4
+template <int ODT, int EPI, bool HAS_BIAS, int MODE = G_PLAIN>
 __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
-    int64_t M, int64_t N, int64_t K, int64_t ldd, int tiles_m, int tiles_n, int group_m) {
+    int64_t M, int64_t N, int64_t K, int64_t ldd, int tiles_m, int tiles_n, int group_m,
+    const float* __restrict__ gate = nullptr, float* __restrict__ QS = nullptr, int64_t ldqs = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -139,47 +153,164 @@ __global__ __launch_bounds__(256, 2) void gemm_w8a8_kernel(
   }
 
   // ---- epilogue: lane owns m = ..+li; accumulator quad g4 holds n = ..+8*g4+4*hi+{0..3} ----
+  if constexpr (MODE == G_QOUT) {
+    // the 16-bit results exactly as the plain epilogue would store them (rows / columns outside the matrix: zero,
+    // ops/common/load.hpp:24-47), the block amax, then q = sat_s8(rne(x * (128 / amax))), scale = amax / 128 (quant.hip)
+    uint32_t pk[2][2][4][2];
+    float amax = 1e-8f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool m_ok = (m0 + wm * 64 + i * 32 + li) < M;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          int64_t n = n0 + wn * 64 + j * 32 + 8 * g4 + 4 * hi;
+          const bool ok = m_ok && n < N;
+          float bf[4] = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (HAS_BIAS) {
+            if (n > N - 4) n = N - 4;
+            const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
+            unpack2<ODT>(bb.x, bf[0], bf[1]);
+            unpack2<ODT>(bb.y, bf[2], bf[3]);
+          }
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            uint32_t w = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][4 * g4 + 2 * e], accf[i][j][4 * g4 + 2 * e + 1],
+                                                               bf[2 * e], bf[2 * e + 1]);
+            if (!ok) w = 0u;
+            pk[i][j][g4][e] = w;
+            float x0, x1;
+            unpack2<ODT>(w, x0, x1);
+            amax = fmaxf(amax, fmaxf(fabsf(x0), fabsf(x1)));
+          }
+        }
+    }
+    amax = wave_max(amax);
+    float* red = reinterpret_cast<float*>(smem);   // (the main loop ended on a barrier: the stages are free)
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float mult = 128.0f / amax;  // IEEE division, as quant.hip
+    if (tid == 0) QS[(int64_t)tm * ldqs + tn] = amax / 128.0f;
+    int8_t* Dq = reinterpret_cast<int8_t*>(D);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int64_t m = m0 + wm * 64 + i * 32 + li;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int64_t n = n0 + wn * 64 + j * 32 + 8 * g4 + 4 * hi;
+          if (n >= N) continue;
+          float x[4];
+          unpack2<ODT>(pk[i][j][g4][0], x[0], x[1]);
+          unpack2<ODT>(pk[i][j][g4][1], x[2], x[3]);
+          uint32_t w = 0u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = rintf(x[r] * mult);  // RNE
+            v = fminf(fmaxf(v, -128.0f), 127.0f);
+            w |= ((uint32_t)(int)v & 0xffu) << (8 * r);
+          }
+          *reinterpret_cast<uint32_t*>(Dq + m * ldd + n) = w;
+        }
+    }
+    return;
+  }
+  constexpr bool RES = (MODE & G_RES) != 0, STATS = (MODE & G_STATS) != 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int64_t m = m0 + wm * 64 + i * 32 + li;
-    if (m >= M) continue;
+    const bool m_ok = m < M;
+    float st_s = 0.f, st_q = 0.f, st_c = 0.f;   // STATS: this lane's 32 of the row's 64 values of the wave's piece (shifted by st_c)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         const int64_t n = n0 + wn * 64 + j * 32 + 8 * g4 + 4 * hi;
-        if (n >= N) continue;  // N % 8 == 0 and n % 4 == 0: the quad is all-in or all-out
+        const bool ok = m_ok && n < N;   // N % 8 == 0 and n % 4 == 0: the quad is all-in or all-out
         float bf[4] = {0.f, 0.f, 0.f, 0.f};
         if constexpr (HAS_BIAS) {
-          const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
-          unpack2<ODT>(bb.x, bf[0], bf[1]);
-          unpack2<ODT>(bb.y, bf[2], bf[3]);
+          if (n < N) {
+            const uint2 bb = *reinterpret_cast<const uint2*>(bias + n);
+            unpack2<ODT>(bb.x, bf[0], bf[1]);
+            unpack2<ODT>(bb.y, bf[2], bf[3]);
+          }
         }
         uint32_t ob[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e)
           ob[e] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][4 * g4 + 2 * e], accf[i][j][4 * g4 + 2 * e + 1],
                                                          bf[2 * e], bf[2 * e + 1]);
-        *reinterpret_cast<uint2*>(D + m * ldd + n) = make_uint2(ob[0], ob[1]);
+        if constexpr (RES) {
+          if (ok) {
+            const uint2 xr = *reinterpret_cast<const uint2*>(D + m * ldd + n);
+            float xf[4], yf[4];
+            unpack2<ODT>(xr.x, xf[0], xf[1]); unpack2<ODT>(xr.y, xf[2], xf[3]);
+            unpack2<ODT>(ob[0], yf[0], yf[1]); unpack2<ODT>(ob[1], yf[2], yf[3]);
+            if (gate != nullptr) {
+              const float4 gv = *reinterpret_cast<const float4*>(gate + n);
+              const float g[4] = {round_half<ODT>(gv.x), round_half<ODT>(gv.y), round_half<ODT>(gv.z), round_half<ODT>(gv.w)};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float t = round_half<ODT>(yf[e] * g[e]);    // y * gate -> x.dtype
+                xf[e] = xf[e] + t;                                // x + t    -> x.dtype (rounded at pack)
+              }
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) xf[e] = xf[e] + yf[e];
+            }
+            ob[0] = pack2<ODT>(xf[0], xf[1]);
+            ob[1] = pack2<ODT>(xf[2], xf[3]);
+          }
+        }
+        if constexpr (STATS) {
+          float sv[4];
+          unpack2<ODT>(ob[0], sv[0], sv[1]); unpack2<ODT>(ob[1], sv[2], sv[3]);
+          if (j == 0 && g4 == 0) st_c = __shfl(sv[0], li, 64);   // the piece's first column sits in the hi = 0 lane
+          if (ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = sv[e] - st_c; st_s += d; st_q = fmaf(d, d, st_q); }
+          }
+        }
+        if (ok) *reinterpret_cast<uint2*>(D + m * ldd + n) = make_uint2(ob[0], ob[1]);
+      }
+    }
+    if constexpr (STATS) {
+      st_s += __shfl_xor(st_s, 32, 64); st_q += __shfl_xor(st_q, 32, 64);
+      if (hi == 0 && m_ok && n0 + wn * 64 < N) {
+        const float ds = st_s * (1.0f / 64.0f);
+        reinterpret_cast<float2*>(QS)[m * ldqs + ((n0 + wn * 64) >> 6)] = make_float2(st_c + ds, fmaxf(fmaf(-ds, st_s, st_q), 0.f));
       }
     }
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS>
+template <int ODT, int EPI, bool HAS_BIAS, int MODE = G_PLAIN>
 static int launch_gemm(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                        const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
-                       hipStream_t st) {
-  auto kern = gemm_w8a8_kernel<ODT, EPI, HAS_BIAS>;
+                       hipStream_t st, const float* gate = nullptr, float* qs = nullptr, int64_t ldqs = 0) {
+  auto kern = gemm_w8a8_kernel<ODT, EPI, HAS_BIAS, MODE>;
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), G_LDS_BYTES, attr_mask);
   const int tiles_m = (int)td_cdiv(m, G_BM), tiles_n = (int)td_cdiv(n, G_BN);
   const int group_m = 4;
   const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;
   kern<<<nwg, 256, G_LDS_BYTES, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k,
-                                      ldd, tiles_m, tiles_n, group_m);
+                                      ldd, tiles_m, tiles_n, group_m, gate, qs, ldqs);
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+// Problems that leave more than half of the 256 CUs without a 256x256 tile go to the 128x128 kernel (two workgroups per CU):
+// the per-rank GEMMs of a wide sequence split (M = 4096, N = 1536: 96 tiles).  TD_TUNE_GEMM_VARIANT overrides (1 / 4 / 5).
+static bool td_gemm_small(int64_t m, int64_t n) {
+  const int v = td_tuning(TD_TUNE_GEMM_VARIANT);
+  if (v == 1) return true;
+  if (v != 0) return false;
+  return td_cdiv(m, 256) * td_cdiv(n, 256) <= 128;
 }
 
 // The 256x256 LDS-DMA kernels address the int8 operands through 32-bit buffer offsets (gemm_w8a8_fi.hip: ga / gb, the
@@ -210,7 +341,7 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
   hipStream_t st = (hipStream_t)stream;
   const int variant = td_tuning(TD_TUNE_GEMM_VARIANT);
   // large problems: the fine-interleaved 256x256 LDS-DMA kernel (gemm_w8a8_fi.hip); every variant is bit-identical
-  if (variant == 4 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0)) {
+  if (variant == 4 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0 && !td_gemm_small(m, n))) {
     TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 4 needs ldd %% 8 == 0");
     return td_gemm_w8a8_fi(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
   }
@@ -246,6 +377,16 @@ extern "C" int td_gemm_w8a8_quant(const int8_t* a, const float* a_s, const int8_
              "td_gemm_w8a8_quant: epilogue %d", epilogue);
   TD_REQUIRE_GEMM_EXTENT("td_gemm_w8a8_quant", m, n, k);
   if (m == 0 || n == 0) return TD_OK;
+  if (td_gemm_small(m, n) && n % 128 == 0) {   // the workgroup tile is the quantisation block
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t ldqs = td_cdiv(n, 128);
+#define TD_GQ(ODT_, EPI_)                                                                                                   \
+    return bias ? launch_gemm<ODT_, EPI_, true, G_QOUT>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, nullptr, d_s, ldqs)       \
+                : launch_gemm<ODT_, EPI_, false, G_QOUT>(a, a_s, b, b_s, bias, d_q, m, n, k, n, st, nullptr, d_s, ldqs);
+    if (act_dtype == TD_BF16) { if (epilogue == TD_EPI_GELU_TANH) { TD_GQ(TD_BF16, TD_EPI_GELU_TANH) } else { TD_GQ(TD_BF16, TD_EPI_NONE) } }
+    else { if (epilogue == TD_EPI_GELU_TANH) { TD_GQ(TD_F16, TD_EPI_GELU_TANH) } else { TD_GQ(TD_F16, TD_EPI_NONE) } }
+#undef TD_GQ
+  }
   if (td_tuning(TD_TUNE_GEMM_VARIANT) == 5)
     return td_gemm_w8a8_m32_q(a, a_s, b, b_s, bias, d_q, d_s, act_dtype, epilogue, m, n, k, (hipStream_t)stream);
   return td_gemm_w8a8_fi_q(a, a_s, b, b_s, bias, d_q, d_s, act_dtype, epilogue, m, n, k, (hipStream_t)stream);
@@ -263,6 +404,14 @@ extern "C" int td_gemm_w8a8_residual(const int8_t* a, const float* a_s, const in
   TD_REQUIRE(ldx >= n && ldx % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_residual: bad ldx=%lld", (long long)ldx);
   TD_REQUIRE_GEMM_EXTENT("td_gemm_w8a8_residual", m, n, k);
   if (m == 0 || n == 0) return TD_OK;
+  if (td_gemm_small(m, n)) {
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == TD_BF16)
+      return bias ? launch_gemm<TD_BF16, TD_EPI_NONE, true, G_RES>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, gate)
+                  : launch_gemm<TD_BF16, TD_EPI_NONE, false, G_RES>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, gate);
+    return bias ? launch_gemm<TD_F16, TD_EPI_NONE, true, G_RES>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, gate)
+                : launch_gemm<TD_F16, TD_EPI_NONE, false, G_RES>(a, a_s, b, b_s, bias, x, m, n, k, ldx, st, gate);
+  }
   if (td_tuning(TD_TUNE_GEMM_VARIANT) == 5)
     return td_gemm_w8a8_m32_res(a, a_s, b, b_s, bias, x, gate, dtype, m, n, k, ldx, (hipStream_t)stream);
   return td_gemm_w8a8_fi_res(a, a_s, b, b_s, bias, x, gate, dtype, m, n, k, ldx, (hipStream_t)stream);
@@ -281,6 +430,13 @@ extern "C" int td_gemm_w8a8_stats(const int8_t* a, const float* a_s, const int8_
   TD_REQUIRE(n % 64 == 0 && n > 0 && m > 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8_stats: n=%lld must be a positive multiple of 64", (long long)n);
   TD_REQUIRE(ld >= n && ld % 8 == 0, TD_ERR_INVALID, "td_gemm_w8a8_stats: bad ld=%lld", (long long)ld);
   TD_REQUIRE_GEMM_EXTENT("td_gemm_w8a8_stats", m, n, k);
+  if (td_gemm_small(m, n)) {
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t pieces = n / 64;
+    if (residual)
+      return launch_gemm<TD_BF16, TD_EPI_NONE, true, G_RES | G_STATS>(a, a_s, b, b_s, bias, d_or_x, m, n, k, ld, st, gate, stats_ws, pieces);
+    return launch_gemm<TD_BF16, TD_EPI_NONE, true, G_STATS>(a, a_s, b, b_s, bias, d_or_x, m, n, k, ld, st, nullptr, stats_ws, pieces);
+  }
   return td_gemm_w8a8_fi_stats(a, a_s, b, b_s, bias, d_or_x, gate, residual, m, n, k, ld, stats_ws, (hipStream_t)stream);
 }
 
