@@ -55,13 +55,17 @@ for M in [int(v) for v in args.M.split(",")]:
         "ffn.2 (RES+STATS)": lambda: K.gemm_w8a8_stats(h[0], h[1], w_f2[0], w_f2[1], b[dim], x=x, gate=gate),
     }
     row = {"M": M}
-    for variant, tag in ((4, "tile256"), (0, "auto")):
-        K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
-        tot = 0.0
+    best = {}
+    for rnd in range(2):                 # the two kernels interleaved per operator, best of two rounds (clock ramps)
         for name, fn in ops.items():
-            t = timeit(fn, args.iters)
-            row[f"{name} {tag} us"] = round(t, 1)
-            tot += t
-        row[f"sum {tag} us"] = round(tot, 1)
+            for variant, tag in ((4, "tile256"), (0, "auto")):
+                K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
+                t = timeit(fn, args.iters)
+                key = f"{name} {tag} us"
+                best[key] = min(best.get(key, 1e9), t)
     K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
+    for tag in ("tile256", "auto"):
+        for name in ops:
+            row[f"{name} {tag} us"] = round(best[f"{name} {tag} us"], 1)
+        row[f"sum {tag} us"] = round(sum(best[f"{name} {tag} us"] for name in ops), 1)
     print(json.dumps(row), flush=True)
