@@ -150,13 +150,16 @@ extern "C" int td_patch_embed(const void* x, int64_t c1, const void* x2, int64_t
 // head: out[l, j] = sum_d hn[l, d] W[j, d] + bias[j] in fp32 (v_mfma_f32_32x32x2_f32, transposed: A = W rows, B = tokens),
 // hn[l, d] = float(cast((x - mean) * rstd)) * (1 + scale[d]) + shift[d]  (wan2pt1.py:451-453).
 // Workgroup = 64 tokens x P (<= 64) outputs; phase 1: row statistics (one wave per 16 rows, two passes over the row in
-// registers); phase 2: K chunks of 128 through LDS, 4 waves as 2 (token halves) x 2 (output halves).
+// registers, up to four rows in flight); phase 2: K chunks of 64 through LDS, 4 waves as 2 (token halves) x 2 (output halves).
+// Measured 141 us at L = 32760, dim 1536 (profiles/NOTES_r03.md): 0.17 % of a video, the chunk size (128 or 64), the LDS
+// read width and the rows in flight in phase 1 all left it within 3 % — the 512-workgroup grid is two per CU whatever the
+// LDS allows, and each chunk is a load -> barrier -> MFMA -> barrier chain with nothing to overlap it.
 // ------------------------------------------------------------------------------------------------------------------
-#define HD_KC 128
-#define HD_KS 132   // LDS row stride in words (16-byte aligned rows; 132 % 32 = 4: eight rows cover the 32 banks with 16 B each)
-// Within a row of a chunk the 128 k are stored EVEN k first, then ODD k (position of k = (k & 1) * 64 + k / 2): the fp32 MFMA
+#define HD_KC 64
+#define HD_KS 68    // LDS row stride in words (16-byte aligned rows; 68 % 32 = 4: eight rows cover the 32 banks with 16 B each)
+// Within a row of a chunk the k are stored EVEN k first, then ODD k (position of k = (k & 1) * HD_KC/2 + k / 2): the fp32 MFMA
 // 32x32x2 gives lane (row, hi) the operand k = kk + hi of step kk, so the operands of four consecutive steps kk = 8m .. 8m+6
-// are the 16 contiguous bytes at hi * 64 + 4m — one ds_read_b128 per operand and four MFMAs instead of one ds_read_b32 each.
+// are the 16 contiguous bytes at hi * HD_KC/2 + 4m — one ds_read_b128 per operand and four MFMAs instead of one ds_read_b32 each.
 
 template <int DT, int NV>
 __global__ __launch_bounds__(256) void head_kernel(const uint16_t* __restrict__ x, const float* __restrict__ scale,
@@ -172,38 +175,45 @@ __global__ __launch_bounds__(256) void head_kernel(const uint16_t* __restrict__ 
   const int b = blockIdx.x / tiles_per_batch, tile = blockIdx.x % tiles_per_batch;
   const int64_t lr0 = (int64_t)tile * 64;
   const uint16_t* xb = x + (int64_t)b * rows * dim;
-  // ---- phase 1: LayerNorm statistics of 64 rows (the arithmetic of norm_rows_kernel<MODE 1>, norm.hip) ----
-  for (int rr = 0; rr < 16; ++rr) {
-    const int row = wave * 16 + rr;
-    int64_t lr = lr0 + row;
-    if (lr >= rows) lr = rows - 1;
-    float f[NV][8];
-    float sum = 0.f;
+  // ---- phase 1: LayerNorm statistics of 64 rows (the arithmetic of norm_rows_kernel<MODE 1>, norm.hip), R rows of a wave in
+  //      flight together (a row is one 3-10 KB read: one at a time the wave only waits) ----
+  constexpr int R = NV <= 4 ? 4 : (NV <= 10 ? 2 : 1);
+  for (int rr = 0; rr < 16; rr += R) {
+    float f[R][NV][8];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int col = (v * 64 + lane) * 8;
-      if (col < dim) unpack8<DT>(*reinterpret_cast<const uint4*>(xb + lr * dim + col), f[v]);
-      else {
+    for (int r = 0; r < R; ++r) {
+      int64_t lr = lr0 + wave * 16 + rr + r;
+      if (lr >= rows) lr = rows - 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) f[v][j] = 0.f;
+      for (int v = 0; v < NV; ++v) {
+        const int col = (v * 64 + lane) * 8;
+        if (col < dim) unpack8<DT>(*reinterpret_cast<const uint4*>(xb + lr * dim + col), f[r][v]);
+        else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f[r][v][j] = 0.f;
+        }
       }
     }
 #pragma unroll
-    for (int v = 0; v < NV; ++v)
+    for (int r = 0; r < R; ++r) {
+      float sum = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sum += f[v][j];
-    const float mean = wave_sum(sum) / (float)dim;
-    float sq = 0.f;
+      for (int v = 0; v < NV; ++v)
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int col = (v * 64 + lane) * 8;
-      if (col < dim) {
+        for (int j = 0; j < 8; ++j) sum += f[r][v][j];
+      const float mean = wave_sum(sum) / (float)dim;
+      float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = f[v][j] - mean; sq += d * d; }
+      for (int v = 0; v < NV; ++v) {
+        const int col = (v * 64 + lane) * 8;
+        if (col < dim) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float d = f[r][v][j] - mean; sq += d * d; }
+        }
       }
+      const float var = wave_sum(sq) / (float)dim;
+      if (lane == 0) st_s[wave * 16 + rr + r] = make_float2(mean, 1.0f / sqrtf(var + eps));
     }
-    const float var = wave_sum(sq) / (float)dim;
-    if (lane == 0) st_s[row] = make_float2(mean, 1.0f / sqrtf(var + eps));
   }
   __syncthreads();
   // ---- phase 2 ----
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256) void head_kernel(const uint16_t* __restrict__ 
         for (int j = 0; j < 8; ++j) hv[j] = 0.f;
       }
       *reinterpret_cast<float4*>(hn_s + row * HD_KS + c8 * 4) = make_float4(hv[0], hv[2], hv[4], hv[6]);        // even k
-      *reinterpret_cast<float4*>(hn_s + row * HD_KS + 64 + c8 * 4) = make_float4(hv[1], hv[3], hv[5], hv[7]);   // odd k
+      *reinterpret_cast<float4*>(hn_s + row * HD_KS + HD_KC / 2 + c8 * 4) = make_float4(hv[1], hv[3], hv[5], hv[7]);   // odd k
     }
     // W chunk: P rows x 128 columns (rows >= P: zero)
     for (int q = tid; q < 64 * (HD_KC / 4); q += 256) {
@@ -249,13 +259,13 @@ __global__ __launch_bounds__(256) void head_kernel(const uint16_t* __restrict__ 
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < P && col < dim) v = *reinterpret_cast<const float4*>(w + (int64_t)row * dim + col);
       *reinterpret_cast<float2*>(w_s + row * HD_KS + c4 * 2) = make_float2(v.x, v.z);
-      *reinterpret_cast<float2*>(w_s + row * HD_KS + 64 + c4 * 2) = make_float2(v.y, v.w);
+      *reinterpret_cast<float2*>(w_s + row * HD_KS + HD_KC / 2 + c4 * 2) = make_float2(v.y, v.w);
     }
     __syncthreads();
 #pragma unroll 4
     for (int m4 = 0; m4 < HD_KC / 8; ++m4) {
-      const float4 a = *reinterpret_cast<const float4*>(w_s + (jh * 32 + li) * HD_KS + hi * 64 + 4 * m4);
-      const float4 bq = *reinterpret_cast<const float4*>(hn_s + (tg * 32 + li) * HD_KS + hi * 64 + 4 * m4);
+      const float4 a = *reinterpret_cast<const float4*>(w_s + (jh * 32 + li) * HD_KS + hi * (HD_KC / 2) + 4 * m4);
+      const float4 bq = *reinterpret_cast<const float4*>(hn_s + (tg * 32 + li) * HD_KS + hi * (HD_KC / 2) + 4 * m4);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, acc, 0, 0, 0);
