@@ -84,8 +84,11 @@ typedef int v8i_t __attribute__((ext_vector_type(8)));
 // in e4m3's uniform relative grid a value lands.
 #define PV8_TAU 1.0f
 #define PV8_LOG2C 7.8041310f   // log2(447 / 2)
-#define A_MAGIC_I 0x4B400000
-#define A_MAGIC_F 12582912.0f
+// INT8 QK chains start from the INLINE constant 1/(2 pi) = 0x3E22F983 as the MFMA's C operand (no 16-register constant):
+// |sum| <= 128 * 127 * 127 < 0x22F983 keeps 0x3E22F983 + sum inside the binade [0.125, 0.25), whose ulp is 2^-26 — the int32
+// result read as fp32 is A_INV2PI_F + sum * 2^-26 ("raw"), monotone in the score.
+#define A_INV2PI_F 0.15915494309189532f
+#define A_QK_MFMA0(acc_, a_, b_) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0.15915494" : "=&v"(acc_) : "v"(a_), "v"(b_));
 __device__ __forceinline__ uint32_t vt_off(uint32_t row, uint32_t slot) {
   return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
 }
@@ -233,10 +236,6 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
   float m_run = -INFINITY, l_part = 0.f;
-  v16i magic16;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) magic16[r] = A_MAGIC_I;
-  if constexpr (QK_I8) asm volatile("" : "+v"(magic16));  // loop-invariant C operand of the first MFMA of every chain
 
   // the Q fragments (plain loads) are older than every DMA piece, so the vmcnt waits below cover them too
   TISSUE(has_lut ? lut[0] : 0, 0)
@@ -261,17 +260,17 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
     const char* vtile = kt + KT::BYTES;
 
     // ---- S^T = K . Q^T : two 32-key groups ----
-    // INT8 path: every 4-MFMA chain starts from C = 0x4B400000 (1.5*2^23): |sum| <= 128*127*128 < 2^22, so the int32
-    // result reinterpreted as fp32 IS 12582912 + sum — "raw".  raw is monotone in the score, so the row max is taken on
-    // raw, and the softmax argument (sum*mult - m) is ONE fma per element: fma(raw, mult, -(12582912*mult + m)).
-    // The folded constant is ~2e3 with an ulp of ~1e-4 (log2 domain): a common factor per (row, K block) of relative
+    // INT8 path: every 4-MFMA chain starts from C = the inline constant 1/(2 pi) (A_INV2PI_F above), so the int32 result
+    // reinterpreted as fp32 IS A_INV2PI_F + sum * 2^-26 — "raw".  raw is monotone in the score, so the row max is taken on
+    // raw, and the softmax argument (sum*mult - m) is ONE fma per element: fma(raw, mult * 2^26, -(A_INV2PI_F * mult * 2^26 + m)).
+    // The folded constant is ~1e3 with an ulp of ~1e-4 (log2 domain): a common factor per (row, K block) of relative
     // size < 1e-4, below the fp16 rounding of P.  No v_cvt, no separate scale multiply, no subtract.
     float s[2][16];
     float mult = p.scale_log2;
     if constexpr (QK_I8) {
       int64_t ksi = (int64_t)h * p.kb_alloc + kb;
       if (p.kbp > 0) { const int r_ = kb / p.kbp; ksi = (int64_t)r_ * p.ks_rs + (int64_t)h * p.kbp + (kb - r_ * p.kbp); }
-      mult = (qs * ks_all[ksi]) * p.scale_log2;
+      mult = ((qs * ks_all[ksi]) * p.scale_log2) * 67108864.0f;   // x 2^26: raw carries the sum in units of 2^-26
       if constexpr (OCC2) {
         v4i kfr[2][4];
 #pragma unroll
@@ -281,11 +280,12 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
         __builtin_amdgcn_sched_barrier(0);   // all eight reads are in flight before the first MFMA
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          v16i acc = magic16;
+          v16i acc;
 #pragma unroll
           for (int kc = 0; kc < 4; ++kc) {
             v4i qv; qv[0] = qf[kc].x; qv[1] = qf[kc].y; qv[2] = qf[kc].z; qv[3] = qf[kc].w;
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kfr[g][kc], qv, acc, 0, 0, 0);
+            if (kc == 0) A_QK_MFMA0(acc, kfr[g][0], qv)
+            else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kfr[g][kc], qv, acc, 0, 0, 0);
           }
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[g][r] = __int_as_float(acc[r]);
@@ -293,12 +293,13 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
       } else {
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
-        v16i acc = magic16;
+        v16i acc;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
           const v4i kf = *reinterpret_cast<const v4i*>(kt + KT::off(32 * g + li, 2 * kc + hi));
           v4i qv; qv[0] = qf[kc].x; qv[1] = qf[kc].y; qv[2] = qf[kc].z; qv[3] = qf[kc].w;
-          acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qv, acc, 0, 0, 0);
+          if (kc == 0) A_QK_MFMA0(acc, kf, qv)
+          else acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf, qv, acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[g][r] = __int_as_float(acc[r]);
@@ -336,8 +337,11 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
     for (int g = 0; g < 2; ++g)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[g][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    constexpr float OFFS = QK_I8 ? A_MAGIC_F : 0.0f;
+    {   // the other half-wave's maximum of the same q row: v_permlane32_swap (VALU) instead of a trip through the LDS crossbar
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    constexpr float OFFS = QK_I8 ? A_INV2PI_F : 0.0f;
     mx = (mx - OFFS) * mult;  // the scaled row max of this block (exact subtraction)
     // lazy running max: the reference point of the exponentials only moves when the row max grows by more than 2^8
     // — softmax is invariant to it as long as numerator and denominator use the same one; P stays <= 256 (fp16-safe)
@@ -530,12 +534,345 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Q64 build of the INT8-QK / FP16-PV kernel (TD_TUNE_ATTN_OCC = 3): the same workgroup (128 Q rows, 4 waves, the same tiles,
+// DMA pieces and epilogue) with the waves arranged 2 (Q halves of 64 rows) x 2 (key halves of 32 keys) instead of 4 x 32 rows:
+// a wave's K fragment (32 keys) and V^T fragments (32 keys) each feed TWO MFMAs (its two 32-row Q blocks), so a tile costs a
+// wave 12 ds_read_b128 instead of 24 for the same 24 MFMAs, and the two Q blocks are two independent MFMA chains.  The price:
+// 128 accumulator registers (two workgroups per CU, three tile buffers), a running max / row sum per key half — every wave
+// is a split-K flash-attention stream over its half of the keys — and one exchange through LDS at the end: wave (wq, wk)
+// hands the partial of Q block 1 - wk to wave (wq, 1 - wk) and finishes Q block wk, i.e. the 32 rows 64 wq + 32 wk + lane
+// that wave 2 wq + wk of the 4 x 32 kernel owns, so the epilogue below is that kernel's.
+// The QK chains start from the INLINE constant 1/(2 pi) = 0x3E22F983 (gemm_w8a8_m32.hip): |sum| <= 128 * 127 * 127 < 0x22F983
+// keeps 0x3E22F983 + sum inside the binade [0.125, 0.25) (ulp 2^-26): the int32 result read as fp32 is M' + sum * 2^-26,
+// monotone in the score, and the softmax argument is one fma(raw, mult * 2^26, -(M' * mult * 2^26 + m)) as in the 4 x 32 kernel,
+// without its 16-register C operand.
+// ------------------------------------------------------------------------------------------------------------------
+template <int ODT>
+__device__ __forceinline__ void attn_tile_out(const AttnParams& p, char* smem, int h, int qb, int tid, int lane, int wave) {
+  // staged [128 tokens][272 B] tile in LDS -> global: 16-byte row-contiguous stores, or the 128x128 block quantiser
+  constexpr int SROW = 272;
+  uint4 tv[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
+    tv[it] = *reinterpret_cast<const uint4*>(smem + row * SROW + ch * 16);
+  }
+  if (p.q_out == nullptr) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
+      const int64_t tok = (int64_t)qb * 128 + row;
+      if (tok < p.L) *reinterpret_cast<uint4*>(p.o + (int64_t)h * p.o_stride_h + tok * p.o_stride_l + ch * 8) = tv[it];
+    }
+    return;
+  }
+  uint32_t mxb = 0u;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const uint32_t w[4] = {tv[it].x, tv[it].y, tv[it].z, tv[it].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t a = w[e] & 0x7fff7fffu;
+      asm("v_pk_max_u16 %0, %0, %1" : "+v"(mxb) : "v"(a));
+    }
+  }
+  uint32_t m16 = max(mxb & 0xffffu, mxb >> 16);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m16 = max(m16, (uint32_t)__shfl_xor((int)m16, o, 64));
+  __syncthreads();
+  uint32_t* red = reinterpret_cast<uint32_t*>(smem);
+  if (lane == 0) red[wave] = m16;
+  __syncthreads();
+  m16 = max(max(red[0], red[1]), max(red[2], red[3]));
+  const float amax = fmaxf(half_bits_to_f32<ODT>(m16), 1e-8f);
+  const float mult = 128.0f / amax;
+  if (tid == 0) p.q_scale[(int64_t)qb * p.H + h] = amax / 128.0f;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
+    const int64_t tok = (int64_t)qb * 128 + row;
+    if (tok >= p.L) continue;
+    float f[8];
+    unpack8<ODT>(tv[it], f);
+    uint32_t wd[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = rintf(f[j] * mult);
+      t = fminf(fmaxf(t, -128.0f), 127.0f);
+      wd[j >> 2] |= ((uint32_t)(int)t & 0xffu) << (8 * (j & 3));
+    }
+    *reinterpret_cast<uint2*>(p.q_out + tok * p.q_ld + (int64_t)h * 128 + ch * 8) = make_uint2(wd[0], wd[1]);
+  }
+}
+
+template <int ODT>
+__global__ __launch_bounds__(256, 2) void attn_i8_q64_kernel(AttnParams p, const int32_t* __restrict__ lut_all,
+                                                             const float* __restrict__ ks_all,
+                                                             const float* __restrict__ qs_all) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef KTile<true> KT;
+  constexpr int VTB = VT_BYTES;
+  constexpr int BUF = KT::BYTES + VTB;
+  constexpr int NBUF = 3;
+  typedef typename Mma16<TD_F16>::frag frag16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wq = wave_u & 1, wk = wave_u >> 1;
+  const uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int h = vid / p.Qb, qb = vid % p.Qb;
+
+  // ---- Q fragments of the wave's two 32-row blocks (B operands) ----
+  uint4 qf[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    int64_t qrow = (int64_t)qb * 128 + wq * 64 + j * 32 + li;
+    if (qrow >= p.L) qrow = p.L - 1;
+    const char* qp = (const char*)p.q + ((int64_t)h * p.L + qrow) * 128;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) qf[j][kc] = *reinterpret_cast<const uint4*>(qp + kc * 32 + hi * 16);
+  }
+
+  const bool has_lut = lut_all != nullptr;
+  const int32_t* __restrict__ lut = lut_all + ((int64_t)h * p.Qb + qb) * (has_lut ? p.nsel : 0);
+  const int nsel = has_lut ? p.nsel : p.Kb;
+  const float qs = qs_all[(int64_t)h * p.Qb + qb];
+
+  // ---- tile staging: exactly the 4 x 32 kernel's (TISSUE) ----
+  constexpr int KPIECES = 2, VPIECES = 4;
+  constexpr uint32_t K_ROWB = 128u;
+  const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.k + (int64_t)h * p.k_rows_alloc * KT::ROWB), 0, 0x7fffffff, 0x00020000);
+  const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)((const char*)p.vt + (int64_t)h * p.kb_alloc * VTB), 0, 0x7fffffff, 0x00020000);
+  int krow[KPIECES];
+  uint32_t kchunk[KPIECES], voffs[4];
+#pragma unroll
+  for (int t = 0; t < KPIECES; ++t) {
+    const int c = wave_u + 4 * t;
+    krow[t] = 8 * c + (lane >> 3);
+    kchunk[t] = (uint32_t)(((lane & 7) ^ ((krow[t] >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int row = 8 * (wave_u + 4 * t) + (lane >> 3);
+    voffs[t] = (uint32_t)(row * 128 + (((lane & 7) ^ ((row >> 1) & 7)) * 16));
+  }
+
+  v16f oacc[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[j][c][r] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_part[2] = {0.f, 0.f};
+
+  TISSUE(has_lut ? lut[0] : 0, 0)
+  if (nsel > 1) {
+    TISSUE(has_lut ? lut[1] : 1, 1)
+    TWAIT(6)
+  } else {
+    TWAIT(0)
+  }
+  __syncthreads();
+
+  for (int it = 0; it < nsel; ++it) {
+    const int cur = it % NBUF;
+    const int kb = has_lut ? lut[it] : it;
+    if (it + 2 < nsel) {
+      const int nb_ = has_lut ? lut[it + 2] : it + 2;
+      TISSUE(nb_, (it + 2) % NBUF)
+    }
+    const char* kt = smem + cur * BUF;
+    const char* vtile = kt + KT::BYTES;
+    // a key half that lies entirely past Lk (second half of a short last block) contributes nothing
+    if ((int64_t)kb * 64 + 32 * wk < p.Lk) {
+      int64_t ksi = (int64_t)h * p.kb_alloc + kb;
+      if (p.kbp > 0) { const int r_ = kb / p.kbp; ksi = (int64_t)r_ * p.ks_rs + (int64_t)h * p.kbp + (kb - r_ * p.kbp); }
+      const float mult = ((qs * ks_all[ksi]) * p.scale_log2) * 67108864.0f;
+
+      // ---- S^T[32 keys x 64 q] = K_half . Q^T : two chains of four MFMAs sharing every K fragment ----
+      v4i kf[4];
+#pragma unroll
+      for (int kc = 0; kc < 4; ++kc) kf[kc] = *reinterpret_cast<const v4i*>(kt + KT::off(32 * wk + li, 2 * kc + hi));
+      float s[2][16];
+      {
+        v16i acc[2];
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            v4i qv; qv[0] = qf[j][kc].x; qv[1] = qf[j][kc].y; qv[2] = qf[j][kc].z; qv[3] = qf[j][kc].w;
+            if (kc == 0) A_QK_MFMA0(acc[j], kf[0], qv)   // (a splat vector C operand of the builtin is materialised in 16 registers)
+            else
+              acc[j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(kf[kc], qv, acc[j], 0, 0, 0);
+          }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[j][r] = __int_as_float(acc[j][r]);
+      }
+      if ((int64_t)(kb + 1) * 64 > p.Lk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t key = (int64_t)kb * 64 + 32 * wk + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= p.Lk) s[j][r] = -INFINITY;
+          }
+      }
+      // ---- per Q block: online softmax over this wave's 32 keys (lazy running max), then O^T += V^T_half . P^T ----
+      uint4 pf[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float mx = s[j][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[j][r]);
+        {   // the other half-wave's maximum of the same q row: v_permlane32_swap (VALU) instead of a trip through the LDS crossbar
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+          mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        mx = (mx - A_INV2PI_F) * mult;
+        const float m_new = (mx > m_run[j] + p.tau) ? mx : m_run[j];
+        const float alpha = __builtin_amdgcn_exp2f(m_run[j] - m_new);
+        m_run[j] = m_new;
+        const float cc = fmaf(-A_INV2PI_F, mult, -m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[j][r] = __builtin_amdgcn_exp2f(fmaf(s[j][r], mult, cc));
+          psum += s[j][r];
+        }
+        l_part[j] = l_part[j] * alpha + psum;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[j][c][r] *= alpha;
+        }
+        pf[j][0] = pack8<TD_F16>(&s[j][0]);
+        pf[j][1] = pack8<TD_F16>(&s[j][8]);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const frag16 vf = *reinterpret_cast<const frag16*>(vtile + vt_off(32 * c + li, 2 * (2 * wk + t) + hi));
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            frag16 pv = *reinterpret_cast<const frag16*>(&pf[j][t]);
+            oacc[j][c] = Mma16<TD_F16>::mma(vf, pv, oacc[j][c]);
+          }
+        }
+    }
+    if (it + 2 < nsel) {
+      TWAIT(6)
+    } else {
+      TWAIT(0)
+    }
+    __syncthreads();
+  }
+
+  // ---- merge the two key halves: wave (wq, wk) finishes Q block wk, its partner (wave ^ 2) the other ----
+  float4* xbuf = reinterpret_cast<float4*>(smem);           // per wave: 16 x 64 float4 + 64 float2
+  float2* xml = reinterpret_cast<float2*>(smem + 4 * 16384);
+  v16f ok[4];
+  float m_s, l_s;
+#define Q64_GIVE(jg_)                                                                              \
+  {                                                                                                \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                  \
+      _Pragma("unroll") for (int g4 = 0; g4 < 4; ++g4)                                             \
+        xbuf[(wave_u * 16 + c * 4 + g4) * 64 + lane] = make_float4(oacc[jg_][c][4 * g4], oacc[jg_][c][4 * g4 + 1], \
+                                                                  oacc[jg_][c][4 * g4 + 2], oacc[jg_][c][4 * g4 + 3]); \
+    xml[wave_u * 64 + lane] = make_float2(m_run[jg_], l_part[jg_]);                                \
+  }
+#define Q64_KEEP(jk_)                                                                              \
+  {                                                                                                \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) ok[c] = oacc[jk_][c];                            \
+    m_s = m_run[jk_]; l_s = l_part[jk_];                                                           \
+  }
+  if (wk == 0) { Q64_GIVE(1) Q64_KEEP(0) } else { Q64_GIVE(0) Q64_KEEP(1) }
+  __syncthreads();
+  float l_part1;
+  {
+    const int pw = wave_u ^ 2;
+    const float2 ml = xml[pw * 64 + lane];
+    const float m = fmaxf(m_s, ml.x);
+    const float a_s = __builtin_amdgcn_exp2f(m_s - m), a_o = __builtin_amdgcn_exp2f(ml.x - m);
+    l_part1 = l_s * a_s + ml.y * a_o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 o4 = xbuf[(pw * 16 + c * 4 + g4) * 64 + lane];
+        ok[c][4 * g4] = ok[c][4 * g4] * a_s + o4.x * a_o;
+        ok[c][4 * g4 + 1] = ok[c][4 * g4 + 1] * a_s + o4.y * a_o;
+        ok[c][4 * g4 + 2] = ok[c][4 * g4 + 2] * a_s + o4.z * a_o;
+        ok[c][4 * g4 + 3] = ok[c][4 * g4 + 3] * a_s + o4.w * a_o;
+      }
+  }
+  __syncthreads();   // every partial has been read: the staging area may overwrite the exchange area
+
+  // ---- epilogue of the 4 x 32 kernel with wave -> 2 wq + wk ----
+  const int wv = 2 * wq + wk;
+  const bool q_ok = (int64_t)qb * 128 + wv * 32 + li < p.L;
+  const float l_tot = l_part1 + __shfl_xor(l_part1, 32, 64);
+  const float inv = 1.0f / l_tot;
+  uint2 addv[16];
+  if (p.add_t) {
+    const uint2* ap = reinterpret_cast<const uint2*>(p.add_t) + (((int64_t)h * p.Qb + qb) * 4 + wv) * 16 * 64 + lane;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) addv[i] = ap[i * 64];
+  }
+  {
+    char* srow = smem + (wv * 32 + li) * 272;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float e0 = ok[c][4 * g4] * inv, e1 = ok[c][4 * g4 + 1] * inv, e2 = ok[c][4 * g4 + 2] * inv, e3 = ok[c][4 * g4 + 3] * inv;
+        uint32_t w0 = pack2<ODT>(e0, e1);
+        uint32_t w1 = pack2<ODT>(e2, e3);
+        if (p.add_t) {
+          float a0, a1, a2, a3, b0, b1, b2, b3;
+          unpack2<ODT>(w0, a0, a1); unpack2<ODT>(w1, a2, a3);
+          unpack2<ODT>(addv[c * 4 + g4].x, b0, b1); unpack2<ODT>(addv[c * 4 + g4].y, b2, b3);
+          w0 = pack2<ODT>(a0 + b0, a1 + b1);
+          w1 = pack2<ODT>(a2 + b2, a3 + b3);
+        }
+        if (!q_ok) { w0 = 0u; w1 = 0u; }
+        *reinterpret_cast<uint2*>(srow + (32 * c + 8 * g4 + 4 * hi) * 2) = make_uint2(w0, w1);
+      }
+  }
+  __syncthreads();
+  attn_tile_out<ODT>(p, smem, h, qb, tid, lane, wave_u);
+}
+
+template <int ODT>
+static int launch_attn_q64(const AttnParams& p_in, hipStream_t st) {
+  AttnParams p = p_in;
+  p.dbg = nullptr;
+  auto kern = attn_i8_q64_kernel<ODT>;
+  constexpr int lds = 3 * (KTile<true>::BYTES + VT_BYTES);   // three tile buffers; also holds the 66-KB exchange area
+  static_assert(lds >= 4 * 16384 + 4 * 512, "exchange area");
+  static std::atomic<uint64_t> attr_mask{0};
+  td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, attr_mask);
+  const unsigned nwg = (unsigned)p.H * (unsigned)p.Qb;
+  kern<<<nwg, 256, lds, st>>>(p, p.lut, p.k_s, p.q_s);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
 template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false>
 static int launch_attn(const AttnParams& p_in, hipStream_t st) {
   AttnParams p = p_in;
   p.dbg = nullptr;
   if constexpr (QK_I8 && !PV8 && !OCC2 && !STAMP) {
     if (td_tuning(TD_TUNE_ATTN_OCC) == 2) return launch_attn<QK_I8, PDT, ODT, PV8, true>(p, st);
+    if (td_tuning(TD_TUNE_ATTN_OCC) == 3) return launch_attn_q64<ODT>(p, st);
   }
   if constexpr (!PV8 && !OCC2 && !STAMP && ODT == TD_BF16 && (QK_I8 || PDT == TD_BF16)) {
     // profiling instantiations of the two kernels the model runs (bf16 outputs)
