@@ -89,6 +89,21 @@ int td_head(const void* x, int dtype, const float* scale, const float* shift, co
             float* out, int unpatchify, int64_t B, int64_t rows, int64_t dim, int64_t out_dim, int64_t T, int64_t Hh,
             int64_t Ww, int64_t row0, td_stream_t stream);
 
+/* ---- f4: the convolutions of the Wan2.1 VAE decoder (csrc/vae_conv.hip; rcm/tokenizers/wan2pt1.py:37-55, 83-131, 177-209) ----
+ * td_vae_conv: y = conv(x) + bias (+ res) on CHANNELS-LAST bf16 activations as one implicit GEMM on the bf16 matrix pipe.
+ *   x [B, Ti, Hi, Wi, Ci] (batch stride in elements; Ci % 32 == 0), w [Co, kt*kh*kw*Ci] with K ordered (dt, dh, dw, c),
+ *   bias [Co] or NULL, res like y or NULL; causal in time (kt - 1 zero frames on the left, CausalConv3d), symmetric
+ *   zero padding in space; up2 != 0: nearest x2 up-sampling of H and W folded into the gather (Resample's
+ *   Upsample + Conv2d, y is [B, Ti, 2Hi, 2Wi, Co]); interleave != 0: the time up-sampler's output mapping — channel n of
+ *   frame t lands in frame 2t + n / (Co/2), channel n % (Co/2) (y is [B, 2Ti, Hi, Wi, Co/2]).  fp32 accumulate; bias added
+ *   in fp32, rounded to bf16, residual added in bf16 (the reference's rounding points).
+ * td_vae_chan_rms: RMS_norm over the channel axis of channels-last rows [rows, C] (C % 8 == 0, <= 512), optional SiLU,
+ *   with every intermediate rounded to bf16 as the reference's bf16 path does (wan2pt1.py:69-70). */
+int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w, const void* bias, const void* res, void* y,
+                int64_t y_batch_stride, int B, int Ti, int Hi, int Wi, int Ci, int Co, int kt, int kh, int kw, int up2,
+                int interleave, td_stream_t stream);
+int td_vae_chan_rms(const void* x, const void* gamma, void* y, int64_t rows, int C, int silu, td_stream_t stream);
+
 /* time embedding (wan2pt1.py:144-153, 671-674) and the AdaLN vectors of all blocks:
  * td_time_sinusoid: t [B] (`dtype`, the bf16-rounded timesteps) -> out f32 [B, freq_dim] = cat(cos, sin)(t * 10000^(-j/half)), fp64;
  * td_gemv_f32: out f32 [B, N] = act(x f32 [B, K]) @ float(w [N, K])^T + float(bias [N]), act = SiLU when silu_input

@@ -114,6 +114,49 @@ def load(which: str = "wan2pt1"):
     return mod
 
 
+def load_aux(which: str):
+    """The reference's VAE (``"tokenizers.wan2pt1"``: rcm/tokenizers/wan2pt1.py) or umT5 encoder (``"utils.umt5"``:
+    rcm/utils/umt5.py), unmodified, for the f4 pins.  Extra shims, none touching a reference file: ``sync_model_states``,
+    ``easy_io`` and ``misc`` of the absent imaginaire package and the absent ``ftfy`` (text cleaning only) as stubs;
+    ``torch.cuda.current_device`` answers 0 while umt5.py is imported (a default ARGUMENT calls it, umt5.py:484)."""
+    key = "aux:" + which
+    if key in _loaded:
+        return _loaded[key]
+    if not available():
+        raise RuntimeError(f"reference not present at {REF_ROOT}")
+    import torch
+
+    _stub_modules()
+    dist = sys.modules["imaginaire.utils.distributed"]
+    dist.sync_model_states = lambda *a, **k: None
+    dist.is_rank0 = lambda *a, **k: True
+    for name in ("easy_io", "misc"):
+        full = "imaginaire.utils." + name
+        if full not in sys.modules:
+            m = types.ModuleType(full)
+            m.__path__ = []
+            sys.modules[full] = m
+            setattr(sys.modules["imaginaire.utils"], name, m)
+    eio = types.ModuleType("imaginaire.utils.easy_io.easy_io")
+    eio.load = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("no checkpoints in the pins"))
+    sys.modules["imaginaire.utils.easy_io"].easy_io = eio
+    sys.modules["imaginaire.utils.easy_io.easy_io"] = eio
+    if "ftfy" not in sys.modules:
+        ft = types.ModuleType("ftfy")
+        ft.fix_text = lambda t: t
+        sys.modules["ftfy"] = ft
+    if REF_PKG not in sys.path:
+        sys.path.insert(0, REF_PKG)
+    cur = torch.cuda.current_device
+    torch.cuda.current_device = lambda: 0
+    try:
+        mod = importlib.import_module("rcm." + which)
+    finally:
+        torch.cuda.current_device = cur
+    _loaded[key] = mod
+    return mod
+
+
 def load_sla():
     """The reference SLA package (imports Triton; only the pure-torch parts run on CPU)."""
     if not available():

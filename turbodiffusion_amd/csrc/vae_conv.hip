@@ -1,0 +1,278 @@
+// f4 — the convolutions of the Wan2.1 VAE decoder as ONE implicit-GEMM kernel on the bf16 matrix pipe,
+// plus its channel RMS-norm (+ SiLU) pass.  Reference semantics: rcm/tokenizers/wan2pt1.py — CausalConv3d (:37-55: kt - 1
+// zero frames on the LEFT of the time axis, symmetric spatial padding), Resample (:94-131: nearest x2 spatial up-sampling
+// followed by a 3x3 convolution; time up-sampling = a (3,1,1) causal convolution to 2C channels whose two halves are
+// interleaved in time), ResidualBlock (:195-209: conv(...) + shortcut), RMS_norm (:69-70).
+//
+// MI355X design.  Activations live channels-last, [B, T, H, W, C] bf16, so a convolution is the GEMM
+//     Y[m, n] = sum_{tap, c} X[pos(m) + tap, c] * W[n, tap, c] + bias[n]
+// with M = B*T*H*W output positions (tens of millions for a 480p clip), N = C_out, K = taps * C_in; the whole clip is one
+// launch (no frame chunks, no cache of boundary frames: the clip's activations fit HBM many times over).  Workgroup tile
+// 256 positions x 32*NB channels (NB = 3: C_out 96 / 192 / 384 / 768 are multiples of 96; NB = 1 for the 3-channel head),
+// four waves of 64 positions each: per 16-wide K step a wave reads 2 A and NB B fragments (ds_read_b128) for 2*NB
+// v_mfma_f32_32x32x16_bf16.  K advances in chunks of 64 = two 32-channel halves, each half with its own tap (C_in = 96 is
+// three halves per tap), gathered straight from the input tensor — zero for taps that fall before the first frame or
+// outside the image, and with the x2 up-sampling folded into the gather (source pixel = (h >> 1, w >> 1)) so the 4x larger
+// up-sampled tensor is never written.  Global loads for chunk j + 1 are in flight while chunk j is multiplied (register
+// prefetch, one LDS stage: 44 KB, two workgroups per CU); 128-byte LDS rows with the 16-byte slot XOR-swizzled by the row
+// (the int8 K tile's scheme in attn.hip) keep both the row-per-thread writes and the 32-row fragment reads conflict-free.
+// Epilogue: + bias (fp32) -> bf16 -> optional residual add in bf16 (the reference's rounding points) -> channels-last store;
+// for the time up-sampler the output channel n lands in frame 2 t + n / (N/2), channel n % (N/2).
+#include "td_common.h"
+
+struct VaeConvP {
+  const uint16_t* x;      // [B, Ti, Hi, Wi, Ci] bf16 (batch stride xs_b elements)
+  const uint16_t* w;      // [Co, taps * Ci] bf16, K ordered (dt, dh, dw, c)
+  const uint16_t* bias;   // [Co] or null
+  const uint16_t* res;    // same layout as y, or null
+  uint16_t* y;            // [B, To', Ho, Wo, Co'] bf16 (batch stride ys_b elements)
+  int64_t xs_b, ys_b;
+  int B, Ti, Hi, Wi, Ci;
+  int To, Ho, Wo, Co;     // the GEMM's output grid (To = Ti; Ho = Hi or 2 Hi)
+  int kt, kh, kw;
+  int up2;                // 1: nearest x2 up-sampling of H, W before the convolution
+  int interleave;         // 1: time up-sampler output mapping (y has 2 To frames of Co / 2 channels)
+  int64_t M;              // B * To * Ho * Wo
+  int halves;             // taps * Ci / 32
+};
+
+#define VC_BM 256
+#define VC_ROWB 128       // bytes per LDS row (64 bf16)
+__device__ __forceinline__ uint32_t vc_off(uint32_t row, uint32_t slot) {
+  return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void vae_conv_kernel(VaeConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* a_s = smem;                       // [256][128 B]
+  char* b_s = smem + VC_BM * VC_ROWB;     // [32 NB][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, hi = lane >> 5;
+  const int tiles_n = (p.Co + 32 * NB - 1) / (32 * NB);
+  const int64_t tile_m = blockIdx.x / tiles_n;
+  const int n0 = (int)(blockIdx.x % tiles_n) * 32 * NB;
+
+  // ---- this thread's A row: output position m = tile_m * 256 + tid -> (b, t, h, w) ----
+  int64_t m = tile_m * VC_BM + tid;
+  if (m >= p.M) m = p.M - 1;
+  int wo = (int)(m % p.Wo);
+  int64_t r1 = m / p.Wo;
+  int ho = (int)(r1 % p.Ho);
+  r1 /= p.Ho;
+  const int to = (int)(r1 % p.To), bb = (int)(r1 / p.To);
+  const uint16_t* xb = p.x + (int64_t)bb * p.xs_b;
+  const int ph = p.kh >> 1, pw = p.kw >> 1;
+  const int cpt = p.Ci >> 5;              // 32-channel halves per tap
+  const int64_t ktot = (int64_t)p.halves * 32;
+
+  // ---- B rows this thread loads: vector v = tid + 256 e -> (row v / 8, slot v % 8) ----
+  constexpr int BV = NB == 3 ? 3 : 1;     // 96 x 8 = 768 vectors, or 32 x 8 = 256
+  const uint16_t* bptr[BV];
+#pragma unroll
+  for (int e = 0; e < BV; ++e) {
+    const int v = tid + 256 * e, row = v >> 3;
+    int n = n0 + row;
+    if (n >= p.Co) n = p.Co - 1;
+    bptr[e] = p.w + (int64_t)n * ktot + (v & 7) * 8;
+  }
+
+  uint4 pa[8], pb[BV];
+  // uniform (scalar) position of the next half to fetch: tap = (dt, dh, dw), channel offset cq * 32
+  int f_dt = 0, f_dh = 0, f_dw = 0, f_cq = 0, f_q = 0;
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bool ok = f_q < p.halves;
+      const int ts = to - (p.kt - 1) + f_dt, hu = ho + f_dh - ph, wu = wo + f_dw - pw;
+      ok = ok && ts >= 0 && hu >= 0 && hu < p.Ho && wu >= 0 && wu < p.Wo;
+      const int hs = p.up2 ? (hu >> 1) : hu, ws = p.up2 ? (wu >> 1) : wu;
+      const uint16_t* src = xb + (((int64_t)ts * p.Hi + hs) * p.Wi + ws) * p.Ci + f_cq * 32;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) pa[4 * s + v] = ok ? *reinterpret_cast<const uint4*>(src + 8 * v) : make_uint4(0u, 0u, 0u, 0u);
+      // advance (uniform)
+      ++f_q;
+      if (++f_cq == cpt) {
+        f_cq = 0;
+        if (++f_dw == p.kw) { f_dw = 0; if (++f_dh == p.kh) { f_dh = 0; ++f_dt; } }
+      }
+    }
+  };
+  int64_t f_k = 0;   // first K index of the chunk being fetched
+  auto prefetch_b = [&]() {
+#pragma unroll
+    for (int e = 0; e < BV; ++e) {
+      const int v = tid + 256 * e;
+      const int64_t kk = f_k + (v & 7) * 8;
+      pb[e] = kk < ktot ? *reinterpret_cast<const uint4*>(bptr[e] + f_k) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    f_k += 64;
+  };
+
+  v16f acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][nb][r] = 0.f;
+
+  const int chunks = (p.halves + 1) >> 1;
+  prefetch();
+  prefetch_b();
+  for (int j = 0; j < chunks; ++j) {
+    __syncthreads();   // chunk j - 1 has been multiplied by every wave
+#pragma unroll
+    for (int v = 0; v < 8; ++v) *reinterpret_cast<uint4*>(a_s + vc_off(tid, v)) = pa[v];
+#pragma unroll
+    for (int e = 0; e < BV; ++e) {
+      const int v = tid + 256 * e;
+      *reinterpret_cast<uint4*>(b_s + vc_off(v >> 3, v & 7)) = pb[e];
+    }
+    __syncthreads();
+    if (j + 1 < chunks) {
+      prefetch();
+      prefetch_b();
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v8bf af[2], bf[NB];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v8bf*>(a_s + vc_off(64 * wave + 32 * i + li, 2 * ks + hi));
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const v8bf*>(b_s + vc_off(32 * nb + li, 2 * ks + hi));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[nb], acc[i][nb], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane = output channel n0 + 32 nb + li; registers = positions (r & 3) + 8 (r >> 2) + 4 hi of the 32-row block ----
+  float bias_v[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + 32 * nb + li;
+    bias_v[nb] = (p.bias && n < p.Co) ? bf16_bits_to_f32(p.bias[n]) : 0.f;
+  }
+  const int half_c = p.Co >> 1;
+  const int64_t per_b = (int64_t)p.To * p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t mm = tile_m * VC_BM + 64 * wave + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+      // element offset of (position mm, channel 0) and the channel stride pattern of the destination
+      int64_t o0;
+      if (p.interleave) {
+        const int w_ = (int)(mm % p.Wo);
+        int64_t q = mm / p.Wo;
+        const int h_ = (int)(q % p.Ho);
+        q /= p.Ho;
+        const int t_ = (int)(q % p.To), b_ = (int)(q / p.To);
+        o0 = (int64_t)b_ * p.ys_b + ((((int64_t)(2 * t_)) * p.Ho + h_) * p.Wo + w_) * half_c;
+      } else {
+        const int64_t b_ = mm / per_b;
+        o0 = b_ * p.ys_b + (mm - b_ * per_b) * p.Co;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int n = n0 + 32 * nb + li;
+        if (mm < p.M && n < p.Co) {
+          int64_t o = o0 + n;
+          if (p.interleave && n >= half_c) o = o0 + (int64_t)p.Ho * p.Wo * half_c + (n - half_c);   // second half: the next frame
+          float v = round_bf16(acc[i][nb][r] + bias_v[nb]);
+          if (p.res) v = round_bf16(v + bf16_bits_to_f32(p.res[o]));
+          p.y[o] = (uint16_t)f32_to_bf16_bits(v);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w, const void* bias, const void* res, void* y,
+                           int64_t y_batch_stride, int B, int Ti, int Hi, int Wi, int Ci, int Co, int kt, int kh, int kw,
+                           int up2, int interleave, td_stream_t stream) {
+  TD_REQUIRE(x && w && y, TD_ERR_INVALID, "td_vae_conv: null pointer");
+  TD_REQUIRE(B > 0 && Ti > 0 && Hi > 0 && Wi > 0 && Co > 0, TD_ERR_INVALID, "td_vae_conv: empty problem");
+  TD_REQUIRE(Ci > 0 && Ci % 32 == 0, TD_ERR_UNSUPPORTED, "td_vae_conv: C_in = %d must be a multiple of 32 (pad with zero channels)", Ci);
+  TD_REQUIRE(kt >= 1 && kt <= 3 && (kh == 1 || kh == 3) && (kw == 1 || kw == 3), TD_ERR_UNSUPPORTED, "td_vae_conv: kernel %dx%dx%d", kt, kh, kw);
+  TD_REQUIRE(!interleave || (Co % 2 == 0 && !res), TD_ERR_INVALID, "td_vae_conv: the time up-sampler needs an even C_out and takes no residual");
+  VaeConvP p;
+  p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.res = (const uint16_t*)res;
+  p.y = (uint16_t*)y; p.xs_b = x_batch_stride; p.ys_b = y_batch_stride;
+  p.B = B; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.Ci = Ci;
+  p.To = Ti; p.Ho = up2 ? 2 * Hi : Hi; p.Wo = up2 ? 2 * Wi : Wi; p.Co = Co;
+  p.kt = kt; p.kh = kh; p.kw = kw; p.up2 = up2; p.interleave = interleave;
+  p.M = (int64_t)B * p.To * p.Ho * p.Wo;
+  p.halves = kt * kh * kw * (Ci / 32);
+  const int nbw = Co <= 32 ? 1 : 3;
+  const int64_t tiles = td_cdiv(p.M, VC_BM) * td_cdiv(Co, 32 * nbw);
+  TD_REQUIRE(tiles < (1ll << 31), TD_ERR_UNSUPPORTED, "td_vae_conv: %lld tiles", (long long)tiles);
+  hipStream_t st = (hipStream_t)stream;
+  if (nbw == 1) {
+    constexpr int lds = (VC_BM + 32) * VC_ROWB;
+    static std::atomic<uint64_t> m1{0};
+    td_ensure_dyn_lds((const void*)vae_conv_kernel<1>, lds, m1);
+    vae_conv_kernel<1><<<(unsigned)tiles, 256, lds, st>>>(p);
+  } else {
+    constexpr int lds = (VC_BM + 96) * VC_ROWB;
+    static std::atomic<uint64_t> m3{0};
+    td_ensure_dyn_lds((const void*)vae_conv_kernel<3>, lds, m3);
+    vae_conv_kernel<3><<<(unsigned)tiles, 256, lds, st>>>(p);
+  }
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RMS_norm over the channel axis (+ SiLU) on channels-last rows, with the rounding points of the reference's bf16 path
+// (wan2pt1.py:69-70: F.normalize(x, dim=C) * sqrt(C) * gamma — every operator's result rounded to bf16):
+//   n = bf16(||x||_2);  q = bf16(x / max(n, 1e-12));  q = bf16(q * sqrt(C));  q = bf16(q * gamma);  y = bf16(silu(q))
+// G lanes per row (G = 16 / 32 / 64 for C <= 128 / 256 / 512), 8 channels per lane.
+// ------------------------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void vae_chan_rms_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma,
+                                                           uint16_t* __restrict__ y, int64_t rows, int C, float scale, int silu) {
+  constexpr int RPB = 256 / G;
+  const int sub = threadIdx.x % G;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+  const bool live = row < rows && sub * 8 < C;
+  float f[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = 0.f;
+  if (live) unpack8<TD_BF16>(*reinterpret_cast<const uint4*>(x + row * C + sub * 8), f);
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+#pragma unroll
+  for (int o = G / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float nrm = fmaxf(round_bf16(sqrtf(ss)), 1e-12f);
+  if (!live) return;
+  float g[8];
+  unpack8<TD_BF16>(*reinterpret_cast<const uint4*>(gamma + sub * 8), g);
+  uint32_t o16[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float q = round_bf16(f[j] / nrm);
+    q = round_bf16(q * scale);
+    q = round_bf16(q * g[j]);
+    if (silu) q = round_bf16(q / (1.0f + __expf(-q)));
+    o16[j] = f32_to_bf16_bits(q);
+  }
+  uint4 ov;
+  ov.x = o16[0] | (o16[1] << 16); ov.y = o16[2] | (o16[3] << 16); ov.z = o16[4] | (o16[5] << 16); ov.w = o16[6] | (o16[7] << 16);
+  *reinterpret_cast<uint4*>(y + row * C + sub * 8) = ov;
+}
+
+extern "C" int td_vae_chan_rms(const void* x, const void* gamma, void* y, int64_t rows, int C, int silu, td_stream_t stream) {
+  TD_REQUIRE(x && gamma && y, TD_ERR_INVALID, "td_vae_chan_rms: null pointer");
+  TD_REQUIRE(rows > 0 && C >= 8 && C % 8 == 0 && C <= 512, TD_ERR_UNSUPPORTED, "td_vae_chan_rms: rows=%lld C=%d (multiple of 8, <= 512)", (long long)rows, C);
+  const float scale = sqrtf((float)C);
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 128) vae_chan_rms_kernel<16><<<(unsigned)td_cdiv(rows, 16), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
+  else if (C <= 256) vae_chan_rms_kernel<32><<<(unsigned)td_cdiv(rows, 8), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
+  else vae_chan_rms_kernel<64><<<(unsigned)td_cdiv(rows, 4), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}

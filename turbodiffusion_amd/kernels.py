@@ -780,3 +780,37 @@ def sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay):
         call("td_sla_linear_kv_final_packed", ptr(ws_kv), ptr(ws_ks), SLA_NCH, SLA_NCH * D * D, D * D, SLA_NCH * D, D,
              at("kv"), at("kss"), L.TD_F32, lay.hg, lay.gb, H, D, stream_ptr())
     return pack
+
+
+# ----------------------------------------------------------------------------- f4: VAE decoder convolutions (vae_conv.hip)
+def vae_conv(x, w2d, bias, kt, kh, kw, res=None, up2=False, interleave=False, out=None):
+    """Channels-last causal convolution on the bf16 matrix pipe.  x [B, T, H, W, Ci] bf16 (only the batch dim may be
+    strided), w2d [Co, kt*kh*kw*Ci] bf16 with K ordered (dt, dh, dw, c), bias [Co] bf16 or None, res like the result or
+    None.  Returns [B, T, H', W', Co] (H' = 2H with ``up2``), or with ``interleave`` writes [B, 2T, H, W, Co/2] — into
+    ``out`` when given (a view whose batch dim may be strided: the time up-sampler writes behind the first frame)."""
+    require_gpu(x, w2d, bias, res, out)
+    B, T, H, W, Ci = x.shape
+    Co = w2d.shape[0]
+    assert x.dtype == torch.bfloat16 and w2d.dtype == torch.bfloat16 and w2d.shape[1] == kt * kh * kw * Ci and w2d.is_contiguous()
+    assert x.stride()[1:] == (H * W * Ci, W * Ci, Ci, 1), "x must be channels-last contiguous within a batch entry"
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    shape = (B, 2 * T, H, W, Co // 2) if interleave else (B, T, Ho, Wo, Co)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.bfloat16, device=x.device)
+    assert tuple(out.shape) == shape and out.dtype == torch.bfloat16
+    assert out.stride()[1:] == (shape[2] * shape[3] * shape[4], shape[3] * shape[4], shape[4], 1)
+    if res is not None:
+        assert tuple(res.shape) == shape and res.stride() == out.stride() and res.dtype == torch.bfloat16
+    call("td_vae_conv", ptr(x), x.stride(0), ptr(w2d), ptr(bias), ptr(res), ptr(out), out.stride(0), B, T, H, W, Ci, Co,
+         kt, kh, kw, int(up2), int(interleave), stream_ptr())
+    return out
+
+
+def vae_chan_rms(x, gamma, silu=True):
+    """RMS_norm over the last (channel) axis of a contiguous channels-last bf16 tensor, optional SiLU (wan2pt1.py:69-70 with
+    the bf16 path's rounding points)."""
+    require_gpu(x, gamma)
+    assert x.dtype == torch.bfloat16 and gamma.dtype == torch.bfloat16 and x.is_contiguous() and gamma.numel() == x.shape[-1]
+    y = torch.empty_like(x)
+    call("td_vae_chan_rms", ptr(x), ptr(gamma), ptr(y), x.numel() // x.shape[-1], x.shape[-1], int(silu), stream_ptr())
+    return y

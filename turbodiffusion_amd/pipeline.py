@@ -1,0 +1,37 @@
+"""Prompt token ids -> video: the three stages of the reference's one-shot script (``inference/wan2.1_t2v_infer.py``:
+text embedding :73-76, sampling loop :95-140, VAE decode :141-149) on one GPU, all three resident (288 GB of HBM: no
+``clear_umt5_memory`` / ``net.cpu()`` paging between the stages).
+
+    text = Umt5Encoder(...)          # turbodiffusion_amd.text_encoder  (f4)
+    net = GraphedModel(WanModel...)  # the hot path
+    vae = WanVaeDecoder(...)         # turbodiffusion_amd.vae_decode    (f4)
+    video = t2v(text, net, vae, ids, mask, height=480, width=832)
+
+Tokenisation (a HuggingFace tokenizer) and video file writing stay with the caller."""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from .sampler import rcm_sample
+
+
+def latent_shape(num_frames: int, height: int, width: int, latent_ch: int = 16):
+    """[C, T, H, W] of the latent for a clip (Wan2pt1VAEInterface: 4x in time after the first frame, 8x in space)."""
+    return (latent_ch, 1 + (num_frames - 1) // 4, height // 8, width // 8)
+
+
+@torch.no_grad()
+def t2v(text_encoder: Callable, net: Callable, vae, ids: torch.Tensor, mask: Optional[torch.Tensor] = None, *,
+        height: int = 480, width: int = 832, num_frames: int = 81, num_steps: int = 4, sigma_max: float = 80.0,
+        seed: int = 0, num_samples: int = 1, dtype=torch.bfloat16, device="cuda"):
+    """Returns video [num_samples * B, 3, num_frames, height, width] in [0, 1] (the script's ``(1 + clamp(v, -1, 1)) / 2``)."""
+    emb = text_encoder(ids, mask).to(device=device, dtype=dtype)                  # [B, L_text, text_dim]
+    emb = emb.repeat(num_samples, 1, 1)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    noise = torch.randn(emb.shape[0], *latent_shape(num_frames, height, width), dtype=torch.float32, device=device, generator=gen)
+    z = rcm_sample(net, noise, emb, num_steps=num_steps, sigma_max=sigma_max, generator=gen, dtype=dtype)
+    video = vae.decode(z)
+    return (1.0 + video.float().clamp(-1, 1)) / 2.0
