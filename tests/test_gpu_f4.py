@@ -46,8 +46,9 @@ def _conv_ref(x, w, b, kt, kh, kw, res=None, up2=False, interleave=False):
     return y
 
 
-@pytest.mark.parametrize("case", ["3x3x3", "residual+tail", "up2", "time-interleave", "head", "1x3x3 Ci96"])
-def test_vae_conv_kernel_vs_torch(K, case):
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("case", ["3x3x3", "residual+tail", "up2", "time-interleave", "head", "1x3x3 Ci96", "wide rows", "time-interleave 192"])
+def test_vae_conv_kernel_vs_torch(K, case, kernel):
     """td_vae_conv (implicit GEMM on the bf16 matrix pipe, csrc/vae_conv.hip) against an fp32 torch convolution of the same
     bf16 inputs: within one bf16 step of the correctly rounded result."""
     g = torch.Generator().manual_seed(len(case))
@@ -63,12 +64,31 @@ def test_vae_conv_kernel_vs_torch(K, case):
         T, H, W, Ci, Co = 4, 12, 10, 32, 3
     elif case == "1x3x3 Ci96":
         T, H, W, Ci, Co, k = 1, 17, 16, 96, 96, (1, 3, 3)
+    elif case == "wide rows":                                      # rows wider than one 256-column tile, residual, 2 N tiles
+        B, T, H, W, Ci, Co, res = 1, 2, 3, 300, 96, 192, True
+    elif case == "time-interleave 192":                            # both halves of the channel pairs are whole 96-channel tiles
+        B, T, H, W, Ci, Co, k, inter = 1, 3, 4, 9, 96, 192, (3, 1, 1), True
     x = torch.randn(B, T, H, W, Ci, generator=g).bfloat16()
     w = (torch.randn(Co, k[0] * k[1] * k[2] * Ci, generator=g) / (k[0] * k[1] * k[2] * Ci) ** 0.5).bfloat16()
     b = (0.1 * torch.randn(Co, generator=g)).bfloat16()
     shape = (B, 2 * T, H, W, Co // 2) if inter else (B, T, 2 * H if up2 else H, 2 * W if up2 else W, Co)
     r = torch.randn(shape, generator=g).bfloat16() if res else None
     ref = _conv_ref(x, w, b, *k, res=r, up2=up2, interleave=inter)
+    K.set_tuning(K.TUNE_VAE_CONV, kernel)      # 0 = default (row tiles, one gather per (dt, dh)); 1 = the first kernel
+    try:
+        out = _run_conv(K, x, w, b, k, r, up2, inter, g)
+    finally:
+        K.set_tuning(K.TUNE_VAE_CONV, 0)
+    assert out.shape == ref.shape and torch.isfinite(out).all()
+    err = (out - ref).abs()
+    # one bf16 step of the result; with a residual the convolution's own step (values up to ~4: 2^-6) survives the add
+    assert (err <= ref.abs() * 2.0 ** -7 + (2.0 ** -6 if res else 1e-3)).all(), f"max err {err.max().item()}"
+    assert (out == ref).float().mean().item() > 0.9       # fp32 accumulation order flips a rounding here and there
+
+
+def _run_conv(K, x, w, b, k, r, up2, inter, g):
+    B, T, H, W, Ci = x.shape
+    Co = w.shape[0]
     if inter:     # the up-sampler's use: input = frames 1.. of a clip, output behind frame 0 of the new clip (strided batch views)
         xfull = torch.cat([torch.randn(B, 1, H, W, Ci, generator=g).bfloat16(), x], 1).to(DEV)
         yfull = torch.full((B, 1 + 2 * T, H, W, Co // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -77,12 +97,7 @@ def test_vae_conv_kernel_vs_torch(K, case):
         assert torch.isnan(yfull[:, 0]).all()
     else:
         out = K.vae_conv(x.to(DEV), w.to(DEV), b.to(DEV), *k, res=None if r is None else r.to(DEV), up2=up2)
-    out = out.float().cpu()
-    assert out.shape == ref.shape and torch.isfinite(out).all()
-    err = (out - ref).abs()
-    # one bf16 step of the result; with a residual the convolution's own step (values up to ~4: 2^-6) survives the add
-    assert (err <= ref.abs() * 2.0 ** -7 + (2.0 ** -6 if res else 1e-3)).all(), f"max err {err.max().item()}"
-    assert (out == ref).float().mean().item() > 0.9       # fp32 accumulation order flips a rounding here and there
+    return out.float().cpu()
 
 
 @pytest.mark.parametrize("C,silu", [(96, True), (192, True), (384, False), (32, True)])

@@ -48,14 +48,19 @@ def main():
                 a.record()
                 r = real(x, w2d, bias, kt, kh, kw, res=res, up2=up2, interleave=interleave, out=out)
                 b.record()
-                evs.append((a, b))
+                evs.append((a, b, (tuple(x.shape), w2d.shape[0], (kt, kh, kw), bool(up2), bool(interleave), res is not None),
+                            2.0 * B_ * T_ * (4 if up2 else 1) * H_ * W_ * w2d.shape[0] * w2d.shape[1]))
                 return r
 
             K.vae_conv = counted
             v = dec.decode(z)
             torch.cuda.synchronize()
             K.vae_conv = real
-            conv_s = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+            conv_s = sum(e[0].elapsed_time(e[1]) for e in evs) * 1e-3
+            if os.environ.get("F4_DETAIL"):
+                for e in evs:
+                    ms = e[0].elapsed_time(e[1])
+                    print(f"  conv x{e[2][0]} -> Co {e[2][1]} k{e[2][2]} up2={e[2][3]} interleave={e[2][4]} res={e[2][5]}: {ms:.2f} ms, {e[3] / ms / 1e9:.0f} TFLOP/s", flush=True)
             print(json.dumps({"what": f"WanVaeDecoder.decode ({dec.backend} backend), whole clip, bf16, latent {tuple(z.shape)} -> video {tuple(v.shape)}",
                               "seconds": round(t, 3), "conv_launches": len(evs), "conv_seconds": round(conv_s, 3),
                               "conv_TFLOP": round(fl[0] / 1e12, 1), "conv_TFLOP_per_s": round(fl[0] / conv_s / 1e12, 1),

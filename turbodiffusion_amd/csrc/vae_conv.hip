@@ -190,6 +190,198 @@ __global__ __launch_bounds__(256, 2) void vae_conv_kernel(VaeConvP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// v2 (default): one workgroup = up to 256 consecutive columns of ONE image row (b, t, h) x 32*NB output channels.
+// Measured on v1 above: the 3-channel head convolution cost as much as a 96-channel one (25 vs 27 ms at 480p) — the kernel
+// was bound by the A gather (every input element fetched once per tap: 27 x), not by the matrix pipe.  Here the K loop
+// walks (dt, dh, 64 channels): the source row segment [w0 - 1, w0 + 256] x 64 channels is brought to LDS ONCE (8 lanes per
+// 128-byte row: coalesced) and serves all three dw taps — the A fragment of tap dw is the same LDS tile read one row
+// further down — so the gather traffic and the LDS writes drop 3 x and there is one barrier pair per 3 x 64 K values
+// (72 MFMAs per wave) instead of per 64.  Rows before the first frame / outside the image skip their iteration
+// altogether.  Tiles never cross an image row, so nothing needs an integer division and the epilogue goes through LDS:
+// every thread then owns one position's 32*NB contiguous channels — 16-byte global stores, 16-byte residual loads.
+// ------------------------------------------------------------------------------------------------------------------
+#define VC2_AROWS 264
+template <int NB>
+__global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* a_s = smem;                              // [264][128 B]: LDS row r = column w0 - pw + r of the (up-sampled) source row
+  char* b_s = smem + VC2_AROWS * VC_ROWB;        // [kw][32 NB][128 B]
+  constexpr int NR = 32 * NB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hi = lane >> 5;
+  const int tiles_n = (p.Co + NR - 1) / NR, tiles_w = (p.Wo + VC_BM - 1) / VC_BM;
+  uint32_t bid = blockIdx.x;
+  const int n0 = (int)(bid % tiles_n) * NR;
+  bid /= tiles_n;
+  const int w0 = (int)(bid % tiles_w) * VC_BM;
+  bid /= tiles_w;
+  const int h = (int)(bid % p.Ho);
+  bid /= p.Ho;
+  const int t = (int)(bid % p.To), b = (int)(bid / p.To);
+  const int ph = p.kh >> 1, pw = p.kw >> 1;
+  const int64_t ktot = (int64_t)p.halves * 32;
+  const uint16_t* xb = p.x + (int64_t)b * p.xs_b;
+
+  // ---- loader roles: vector v = tid + 256 e -> (row tid / 8 + 32 e, 16-byte slot tid % 8) ----
+  const int slot = tid & 7, r8 = tid >> 3;
+  constexpr int AV = 9;                          // rows r8 + 32 e, e = 0..8 (e = 8: rows 256.. : the right halo)
+  constexpr int BVT = (3 * NR * 8 + 255) / 256;  // B vectors per thread for kw = 3 (9 for NB = 3, 3 for NB = 1)
+  uint4 pa[AV], pb[BVT];
+  int a_col[AV];                                 // source column (after the up-sampling shift) or -1
+#pragma unroll
+  for (int e = 0; e < AV; ++e) {
+    const int r = r8 + 32 * e, wu = w0 - pw + r;
+    const bool ok = r < VC_BM + 2 * pw && wu >= 0 && wu < p.Wo;
+    a_col[e] = ok ? (p.up2 ? (wu >> 1) : wu) : -1;
+  }
+  const int nbv = p.kw * NR * 8;                 // B vectors in use
+  int64_t b_off[BVT];                            // element offset of (row n, tap dw) within the weights, without (dt, dh, c0)
+#pragma unroll
+  for (int e = 0; e < BVT; ++e) {
+    const int ridx = r8 + 32 * e, dw = ridx / NR;
+    int n = n0 + (ridx - dw * NR);
+    if (n >= p.Co) n = p.Co - 1;
+    b_off[e] = (int64_t)n * ktot + (int64_t)dw * p.Ci + slot * 8;
+  }
+
+  v16f acc[2][NB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][nb][r] = 0.f;
+
+  // ---- the list of iterations (dt, dh, c0) whose source row exists ----
+  const int nc = (p.Ci + 63) >> 6;
+  int it_dt = 0, it_dh = 0, it_c = 0;            // position of the NEXT iteration to fetch
+  auto row_ok = [&](int dt, int dh) {
+    const int ts = t - (p.kt - 1) + dt, hu = h + dh - ph;
+    return ts >= 0 && hu >= 0 && hu < p.Ho;
+  };
+  auto advance_to_valid = [&]() {                // skip (dt, dh) pairs that fall outside; returns false at the end
+    while (it_dt < p.kt && !row_ok(it_dt, it_dh)) {
+      it_c = 0;
+      if (++it_dh == p.kh) { it_dh = 0; ++it_dt; }
+    }
+    return it_dt < p.kt;
+  };
+  int f_kc = 0;                                  // channels of the fetched iteration (64 or the tail)
+  auto fetch = [&]() {
+    const int ts = t - (p.kt - 1) + it_dt, hu = h + it_dh - ph;
+    const int hs = p.up2 ? (hu >> 1) : hu;
+    const int c0 = it_c * 64;
+    f_kc = min(64, p.Ci - c0);
+    const uint16_t* srow = xb + (((int64_t)ts * p.Hi + hs) * p.Wi) * p.Ci + c0 + slot * 8;
+    const bool sl_ok = slot * 8 < f_kc;
+#pragma unroll
+    for (int e = 0; e < AV; ++e)
+      pa[e] = (sl_ok && a_col[e] >= 0) ? *reinterpret_cast<const uint4*>(srow + (int64_t)a_col[e] * p.Ci) : make_uint4(0u, 0u, 0u, 0u);
+    const int64_t kbase = (int64_t)((it_dt * p.kh + it_dh) * p.kw) * p.Ci + c0;
+#pragma unroll
+    for (int e = 0; e < BVT; ++e)
+      pb[e] = (sl_ok && tid + 256 * e < nbv) ? *reinterpret_cast<const uint4*>(p.w + b_off[e] + kbase) : make_uint4(0u, 0u, 0u, 0u);
+    if (++it_c == nc) {
+      it_c = 0;
+      if (++it_dh == p.kh) { it_dh = 0; ++it_dt; }
+    }
+  };
+
+  bool have = advance_to_valid();
+  if (have) fetch();
+  while (have) {
+    const int kc = f_kc;
+    __syncthreads();   // the previous iteration has been multiplied by every wave
+#pragma unroll
+    for (int e = 0; e < AV; ++e) {
+      const int r = r8 + 32 * e;
+      if (r < VC2_AROWS) *reinterpret_cast<uint4*>(a_s + vc_off(r, slot)) = pa[e];
+    }
+#pragma unroll
+    for (int e = 0; e < BVT; ++e)
+      if (tid + 256 * e < nbv) *reinterpret_cast<uint4*>(b_s + vc_off(r8 + 32 * e, slot)) = pb[e];
+    __syncthreads();
+    have = advance_to_valid();
+    if (have) fetch();
+    const int nks = kc >> 4;
+    for (int dw = 0; dw < p.kw; ++dw) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < nks) {
+          v8bf af[2], bf[NB];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v8bf*>(a_s + vc_off(64 * wave + 32 * i + li + dw, 2 * ks + hi));
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const v8bf*>(b_s + vc_off(dw * NR + 32 * nb + li, 2 * ks + hi));
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[nb], acc[i][nb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue through LDS: O[256 positions][32 NB channels] bf16, row stride OS bytes ----
+  constexpr int OS = NR * 2 + 16;
+  __syncthreads();
+  {
+    float bias_v[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + 32 * nb + li;
+      bias_v[nb] = (p.bias && n < p.Co) ? bf16_bits_to_f32(p.bias[n]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 64 * wave + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          *reinterpret_cast<uint16_t*>(smem + row * OS + (32 * nb + li) * 2) = (uint16_t)f32_to_bf16_bits(acc[i][nb][r] + bias_v[nb]);
+        }
+  }
+  __syncthreads();
+  const int w = w0 + tid;
+  if (w < p.Wo) {
+    const int half_c = p.Co >> 1;
+    int64_t o;
+    if (p.interleave) {
+      const int kk = n0 >= half_c ? 1 : 0;
+      o = (int64_t)b * p.ys_b + ((((int64_t)(2 * t + kk)) * p.Ho + h) * p.Wo + w) * half_c + (n0 - kk * half_c);
+    } else {
+      o = (int64_t)b * p.ys_b + (((int64_t)t * p.Ho + h) * p.Wo + w) * p.Co + n0;
+    }
+    const char* orow = smem + tid * OS;
+    if (n0 + NR <= p.Co) {
+#pragma unroll
+      for (int v = 0; v < NR / 8; ++v) {
+        uint4 ov = *reinterpret_cast<const uint4*>(orow + 16 * v);
+        if (p.res) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(p.res + o + 8 * v);
+          float a[8], c[8];
+          unpack8<TD_BF16>(ov, a);
+          unpack8<TD_BF16>(rv, c);
+          uint32_t q[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) q[j] = f32_to_bf16_bits(a[j] + c[j]);
+          ov.x = q[0] | (q[1] << 16); ov.y = q[2] | (q[3] << 16); ov.z = q[4] | (q[5] << 16); ov.w = q[6] | (q[7] << 16);
+        }
+        *reinterpret_cast<uint4*>(p.y + o + 8 * v) = ov;
+      }
+    } else {   // a partial channel tile (the 3-channel head): element stores
+      for (int c = 0; n0 + c < p.Co; ++c) {
+        float v = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(orow + 2 * c));
+        if (p.res) v = round_bf16(v + bf16_bits_to_f32(p.res[o + c]));
+        p.y[o + c] = (uint16_t)f32_to_bf16_bits(v);
+      }
+    }
+  }
+}
+
 extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w, const void* bias, const void* res, void* y,
                            int64_t y_batch_stride, int B, int Ti, int Hi, int Wi, int Ci, int Co, int kt, int kh, int kw,
                            int up2, int interleave, td_stream_t stream) {
@@ -210,6 +402,25 @@ extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w,
   const int64_t tiles = td_cdiv(p.M, VC_BM) * td_cdiv(Co, 32 * nbw);
   TD_REQUIRE(tiles < (1ll << 31), TD_ERR_UNSUPPORTED, "td_vae_conv: %lld tiles", (long long)tiles);
   hipStream_t st = (hipStream_t)stream;
+  const bool v2_ok = (Co % 16 == 0 || Co <= 32) && (!interleave || (Co / 2) % (32 * nbw) == 0) &&
+                     (int64_t)y_batch_stride % 8 == 0;
+  if (td_tuning(TD_TUNE_VAE_CONV) != 1 && v2_ok) {
+    const int64_t t2 = (int64_t)B * p.To * p.Ho * td_cdiv(p.Wo, VC_BM) * td_cdiv(Co, 32 * nbw);
+    TD_REQUIRE(t2 < (1ll << 31), TD_ERR_UNSUPPORTED, "td_vae_conv: %lld tiles", (long long)t2);
+    if (nbw == 1) {
+      constexpr int lds = (VC2_AROWS + 3 * 32) * VC_ROWB;
+      static std::atomic<uint64_t> m21{0};
+      td_ensure_dyn_lds((const void*)vae_conv2_kernel<1>, lds, m21);
+      vae_conv2_kernel<1><<<(unsigned)t2, 256, lds, st>>>(p);
+    } else {
+      constexpr int lds = (VC2_AROWS + 3 * 96) * VC_ROWB;
+      static std::atomic<uint64_t> m23{0};
+      td_ensure_dyn_lds((const void*)vae_conv2_kernel<3>, lds, m23);
+      vae_conv2_kernel<3><<<(unsigned)t2, 256, lds, st>>>(p);
+    }
+    TD_CHECK_LAUNCH();
+    return TD_OK;
+  }
   if (nbw == 1) {
     constexpr int lds = (VC_BM + 32) * VC_ROWB;
     static std::atomic<uint64_t> m1{0};
