@@ -306,6 +306,8 @@ __global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
     have = advance_to_valid();
     if (have) fetch();
     const int nks = kc >> 4;
+    // a wave whose 64 columns all lie past the end of the image row (the last tile of a row: 832 = 3 x 256 + 64) only helps load
+    if (w0 + 64 * wave < p.Wo)
     for (int dw = 0; dw < p.kw; ++dw) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
