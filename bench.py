@@ -209,6 +209,9 @@ def main():
                     "one video); N/sp groups run independent videos.  Default 0 = N: ONE video sharded over all GPUs")
     ap.add_argument("--no-replica-leg", action="store_true", help="N > 1: skip the throughput-mode measurement (N "
                     "independent videos) that follows the timed region")
+    ap.add_argument("--prompt-to-pixels", action="store_true", help="N = 1: after the timed region also time the user-visible "
+                    "path prompt ids -> umT5-XXL text embedding -> the 4 steps -> whole-clip VAE decode (random-init weights of the "
+                    "real architectures, all three models resident); reported in `prompt_to_pixels`, never as `value`")
     ap.add_argument("--two-in-flight", action="store_true", help="N = 1: after the timed region also measure two independent "
                     "videos in flight on two streams, interleaved step by step from one host thread (reported beside the "
                     "headline, never as `value`).  Opt-in since round 3: the round-2 form — two host THREADS replaying hipGraphs "
@@ -414,6 +417,56 @@ def main():
         except Exception as e:  # an extra, never fatal
             two_in_flight = repr(e)
 
+    # ---- user-visible extra (N = 1): prompt ids -> text embedding -> sampling -> pixels (scope row f4), never the headline
+    p2p = None
+    if world == 1 and args.prompt_to_pixels:
+        try:
+            from turbodiffusion_amd import text_encoder as TE, vae_decode as VD
+            enc = TE.Umt5Encoder(TE.synthetic_state_dict(device=dev), device=dev)       # XXL: 24 layers, dim 4096 (10.7 GiB)
+            vae = VD.WanVaeDecoder(VD.synthetic_state_dict(), device=dev)               # dim 96, HIP convolution kernel
+            gi = torch.Generator(device=dev).manual_seed(5)
+            ids = torch.randint(1, 256384, (1, 512), device=dev, generator=gi)
+            msk = torch.zeros(1, 512, dtype=torch.long, device=dev)
+            msk[0, :64] = 1                                                             # a 64-token prompt
+
+            def prompt_to_pixels():
+                emb = enc(ids, msk)
+                if emb.shape[-1] != cfg.get("text_dim", 4096):
+                    raise RuntimeError("text width mismatch")
+                z = rcm_sample(run_net, init_noise, emb, num_steps=args.num_steps, generator=g, y=y, sigma_max=sigma_max,
+                               net_low=run_low, boundary=0.9)
+                return vae.decode(z)
+
+            vid = prompt_to_pixels()
+            sync()
+            ts = {}
+            t0 = time.perf_counter()
+            emb = enc(ids, msk)
+            sync()
+            ts["umt5_ms"] = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            z = rcm_sample(run_net, init_noise, emb, num_steps=args.num_steps, generator=g, y=y, sigma_max=sigma_max,
+                           net_low=run_low, boundary=0.9)
+            sync()
+            ts["sampling_ms"] = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            vid = vae.decode(z)
+            sync()
+            ts["vae_decode_ms"] = (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            for _ in range(3):
+                vid = prompt_to_pixels()
+            sync()
+            p2p = {"seconds_per_video": (time.perf_counter() - t0) / 3, **{k: round(v, 2) for k, v in ts.items()},
+                   "video_shape": list(vid.shape), "finite": bool(torch.isfinite(vid).all()),
+                   "what": "64-token prompt ids -> umT5-XXL (random init) -> 4-step sampling (hipGraph) -> whole-clip VAE decode "
+                           "(random init), all resident; tokenisation and file writing excluded"}
+            del enc, vae, vid
+            torch.cuda.empty_cache()
+            phase("prompt-to-pixels leg done")
+        except Exception as e:  # an extra, never fatal
+            p2p = {"error": repr(e)}
+
     if world > 1:
         tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -536,6 +589,8 @@ def main():
             res["replicas"] = replicas
         if two_in_flight is not None:
             res["two_videos_in_flight_videos_per_s"] = two_in_flight
+        if p2p is not None:
+            res["prompt_to_pixels"] = p2p
         if args.layers:
             res["config"]["DEBUG_num_layers_override"] = args.layers
         if world == 1 and not args.no_cpu_baseline:

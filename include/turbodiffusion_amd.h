@@ -103,6 +103,14 @@ int td_head(const void* x, int dtype, const float* scale, const float* shift, co
 int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w, const void* bias, const void* res, void* y,
                 int64_t y_batch_stride, int B, int Ti, int Hi, int Wi, int Ci, int Co, int kt, int kh, int kw, int up2,
                 int interleave, td_stream_t stream);
+/* td_vae_conv_ex: the same with an explicit output grid [To, Ho, Wo], output strides (1 | 2) and LEFT zero padding — the
+ *   encoder's down-samplers (wan2pt1.py:98-102, 133-149): ZeroPad2d((0, 1, 0, 1)) + 3x3 stride-2 convolution =
+ *   (stride_hw 2, pad_h = pad_w = 0, Ho = Hi / 2); the unpadded stride-2 (3,1,1) time convolution = (stride_t 2, pad_t 0,
+ *   To = (Ti - 3) / 2 + 1).  Whatever the grid reaches beyond the right / bottom / last frame reads zero. */
+int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void* w, const void* bias, const void* res, void* y,
+                   int64_t y_batch_stride, int B, int Ti, int Hi, int Wi, int Ci, int Co, int kt, int kh, int kw, int up2,
+                   int interleave, int To, int Ho, int Wo, int stride_t, int stride_hw, int pad_t, int pad_h, int pad_w,
+                   td_stream_t stream);
 int td_vae_chan_rms(const void* x, const void* gamma, void* y, int64_t rows, int C, int silu, td_stream_t stream);
 
 /* time embedding (wan2pt1.py:144-153, 671-674) and the AdaLN vectors of all blocks:

@@ -67,6 +67,16 @@ def main():
     with torch.no_grad():
         video2 = vae2.decode(z2, [mean, 1.0 / std])
     fx["vae_hip_size"] = {"dim": 32, "seed": 21, "z": z2, "video": video2}
+    # ---- the encoder at the HIP size: weights = turbodiffusion_amd.vae_encode.synthetic_state_dict(dim=32, seed=23); 5 frames of
+    # 48 x 40 -> 2 latent frames of 6 x 5 (reference: chunked WanVAE_.encode)
+    from turbodiffusion_amd.vae_encode import synthetic_state_dict as enc_sd
+    sde = enc_sd(dim=32, z_dim=16, seed=23, dtype=torch.float32)
+    missing, unexpected = vae2.load_state_dict(sde, strict=False)
+    assert not unexpected and all(k.startswith(("decoder.", "conv2.")) for k in missing), (missing[:4], unexpected[:4])
+    xv = torch.randn(2, 3, 5, 48, 40, generator=g).clamp(-1, 1).bfloat16().float()
+    with torch.no_grad():
+        lat = vae2.encode(xv, [mean, 1.0 / std])
+    fx["vae_enc_hip_size"] = {"dim": 32, "seed": 23, "video": xv, "latent": lat}
     # ---- umT5: 3 layers, dim 64, 4 heads, per-layer position tables (umT5), prompts of 17 / 40 / 1 / 5 tokens padded to 40
     enc = u.T5Encoder(vocab=97, dim=64, dim_attn=48, dim_ffn=160, num_heads=4, num_layers=3, num_buckets=32,
                       shared_pos=False, dropout=0.1).eval()

@@ -42,3 +42,16 @@ def test_bench_two_in_flight_extra_runs_single_threaded():
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert isinstance(r["two_videos_in_flight_videos_per_s"], float) and r["two_videos_in_flight_videos_per_s"] > 0
     assert r["value"] > 0 and "box" not in r
+
+
+def test_bench_prompt_to_pixels_extra():
+    """The opt-in user-visible extra: umT5 -> sampling -> whole-clip VAE decode, reported beside the headline."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--layers", "2",
+                          "--no-cpu-baseline", "--no-box-calibration", "--prompt-to-pixels"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    p = r["prompt_to_pixels"]
+    assert "error" not in p, p
+    assert p["finite"] and p["video_shape"] == [1, 3, 81, 480, 832] and 0 < p["seconds_per_video"] < 60
+    assert p["umt5_ms"] > 0 and p["sampling_ms"] > 0 and p["vae_decode_ms"] > 0 and r["value"] > 0

@@ -100,6 +100,61 @@ def _run_conv(K, x, w, b, k, r, up2, inter, g):
     return out.float().cpu()
 
 
+@pytest.mark.parametrize("case", ["spatial stride 2", "time stride 2", "spatial stride 2, odd rows"])
+def test_vae_conv_strided_vs_torch(K, case):
+    """td_vae_conv_ex: the encoder's down-samplers — ZeroPad2d((0, 1, 0, 1)) + 3x3 stride 2, and the unpadded stride-2 (3,1,1)
+    time convolution (wan2pt1.py:98-102, 133-149) — against fp32 torch on the same bf16 inputs."""
+    g = torch.Generator().manual_seed(len(case))
+    if case == "time stride 2":
+        B, T, H, W, Ci, Co, k = 2, 9, 5, 6, 64, 64, (3, 1, 1)
+    elif case == "spatial stride 2":
+        B, T, H, W, Ci, Co, k = 1, 3, 12, 10, 96, 96, (1, 3, 3)
+    else:
+        B, T, H, W, Ci, Co, k = 1, 2, 34, 18, 32, 192, (1, 3, 3)
+    x = torch.randn(B, T, H, W, Ci, generator=g).bfloat16()
+    w = (torch.randn(Co, k[0] * k[1] * k[2] * Ci, generator=g) / (k[0] * k[1] * k[2] * Ci) ** 0.5).bfloat16()
+    b = (0.1 * torch.randn(Co, generator=g)).bfloat16()
+    xc = x.float().permute(0, 4, 1, 2, 3)
+    w5 = w.float().reshape(Co, *k, Ci).permute(0, 4, 1, 2, 3)
+    if k[0] == 3:
+        ref = F.conv3d(xc, w5, b.float(), stride=(2, 1, 1))
+        out = K.vae_conv_strided(x.to(DEV), w.to(DEV), b.to(DEV), *k, stride_t=2, pad_t=0)
+    else:
+        ref = F.conv3d(F.pad(xc, (0, 1, 0, 1)), w5, b.float(), stride=(1, 2, 2))
+        out = K.vae_conv_strided(x.to(DEV), w.to(DEV), b.to(DEV), *k, stride_hw=2, pad_hw=0)
+    ref = ref.bfloat16().float().permute(0, 2, 3, 4, 1)
+    out = out.float().cpu()
+    assert out.shape == ref.shape
+    assert ((out - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all() and (out == ref).float().mean().item() > 0.9
+
+
+def test_vae_encode_on_the_gpu_matches_the_reference_fixture():
+    """The HIP backend of the encoder (bf16, channels-last) against the fp32 output of the REFERENCE's chunked encode."""
+    from turbodiffusion_amd.vae_encode import WanVaeEncoder, synthetic_state_dict
+    fx = torch.load(GOLD)["vae_enc_hip_size"]
+    enc = WanVaeEncoder(synthetic_state_dict(dim=fx["dim"], seed=fx["seed"]), dtype=torch.bfloat16, device=DEV)
+    assert enc.backend == "hip"
+    out = enc.encode(fx["video"].to(DEV))
+    assert out.shape == fx["latent"].shape and out.dtype == torch.float32 and torch.isfinite(out).all()
+    e = rel_l2(out, fx["latent"])
+    print(f"\n[VAE encode, HIP backend, bf16] rel-L2 vs the reference's fp32 encode: {e:.4f}")
+    assert e < 2e-2                                           # (the library bf16 path on the CPU: 0.7e-2)
+
+
+def test_i2v_conditioning_channels(K):
+    """``y`` of Wan2.2 I2V (wan2.2_i2v_infer.py:139-152): 4 mask channels (first latent frame = 1) + the encoded [image, 0, ...]."""
+    from turbodiffusion_amd.pipeline import i2v_condition
+    from turbodiffusion_amd.vae_encode import WanVaeEncoder, synthetic_state_dict
+    enc = WanVaeEncoder(synthetic_state_dict(dim=32, seed=23), dtype=torch.bfloat16, device=DEV)
+    img = torch.rand(1, 3, 48, 40, device=DEV) * 2 - 1
+    y = i2v_condition(enc, img, num_frames=9)
+    assert y.shape == (1, 20, 3, 6, 5) and y.dtype == torch.bfloat16 and torch.isfinite(y).all()
+    assert bool((y[:, :4, 0] == 1).all()) and bool((y[:, :4, 1:] == 0).all())
+    frames = torch.zeros(1, 3, 9, 48, 40, device=DEV)
+    frames[:, :, 0] = img
+    assert torch.equal(y[:, 4:], enc.encode(frames).bfloat16())
+
+
 @pytest.mark.parametrize("C,silu", [(96, True), (192, True), (384, False), (32, True)])
 def test_vae_chan_rms_kernel_vs_the_bf16_operator_chain(K, C, silu):
     g = torch.Generator().manual_seed(C)

@@ -42,6 +42,29 @@ def test_whole_clip_vae_decode_equals_the_reference_chunked_decode(dim, zd, T, H
 
 
 @needs_ref
+@pytest.mark.parametrize("dim,zd,T,H,W", [(8, 4, 9, 32, 32), (8, 4, 1, 16, 24), (16, 16, 5, 32, 16), (8, 4, 13, 16, 16)])
+def test_whole_clip_vae_encode_equals_the_reference_chunked_encode(dim, zd, T, H, W):
+    """One pass over all frames == the reference's 1 + 4 + 4 + ... chunked encode with its feature caches, incl. the temporal
+    down-samplers' first-frame rule (the first frame passes, frames 1.. come from stride-2 windows starting at even frames)."""
+    from turbodiffusion_amd.vae_encode import WanVaeEncoder
+    v = rh.load_aux("tokenizers.wan2pt1")
+    vae = v.WanVAE_(dim=dim, z_dim=zd, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
+                    temperal_downsample=[False, True, True], dropout=0.0).eval()
+    randomise(vae, dim + T)
+    g = torch.Generator().manual_seed(T)
+    x = torch.randn(2, 3, T, H, W, generator=g)
+    mean, std = 0.5 * torch.randn(zd, generator=g), torch.rand(zd, generator=g) + 0.5
+    with torch.no_grad():
+        ref = vae.encode(x, [mean, 1.0 / std])
+    enc = WanVaeEncoder.from_reference(vae, dtype=torch.float32, device="cpu", mean=mean.tolist(), std=std.tolist())
+    out = enc.encode(x)
+    assert out.shape == ref.shape == (2, zd, enc.latent_frames(T), H // 8, W // 8) and enc.latent_frames(T) == 1 + (T - 1) // 4
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        enc.encode(torch.zeros(1, 3, T + 2, H, W))          # not 1 + 4k frames
+
+
+@needs_ref
 @pytest.mark.parametrize("shared", [False, True])
 def test_umt5_encoder_equals_the_reference_encoder(shared):
     u = rh.load_aux("utils.umt5")
@@ -76,6 +99,13 @@ def test_f4_modules_against_the_reference_fixture():
     fx = torch.load(GOLD)
     dec = WanVaeDecoder(fx["vae"]["state_dict"], dtype=torch.float32, device="cpu")
     torch.testing.assert_close(dec.decode(fx["vae"]["z"]), fx["vae"]["video"], rtol=1e-5, atol=2e-5)
+    from turbodiffusion_amd.vae_encode import WanVaeEncoder, synthetic_state_dict as enc_sd
+    from turbodiffusion_amd.vae_decode import synthetic_state_dict as dec_sd
+    hd, he = fx["vae_hip_size"], fx["vae_enc_hip_size"]     # the seeded weights the GPU tests rebuild reproduce the fixture
+    dec2 = WanVaeDecoder(dec_sd(dim=hd["dim"], seed=hd["seed"], dtype=torch.float32), dtype=torch.float32, device="cpu")
+    torch.testing.assert_close(dec2.decode(hd["z"]), hd["video"], rtol=1e-5, atol=2e-5)
+    enc2 = WanVaeEncoder(enc_sd(dim=he["dim"], seed=he["seed"], dtype=torch.float32), dtype=torch.float32, device="cpu")
+    torch.testing.assert_close(enc2.encode(he["video"]), he["latent"], rtol=1e-5, atol=2e-5)
     t5 = fx["umt5"]
     enc = Umt5Encoder(t5["state_dict"], dtype=torch.float32, device="cpu")
     assert (enc.num_heads, enc.num_buckets, enc.dim, enc.dim_ffn, len(enc.layers), enc.shared_pos) == (4, 32, 64, 160, 3, False)

@@ -28,7 +28,7 @@ def timed(fn, reps=3):
 
 
 def main():
-    which = sys.argv[1:] or ["vae480", "vae720", "umt5"]
+    which = sys.argv[1:] or ["vae480", "vae720", "enc480", "umt5"]
     if any(w.startswith("vae") for w in which):
         dec = WanVaeDecoder(vae_state_dict(), dtype=torch.bfloat16, device=DEV)          # HIP backend
         for tag, (h, w) in (("vae480", (480, 832)), ("vae720", (720, 1280))):
@@ -69,6 +69,18 @@ def main():
             del v, z
             torch.cuda.empty_cache()
         del dec
+        torch.cuda.empty_cache()
+    if "enc480" in which:
+        from turbodiffusion_amd.vae_encode import WanVaeEncoder, synthetic_state_dict as enc_state_dict
+        enc = WanVaeEncoder(enc_state_dict(), dtype=torch.bfloat16, device=DEV)
+        vid = torch.rand(1, 3, 81, 480, 832, device=DEV) * 2 - 1
+        torch.cuda.reset_peak_memory_stats()
+        t = timed(lambda: enc.encode(vid), reps=2)
+        lat = enc.encode(vid)
+        print(json.dumps({"what": f"WanVaeEncoder.encode ({enc.backend} backend), whole clip, bf16, video {tuple(vid.shape)} -> latent {tuple(lat.shape)}",
+                          "seconds": round(t, 3), "peak_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                          "finite": bool(torch.isfinite(lat).all())}), flush=True)
+        del enc, vid, lat
         torch.cuda.empty_cache()
     if "umt5" in which:
         enc = Umt5Encoder(t5_state_dict(device=DEV), dtype=torch.bfloat16, device=DEV)

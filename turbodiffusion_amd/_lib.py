@@ -31,6 +31,7 @@ SIGNATURES = {
     "td_head": [_vp, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
     "td_time_sinusoid": [_vp, _i32, _vp, _i64, _i64, _vp],
     "td_vae_conv": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
+    "td_vae_conv_ex": [_vp, _i64, _vp, _vp, _vp, _vp, _i64] + [_i32] * 19 + [_vp],
     "td_vae_chan_rms": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_gemv_f32": [_vp, _vp, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp],
     "td_bcast_add": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],

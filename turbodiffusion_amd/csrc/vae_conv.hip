@@ -34,6 +34,10 @@ struct VaeConvP {
   int interleave;         // 1: time up-sampler output mapping (y has 2 To frames of Co / 2 channels)
   int64_t M;              // B * To * Ho * Wo
   int halves;             // taps * Ci / 32
+  int st, ss;             // output strides in time / space (the encoder's down-samplers: 2); 1 = plain
+  int pt, ph, pw;         // zero frames / rows / columns on the LEFT (kt - 1, kh / 2, kw / 2 = causal in time, centred in space;
+                          // the encoder's ZeroPad2d((0, 1, 0, 1)) and its unpadded stride-2 time convolution pass 0); whatever the
+                          // output grid reaches beyond the right edge is zero too
 };
 
 #define VC_BM 256
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void vae_conv_kernel(VaeConvP p) {
   r1 /= p.Ho;
   const int to = (int)(r1 % p.To), bb = (int)(r1 / p.To);
   const uint16_t* xb = p.x + (int64_t)bb * p.xs_b;
-  const int ph = p.kh >> 1, pw = p.kw >> 1;
+  const int hsrc = p.up2 ? 2 * p.Hi : p.Hi, wsrc = p.up2 ? 2 * p.Wi : p.Wi;   // extent of the (up-sampled) source image
   const int cpt = p.Ci >> 5;              // 32-channel halves per tap
   const int64_t ktot = (int64_t)p.halves * 32;
 
@@ -84,8 +88,8 @@ __global__ __launch_bounds__(256, 2) void vae_conv_kernel(VaeConvP p) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bool ok = f_q < p.halves;
-      const int ts = to - (p.kt - 1) + f_dt, hu = ho + f_dh - ph, wu = wo + f_dw - pw;
-      ok = ok && ts >= 0 && hu >= 0 && hu < p.Ho && wu >= 0 && wu < p.Wo;
+      const int ts = to * p.st - p.pt + f_dt, hu = ho * p.ss - p.ph + f_dh, wu = wo * p.ss - p.pw + f_dw;
+      ok = ok && ts >= 0 && ts < p.Ti && hu >= 0 && hu < hsrc && wu >= 0 && wu < wsrc;
       const int hs = p.up2 ? (hu >> 1) : hu, ws = p.up2 ? (wu >> 1) : wu;
       const uint16_t* src = xb + (((int64_t)ts * p.Hi + hs) * p.Wi + ws) * p.Ci + f_cq * 32;
 #pragma unroll
@@ -384,9 +388,10 @@ __global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
   }
 }
 
-extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w, const void* bias, const void* res, void* y,
-                           int64_t y_batch_stride, int B, int Ti, int Hi, int Wi, int Ci, int Co, int kt, int kh, int kw,
-                           int up2, int interleave, td_stream_t stream) {
+extern "C" int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void* w, const void* bias, const void* res, void* y,
+                              int64_t y_batch_stride, int B, int Ti, int Hi, int Wi, int Ci, int Co, int kt, int kh, int kw,
+                              int up2, int interleave, int To, int Ho, int Wo, int stride_t, int stride_hw, int pad_t,
+                              int pad_h, int pad_w, td_stream_t stream) {
   TD_REQUIRE(x && w && y, TD_ERR_INVALID, "td_vae_conv: null pointer");
   TD_REQUIRE(B > 0 && Ti > 0 && Hi > 0 && Wi > 0 && Co > 0, TD_ERR_INVALID, "td_vae_conv: empty problem");
   TD_REQUIRE(Ci > 0 && Ci % 32 == 0, TD_ERR_UNSUPPORTED, "td_vae_conv: C_in = %d must be a multiple of 32 (pad with zero channels)", Ci);
@@ -396,7 +401,13 @@ extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w,
   p.x = (const uint16_t*)x; p.w = (const uint16_t*)w; p.bias = (const uint16_t*)bias; p.res = (const uint16_t*)res;
   p.y = (uint16_t*)y; p.xs_b = x_batch_stride; p.ys_b = y_batch_stride;
   p.B = B; p.Ti = Ti; p.Hi = Hi; p.Wi = Wi; p.Ci = Ci;
-  p.To = Ti; p.Ho = up2 ? 2 * Hi : Hi; p.Wo = up2 ? 2 * Wi : Wi; p.Co = Co;
+  TD_REQUIRE(To > 0 && Ho > 0 && Wo > 0 && (stride_t == 1 || stride_t == 2) && (stride_hw == 1 || stride_hw == 2) && pad_t >= 0 &&
+             pad_h >= 0 && pad_w >= 0, TD_ERR_INVALID, "td_vae_conv: output grid %dx%dx%d strides %d/%d", To, Ho, Wo, stride_t, stride_hw);
+  const bool plain = stride_t == 1 && stride_hw == 1 && pad_t == kt - 1 && pad_h == kh / 2 && pad_w == kw / 2 && To == Ti &&
+                     Ho == (up2 ? 2 * Hi : Hi) && Wo == (up2 ? 2 * Wi : Wi);
+  TD_REQUIRE(plain || !interleave, TD_ERR_UNSUPPORTED, "td_vae_conv: the time up-sampler mapping needs the plain geometry");
+  p.To = To; p.Ho = Ho; p.Wo = Wo; p.Co = Co;
+  p.st = stride_t; p.ss = stride_hw; p.pt = pad_t; p.ph = pad_h; p.pw = pad_w;
   p.kt = kt; p.kh = kh; p.kw = kw; p.up2 = up2; p.interleave = interleave;
   p.M = (int64_t)B * p.To * p.Ho * p.Wo;
   p.halves = kt * kh * kw * (Ci / 32);
@@ -404,7 +415,7 @@ extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w,
   const int64_t tiles = td_cdiv(p.M, VC_BM) * td_cdiv(Co, 32 * nbw);
   TD_REQUIRE(tiles < (1ll << 31), TD_ERR_UNSUPPORTED, "td_vae_conv: %lld tiles", (long long)tiles);
   hipStream_t st = (hipStream_t)stream;
-  const bool v2_ok = (Co % 16 == 0 || Co <= 32) && (!interleave || (Co / 2) % (32 * nbw) == 0) &&
+  const bool v2_ok = plain && (Co % 16 == 0 || Co <= 32) && (!interleave || (Co / 2) % (32 * nbw) == 0) &&
                      (int64_t)y_batch_stride % 8 == 0;
   if (td_tuning(TD_TUNE_VAE_CONV) != 1 && v2_ok) {
     const int64_t t2 = (int64_t)B * p.To * p.Ho * td_cdiv(p.Wo, VC_BM) * td_cdiv(Co, 32 * nbw);
@@ -436,6 +447,13 @@ extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w,
   }
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w, const void* bias, const void* res, void* y,
+                           int64_t y_batch_stride, int B, int Ti, int Hi, int Wi, int Ci, int Co, int kt, int kh, int kw,
+                           int up2, int interleave, td_stream_t stream) {
+  return td_vae_conv_ex(x, x_batch_stride, w, bias, res, y, y_batch_stride, B, Ti, Hi, Wi, Ci, Co, kt, kh, kw, up2, interleave, Ti,
+                        up2 ? 2 * Hi : Hi, up2 ? 2 * Wi : Wi, 1, 1, kt - 1, kh / 2, kw / 2, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

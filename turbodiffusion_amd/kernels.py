@@ -784,6 +784,28 @@ def sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay):
 
 
 # ----------------------------------------------------------------------------- f4: VAE decoder convolutions (vae_conv.hip)
+def vae_conv_strided(x, w2d, bias, kt, kh, kw, stride_t=1, stride_hw=1, pad_t=None, pad_hw=None):
+    """td_vae_conv_ex: the encoder's down-sampling convolutions.  x [B, T, H, W, Ci] channels-last bf16; LEFT zero padding
+    ``pad_t`` frames (default kt - 1: causal) and ``pad_hw`` rows / columns (default k // 2); the output grid is what the
+    reference's padded convolutions produce: T' = (T + pad_t - kt) // stride_t + 1, H' = (H + 2 (k // 2) - k) // stride_hw + 1
+    for the centred case and H // 2 for ZeroPad2d((0, 1, 0, 1)) + stride 2 (``pad_hw = 0``)."""
+    require_gpu(x, w2d, bias)
+    B, T, H, W, Ci = x.shape
+    Co = w2d.shape[0]
+    assert x.dtype == torch.bfloat16 and w2d.dtype == torch.bfloat16 and w2d.shape[1] == kt * kh * kw * Ci and w2d.is_contiguous()
+    assert x.stride()[1:] == (H * W * Ci, W * Ci, Ci, 1)
+    pt = kt - 1 if pad_t is None else pad_t
+    ph, pw = (kh // 2, kw // 2) if pad_hw is None else (pad_hw, pad_hw)
+    To = (T + pt - kt) // stride_t + 1
+    # right padding: centred -> k // 2; the down-sampler's (0, 1) -> 1 when the left pad is 0 and k = 3
+    rh, rw = (kh // 2, kw // 2) if pad_hw is None else ((1, 1) if (pad_hw == 0 and kh == 3) else (pad_hw, pad_hw))
+    Ho, Wo = (H + ph + rh - kh) // stride_hw + 1, (W + pw + rw - kw) // stride_hw + 1
+    out = torch.empty((B, To, Ho, Wo, Co), dtype=torch.bfloat16, device=x.device)
+    call("td_vae_conv_ex", ptr(x), x.stride(0), ptr(w2d), ptr(bias), None, ptr(out), out.stride(0), B, T, H, W, Ci, Co, kt, kh, kw,
+         0, 0, To, Ho, Wo, stride_t, stride_hw, pt, ph, pw, stream_ptr())
+    return out
+
+
 def vae_conv(x, w2d, bias, kt, kh, kw, res=None, up2=False, interleave=False, out=None):
     """Channels-last causal convolution on the bf16 matrix pipe.  x [B, T, H, W, Ci] bf16 (only the batch dim may be
     strided), w2d [Co, kt*kh*kw*Ci] bf16 with K ordered (dt, dh, dw, c), bias [Co] bf16 or None, res like the result or

@@ -35,3 +35,33 @@ def t2v(text_encoder: Callable, net: Callable, vae, ids: torch.Tensor, mask: Opt
     z = rcm_sample(net, noise, emb, num_steps=num_steps, sigma_max=sigma_max, generator=gen, dtype=dtype)
     video = vae.decode(z)
     return (1.0 + video.float().clamp(-1, 1)) / 2.0
+
+
+@torch.no_grad()
+def i2v_condition(vae_enc, image: torch.Tensor, num_frames: int = 81, dtype=torch.bfloat16):
+    """The conditioning channels ``y`` of Wan2.2 I2V (``inference/wan2.2_i2v_infer.py:139-152``): the first frame = the image
+    ([B, 3, H, W] in [-1, 1]), the other ``num_frames - 1`` frames zero, through the VAE encoder; 4 mask channels (1 on the
+    first latent frame) in front -> [B, 4 + 16, T_lat, H/8, W/8]."""
+    B, C, H, W = image.shape
+    frames = torch.zeros(B, C, num_frames, H, W, dtype=torch.float32, device=image.device)
+    frames[:, :, 0] = image
+    lat = vae_enc.encode(frames)
+    msk = torch.zeros(B, 4, *lat.shape[2:], dtype=dtype, device=lat.device)
+    msk[:, :, 0] = 1.0
+    return torch.cat([msk, lat.to(dtype)], dim=1)
+
+
+@torch.no_grad()
+def i2v(text_encoder: Callable, net_high: Callable, net_low: Callable, vae_enc, vae_dec, ids: torch.Tensor,
+        mask: Optional[torch.Tensor], image: torch.Tensor, *, num_frames: int = 81, num_steps: int = 4, sigma_max: float = 200.0,
+        boundary: float = 0.9, seed: int = 0, dtype=torch.bfloat16, device="cuda"):
+    """Image + prompt ids -> video in [0, 1]: the stages of ``inference/wan2.2_i2v_infer.py`` (text :96-99, conditioning
+    :139-152, the loop with the expert switch at ``boundary`` :173-213, decode :214-222), both experts resident."""
+    emb = text_encoder(ids, mask).to(device=device, dtype=dtype)
+    y = i2v_condition(vae_enc, image.to(device), num_frames, dtype)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    noise = torch.randn(emb.shape[0], 16, *y.shape[2:], dtype=torch.float32, device=device, generator=gen)
+    z = rcm_sample(net_high, noise, emb, num_steps=num_steps, sigma_max=sigma_max, generator=gen, y=y, net_low=net_low,
+                   boundary=boundary, dtype=dtype)
+    return (1.0 + vae_dec.decode(z).float().clamp(-1, 1)) / 2.0
