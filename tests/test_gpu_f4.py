@@ -46,7 +46,7 @@ def _conv_ref(x, w, b, kt, kh, kw, res=None, up2=False, interleave=False):
     return y
 
 
-@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("kernel", [0, 1, 3])   # default (row tiles) | the first kernel | row tiles forced to 512 columns
 @pytest.mark.parametrize("case", ["3x3x3", "residual+tail", "up2", "time-interleave", "head", "1x3x3 Ci96", "wide rows", "time-interleave 192"])
 def test_vae_conv_kernel_vs_torch(K, case, kernel):
     """td_vae_conv (implicit GEMM on the bf16 matrix pipe, csrc/vae_conv.hip) against an fp32 torch convolution of the same
@@ -221,3 +221,32 @@ def test_prompt_ids_to_video_runs_the_three_stages():
     v2 = t2v(text, net, vae, ids, mask, height=128, width=128, num_frames=13, seed=3, device=DEV)
     assert v1.shape == (1, 3, 13, 128, 128) and torch.isfinite(v1).all() and 0.0 <= float(v1.min()) and float(v1.max()) <= 1.0
     assert torch.equal(v1, v2)
+
+
+def test_image_and_prompt_to_video_runs_the_i2v_data_path():
+    """wan2.2_i2v_infer.py's data path on toy models: umT5 -> VAE-encoded conditioning -> 4 steps with the expert switch at the
+    boundary (two DiTs resident) -> VAE decode."""
+    from turbodiffusion_amd.pipeline import i2v
+    from turbodiffusion_amd.text_encoder import Umt5Encoder
+    from turbodiffusion_amd.vae_decode import WanVaeDecoder, synthetic_state_dict as dec_sd
+    from turbodiffusion_amd.vae_encode import WanVaeEncoder, synthetic_state_dict as enc_sd
+    from turbodiffusion_amd.wan import WanModel
+    fx = torch.load(GOLD)
+    text = Umt5Encoder(fx["umt5"]["state_dict"], dtype=torch.bfloat16, device=DEV)
+    enc = WanVaeEncoder(enc_sd(dim=32, seed=23), dtype=torch.bfloat16, device=DEV)
+    dec = WanVaeDecoder(dec_sd(dim=32, seed=21), dtype=torch.bfloat16, device=DEV)
+    cfg = dict(model_type="i2v", in_dim=36, dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=64, freq_dim=64, text_len=40)
+    nets = []
+    for seed in (5, 6):
+        with torch.device(DEV):
+            net = WanModel(attention_type="sagesla", sla_topk=0.5, quant_linear=True, **cfg)
+        own = net.state_dict()
+        sd = {k: (v.to(DEV).to(own[k].dtype) if k in own else v.to(DEV)) for k, v in W.make_state_dict(cfg, seed).items()}
+        net.load_from_float_state_dict(sd)
+        nets.append(net.eval())
+    img = torch.rand(1, 3, 128, 128, device=DEV) * 2 - 1
+    ids, mask = fx["umt5"]["ids"][:1], fx["umt5"]["mask"][:1]
+    v1 = i2v(text, nets[0], nets[1], enc, dec, ids, mask, img, num_frames=13, seed=4, device=DEV)
+    assert v1.shape == (1, 3, 13, 128, 128) and torch.isfinite(v1).all() and 0.0 <= float(v1.min()) and float(v1.max()) <= 1.0
+    v2 = i2v(text, nets[0], nets[0], enc, dec, ids, mask, img, num_frames=13, seed=4, device=DEV)
+    assert not torch.equal(v1, v2)            # the low-noise expert took over after the boundary

@@ -205,21 +205,27 @@ __global__ __launch_bounds__(256, 2) void vae_conv_kernel(VaeConvP p) {
 // altogether.  Tiles never cross an image row, so nothing needs an integer division and the epilogue goes through LDS:
 // every thread then owns one position's 32*NB contiguous channels — 16-byte global stores, 16-byte residual loads.
 // ------------------------------------------------------------------------------------------------------------------
-#define VC2_AROWS 264
-template <int NB>
-__global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
+// WR = 32-row blocks per wave: 2 -> 256-column tiles, two workgroups per CU (the default); 4 -> 512-column tiles, wave tile
+// 128 x 96 (7 fragment reads per 12 MFMAs instead of 5 per 6; 192 accumulators in AGPRs), ONE workgroup per CU with the
+// 512-register file of a single wave per SIMD — built to test whether LDS bandwidth is what bounds the kernel: it is not, the
+// 96-channel level runs at 549 instead of 700 TFLOP/s (one wave per SIMD has nothing to run beside its own LDS writes and
+// barriers).  Kept selectable (TD_TUNE_VAE_CONV = 3) and tested.
+template <int NB, int WR>
+__global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConvP p) {
+  constexpr int BM = 64 * WR * 2;                // columns per tile: 256 | 512
+  constexpr int AROWS = BM + 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* a_s = smem;                              // [264][128 B]: LDS row r = column w0 - pw + r of the (up-sampled) source row
-  char* b_s = smem + VC2_AROWS * VC_ROWB;        // [kw][32 NB][128 B]
+  char* b_s = smem + AROWS * VC_ROWB;           // [kw][32 NB][128 B]
   constexpr int NR = 32 * NB;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hi = lane >> 5;
-  const int tiles_n = (p.Co + NR - 1) / NR, tiles_w = (p.Wo + VC_BM - 1) / VC_BM;
+  const int tiles_n = (p.Co + NR - 1) / NR, tiles_w = (p.Wo + BM - 1) / BM;
   uint32_t bid = blockIdx.x;
   const int n0 = (int)(bid % tiles_n) * NR;
   bid /= tiles_n;
-  const int w0 = (int)(bid % tiles_w) * VC_BM;
+  const int w0 = (int)(bid % tiles_w) * BM;
   bid /= tiles_w;
   const int h = (int)(bid % p.Ho);
   bid /= p.Ho;
@@ -230,14 +236,14 @@ __global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
 
   // ---- loader roles: vector v = tid + 256 e -> (row tid / 8 + 32 e, 16-byte slot tid % 8) ----
   const int slot = tid & 7, r8 = tid >> 3;
-  constexpr int AV = 9;                          // rows r8 + 32 e, e = 0..8 (e = 8: rows 256.. : the right halo)
+  constexpr int AV = BM / 32 + 1;                // rows r8 + 32 e (the last e: rows BM.. : the right halo)
   constexpr int BVT = (3 * NR * 8 + 255) / 256;  // B vectors per thread for kw = 3 (9 for NB = 3, 3 for NB = 1)
   uint4 pa[AV], pb[BVT];
   int a_col[AV];                                 // source column (after the up-sampling shift) or -1
 #pragma unroll
   for (int e = 0; e < AV; ++e) {
     const int r = r8 + 32 * e, wu = w0 - pw + r;
-    const bool ok = r < VC_BM + 2 * pw && wu >= 0 && wu < p.Wo;
+    const bool ok = r < BM + 2 * pw && wu >= 0 && wu < p.Wo;
     a_col[e] = ok ? (p.up2 ? (wu >> 1) : wu) : -1;
   }
   const int nbv = p.kw * NR * 8;                 // B vectors in use
@@ -250,9 +256,9 @@ __global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
     b_off[e] = (int64_t)n * ktot + (int64_t)dw * p.Ci + slot * 8;
   }
 
-  v16f acc[2][NB];
+  v16f acc[WR][NB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WR; ++i)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
 #pragma unroll
     for (int e = 0; e < AV; ++e) {
       const int r = r8 + 32 * e;
-      if (r < VC2_AROWS) *reinterpret_cast<uint4*>(a_s + vc_off(r, slot)) = pa[e];
+      if (r < AROWS) *reinterpret_cast<uint4*>(a_s + vc_off(r, slot)) = pa[e];
     }
 #pragma unroll
     for (int e = 0; e < BVT; ++e)
@@ -311,18 +317,18 @@ __global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
     if (have) fetch();
     const int nks = kc >> 4;
     // a wave whose 64 columns all lie past the end of the image row (the last tile of a row: 832 = 3 x 256 + 64) only helps load
-    if (w0 + 64 * wave < p.Wo)
+    if (w0 + 32 * WR * wave < p.Wo)
     for (int dw = 0; dw < p.kw; ++dw) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         if (ks < nks) {
-          v8bf af[2], bf[NB];
+          v8bf af[WR], bf[NB];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v8bf*>(a_s + vc_off(64 * wave + 32 * i + li + dw, 2 * ks + hi));
+          for (int i = 0; i < WR; ++i) af[i] = *reinterpret_cast<const v8bf*>(a_s + vc_off(32 * WR * wave + 32 * i + li + dw, 2 * ks + hi));
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const v8bf*>(b_s + vc_off(dw * NR + 32 * nb + li, 2 * ks + hi));
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < WR; ++i)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[nb], acc[i][nb], 0, 0, 0);
         }
@@ -330,59 +336,63 @@ __global__ __launch_bounds__(256, 2) void vae_conv2_kernel(VaeConvP p) {
     }
   }
 
-  // ---- epilogue through LDS: O[256 positions][32 NB channels] bf16, row stride OS bytes ----
+  // ---- epilogue through LDS, 256 positions per pass: O[256][32 NB channels] bf16, row stride OS bytes ----
   constexpr int OS = NR * 2 + 16;
-  __syncthreads();
-  {
-    float bias_v[NB];
+  float bias_v[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int n = n0 + 32 * nb + li;
-      bias_v[nb] = (p.bias && n < p.Co) ? bf16_bits_to_f32(p.bias[n]) : 0.f;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 64 * wave + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          *reinterpret_cast<uint16_t*>(smem + row * OS + (32 * nb + li) * 2) = (uint16_t)f32_to_bf16_bits(acc[i][nb][r] + bias_v[nb]);
-        }
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + 32 * nb + li;
+    bias_v[nb] = (p.bias && n < p.Co) ? bf16_bits_to_f32(p.bias[n]) : 0.f;
   }
-  __syncthreads();
-  const int w = w0 + tid;
-  if (w < p.Wo) {
-    const int half_c = p.Co >> 1;
-    int64_t o;
-    if (p.interleave) {
-      const int kk = n0 >= half_c ? 1 : 0;
-      o = (int64_t)b * p.ys_b + ((((int64_t)(2 * t + kk)) * p.Ho + h) * p.Wo + w) * half_c + (n0 - kk * half_c);
-    } else {
-      o = (int64_t)b * p.ys_b + (((int64_t)t * p.Ho + h) * p.Wo + w) * p.Co + n0;
+  const int half_c = p.Co >> 1;
+#pragma unroll
+  for (int q = 0; q < BM / 256; ++q) {
+    __syncthreads();   // the K loop's (or the previous pass's) LDS contents are no longer needed
+    if ((32 * WR * wave) / 256 == q) {
+      const int rbase = 32 * WR * wave - 256 * q;
+#pragma unroll
+      for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            *reinterpret_cast<uint16_t*>(smem + row * OS + (32 * nb + li) * 2) = (uint16_t)f32_to_bf16_bits(acc[i][nb][r] + bias_v[nb]);
+          }
     }
-    const char* orow = smem + tid * OS;
-    if (n0 + NR <= p.Co) {
-#pragma unroll
-      for (int v = 0; v < NR / 8; ++v) {
-        uint4 ov = *reinterpret_cast<const uint4*>(orow + 16 * v);
-        if (p.res) {
-          const uint4 rv = *reinterpret_cast<const uint4*>(p.res + o + 8 * v);
-          float a[8], c[8];
-          unpack8<TD_BF16>(ov, a);
-          unpack8<TD_BF16>(rv, c);
-          uint32_t q[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) q[j] = f32_to_bf16_bits(a[j] + c[j]);
-          ov.x = q[0] | (q[1] << 16); ov.y = q[2] | (q[3] << 16); ov.z = q[4] | (q[5] << 16); ov.w = q[6] | (q[7] << 16);
-        }
-        *reinterpret_cast<uint4*>(p.y + o + 8 * v) = ov;
+    __syncthreads();
+    const int w = w0 + 256 * q + tid;
+    if (w < p.Wo) {
+      int64_t o;
+      if (p.interleave) {
+        const int kk = n0 >= half_c ? 1 : 0;
+        o = (int64_t)b * p.ys_b + ((((int64_t)(2 * t + kk)) * p.Ho + h) * p.Wo + w) * half_c + (n0 - kk * half_c);
+      } else {
+        o = (int64_t)b * p.ys_b + (((int64_t)t * p.Ho + h) * p.Wo + w) * p.Co + n0;
       }
-    } else {   // a partial channel tile (the 3-channel head): element stores
-      for (int c = 0; n0 + c < p.Co; ++c) {
-        float v = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(orow + 2 * c));
-        if (p.res) v = round_bf16(v + bf16_bits_to_f32(p.res[o + c]));
-        p.y[o + c] = (uint16_t)f32_to_bf16_bits(v);
+      const char* orow = smem + tid * OS;
+      if (n0 + NR <= p.Co) {
+#pragma unroll
+        for (int v = 0; v < NR / 8; ++v) {
+          uint4 ov = *reinterpret_cast<const uint4*>(orow + 16 * v);
+          if (p.res) {
+            const uint4 rv = *reinterpret_cast<const uint4*>(p.res + o + 8 * v);
+            float a[8], c[8];
+            unpack8<TD_BF16>(ov, a);
+            unpack8<TD_BF16>(rv, c);
+            uint32_t qq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qq[j] = f32_to_bf16_bits(a[j] + c[j]);
+            ov.x = qq[0] | (qq[1] << 16); ov.y = qq[2] | (qq[3] << 16); ov.z = qq[4] | (qq[5] << 16); ov.w = qq[6] | (qq[7] << 16);
+          }
+          *reinterpret_cast<uint4*>(p.y + o + 8 * v) = ov;
+        }
+      } else {   // a partial channel tile (the 3-channel head): element stores
+        for (int c = 0; n0 + c < p.Co; ++c) {
+          float v = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(orow + 2 * c));
+          if (p.res) v = round_bf16(v + bf16_bits_to_f32(p.res[o + c]));
+          p.y[o + c] = (uint16_t)f32_to_bf16_bits(v);
+        }
       }
     }
   }
@@ -418,18 +428,25 @@ extern "C" int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void*
   const bool v2_ok = plain && (Co % 16 == 0 || Co <= 32) && (!interleave || (Co / 2) % (32 * nbw) == 0) &&
                      (int64_t)y_batch_stride % 8 == 0;
   if (td_tuning(TD_TUNE_VAE_CONV) != 1 && v2_ok) {
-    const int64_t t2 = (int64_t)B * p.To * p.Ho * td_cdiv(p.Wo, VC_BM) * td_cdiv(Co, 32 * nbw);
+    const bool wide = nbw == 3 && td_tuning(TD_TUNE_VAE_CONV) == 3;   // measured slower (549 vs 700 TFLOP/s at 480p): opt-in
+    const int bm = wide ? 512 : 256;
+    const int64_t t2 = (int64_t)B * p.To * p.Ho * td_cdiv(p.Wo, bm) * td_cdiv(Co, 32 * nbw);
     TD_REQUIRE(t2 < (1ll << 31), TD_ERR_UNSUPPORTED, "td_vae_conv: %lld tiles", (long long)t2);
     if (nbw == 1) {
-      constexpr int lds = (VC2_AROWS + 3 * 32) * VC_ROWB;
+      constexpr int lds = (264 + 3 * 32) * VC_ROWB;
       static std::atomic<uint64_t> m21{0};
-      td_ensure_dyn_lds((const void*)vae_conv2_kernel<1>, lds, m21);
-      vae_conv2_kernel<1><<<(unsigned)t2, 256, lds, st>>>(p);
-    } else {
-      constexpr int lds = (VC2_AROWS + 3 * 96) * VC_ROWB;
+      td_ensure_dyn_lds((const void*)vae_conv2_kernel<1, 2>, lds, m21);
+      vae_conv2_kernel<1, 2><<<(unsigned)t2, 256, lds, st>>>(p);
+    } else if (!wide) {
+      constexpr int lds = (264 + 3 * 96) * VC_ROWB;
       static std::atomic<uint64_t> m23{0};
-      td_ensure_dyn_lds((const void*)vae_conv2_kernel<3>, lds, m23);
-      vae_conv2_kernel<3><<<(unsigned)t2, 256, lds, st>>>(p);
+      td_ensure_dyn_lds((const void*)vae_conv2_kernel<3, 2>, lds, m23);
+      vae_conv2_kernel<3, 2><<<(unsigned)t2, 256, lds, st>>>(p);
+    } else {
+      constexpr int lds = (520 + 3 * 96) * VC_ROWB;
+      static std::atomic<uint64_t> m43{0};
+      td_ensure_dyn_lds((const void*)vae_conv2_kernel<3, 4>, lds, m43);
+      vae_conv2_kernel<3, 4><<<(unsigned)t2, 256, lds, st>>>(p);
     }
     TD_CHECK_LAUNCH();
     return TD_OK;
