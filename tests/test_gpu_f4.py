@@ -250,3 +250,45 @@ def test_image_and_prompt_to_video_runs_the_i2v_data_path():
     assert v1.shape == (1, 3, 13, 128, 128) and torch.isfinite(v1).all() and 0.0 <= float(v1.min()) and float(v1.max()) <= 1.0
     v2 = i2v(text, nets[0], nets[0], enc, dec, ids, mask, img, num_frames=13, seed=4, device=DEV)
     assert not torch.equal(v1, v2)            # the low-noise expert took over after the boundary
+
+
+@pytest.mark.parametrize("case", ["3x3x3 + residual", "up2"])
+def test_vae_conv_at_the_480p_clip_size_sampled_positions(K, case):
+    """The real extents of a 480p clip (tensors of 3-6 GB: every offset beyond 32 bits): sampled output positions — corners,
+    borders, the first and last frame, random interior — against a direct fp32 evaluation of the 27 (9) taps."""
+    g = torch.Generator(device=DEV).manual_seed(7)
+    if case == "up2":
+        B, T, H, W, Ci, Co, k, up2 = 1, 81, 240, 416, 192, 96, (1, 3, 3), True
+    else:
+        B, T, H, W, Ci, Co, k, up2 = 1, 81, 480, 832, 96, 96, (3, 3, 3), False
+    x = torch.randn(B, T, H, W, Ci, device=DEV, generator=g, dtype=torch.bfloat16)
+    w = (torch.randn(Co, k[0] * k[1] * k[2] * Ci, device=DEV, generator=g) / (k[0] * k[1] * k[2] * Ci) ** 0.5).bfloat16()
+    b = (0.1 * torch.randn(Co, device=DEV, generator=g)).bfloat16()
+    Ho, Wo = (2 * H, 2 * W) if up2 else (H, W)
+    res = None if up2 else torch.randn(B, T, Ho, Wo, Co, device=DEV, generator=g, dtype=torch.bfloat16)
+    out = K.vae_conv(x, w, b, *k, res=res, up2=up2)
+    assert out.shape == (B, T, Ho, Wo, Co)
+    gi = torch.Generator().manual_seed(3)
+    pts = [(0, 0, 0), (T - 1, Ho - 1, Wo - 1), (0, Ho - 1, 0), (T - 1, 0, Wo - 1), (1, 1, 1), (T - 1, Ho // 2, Wo - 1), (40, 0, 255), (40, 7, 256)]
+    pts += [(int(torch.randint(0, T, (1,), generator=gi)), int(torch.randint(0, Ho, (1,), generator=gi)),
+             int(torch.randint(0, Wo, (1,), generator=gi))) for _ in range(120)]
+    w5 = w.float().reshape(Co, k[0], k[1], k[2], Ci)
+    worst = 0.0
+    for (t, h, ww) in pts:
+        acc = b.float().clone()
+        for dt in range(k[0]):
+            for dh in range(k[1]):
+                for dw in range(k[2]):
+                    ts, hu, wu = t - (k[0] - 1) + dt, h + dh - k[1] // 2, ww + dw - k[2] // 2
+                    if ts < 0 or hu < 0 or hu >= Ho or wu < 0 or wu >= Wo:
+                        continue
+                    src = x[0, ts, hu >> 1 if up2 else hu, wu >> 1 if up2 else wu].float()
+                    acc += w5[:, dt, dh, dw] @ src
+        ref = acc.bfloat16().float()
+        if res is not None:
+            ref = (ref + res[0, t, h, ww].float()).bfloat16().float()
+        got = out[0, t, h, ww].float()
+        err = (got - ref).abs()
+        worst = max(worst, float(err.max()))
+        assert (err <= ref.abs() * 2.0 ** -7 + (2.0 ** -6 if res is not None else 1e-3)).all(), ((t, h, ww), float(err.max()))
+    print(f"\n[td_vae_conv at the 480p size, {case}] {len(pts)} positions, worst |diff| {worst:.4f}")
