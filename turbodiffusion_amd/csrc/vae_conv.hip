@@ -482,35 +482,68 @@ extern "C" int td_vae_conv(const void* x, int64_t x_batch_stride, const void* w,
 template <int G>
 __global__ __launch_bounds__(256) void vae_chan_rms_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ gamma,
                                                            uint16_t* __restrict__ y, int64_t rows, int C, float scale, int silu) {
-  constexpr int RPB = 256 / G;
+  constexpr int RPB = 256 / G;   // rows per pass of the block
+  constexpr int R = 8;           // passes per block: eight 16-byte loads in flight per lane (one row per lane group and pass
+                                 // left the kernel at 1.7-2 TB/s: too few bytes in flight per CU)
   const int sub = threadIdx.x % G;
-  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
-  const bool live = row < rows && sub * 8 < C;
-  float f[8];
+  const int64_t row0 = (int64_t)blockIdx.x * (RPB * R) + threadIdx.x / G;
+  const bool lane_live = sub * 8 < C;
+  uint4 v[R];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) f[j] = 0.f;
-  if (live) unpack8<TD_BF16>(*reinterpret_cast<const uint4*>(x + row * C + sub * 8), f);
-  float ss = 0.f;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
-#pragma unroll
-  for (int o = G / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
-  const float nrm = fmaxf(round_bf16(sqrtf(ss)), 1e-12f);
-  if (!live) return;
-  float g[8];
-  unpack8<TD_BF16>(*reinterpret_cast<const uint4*>(gamma + sub * 8), g);
-  uint32_t o16[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float q = round_bf16(f[j] / nrm);
-    q = round_bf16(q * scale);
-    q = round_bf16(q * g[j]);
-    if (silu) q = round_bf16(q / (1.0f + __expf(-q)));
-    o16[j] = f32_to_bf16_bits(q);
+  for (int i = 0; i < R; ++i) {
+    const int64_t row = row0 + (int64_t)i * RPB;
+    v[i] = (lane_live && row < rows) ? *reinterpret_cast<const uint4*>(x + row * C + sub * 8) : make_uint4(0u, 0u, 0u, 0u);
   }
-  uint4 ov;
-  ov.x = o16[0] | (o16[1] << 16); ov.y = o16[2] | (o16[3] << 16); ov.z = o16[4] | (o16[5] << 16); ov.w = o16[6] | (o16[7] << 16);
-  *reinterpret_cast<uint4*>(y + row * C + sub * 8) = ov;
+  float g[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) g[j] = 0.f;
+  if (lane_live) unpack8<TD_BF16>(*reinterpret_cast<const uint4*>(gamma + sub * 8), g);
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int64_t row = row0 + (int64_t)i * RPB;
+    float f[8];
+    unpack8<TD_BF16>(v[i], f);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+#pragma unroll
+    for (int o = G / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float nrm = fmaxf(round_bf16(sqrtf(ss)), 1e-12f);
+    if (lane_live && row < rows) {
+      // x / nrm correctly rounded without the division sequence: rinv = RN(1 / nrm) by one Newton step on v_rcp_f32, then
+      // Markstein's correction (as in sla_prep.hip); every rounding to bf16 is the hardware pack (v_cvt_pk_bf16_f32), two
+      // elements per instruction.  (The kernel is VALU-bound, not HBM-bound: with IEEE divisions and software rounding it
+      // ran at 2 TB/s.)
+      float rinv = __builtin_amdgcn_rcpf(nrm);
+      rinv = fmaf(fmaf(-nrm, rinv, 1.0f), rinv, rinv);
+      uint32_t o16[8];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        float q0, q1;
+        {
+          const float a0 = f[j] * rinv, a1 = f[j + 1] * rinv;
+          q0 = fmaf(fmaf(-a0, nrm, f[j]), rinv, a0);
+          q1 = fmaf(fmaf(-a1, nrm, f[j + 1]), rinv, a1);
+        }
+        unpack2<TD_BF16>(pack2<TD_BF16>(q0, q1), q0, q1);
+        unpack2<TD_BF16>(pack2<TD_BF16>(q0 * scale, q1 * scale), q0, q1);
+        uint32_t w = pack2<TD_BF16>(q0 * g[j], q1 * g[j + 1]);
+        if (silu) {
+          unpack2<TD_BF16>(w, q0, q1);
+          // silu(q) = q / (1 + exp(-q)) = q * rcp(1 + exp2(-q * log2 e)); v_exp / v_rcp are within 1 ulp of fp32, far inside
+          // the bf16 rounding that follows
+          q0 = q0 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * q0));
+          q1 = q1 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * q1));
+          w = pack2<TD_BF16>(q0, q1);
+        }
+        o16[j] = w & 0xffffu;
+        o16[j + 1] = w >> 16;
+      }
+      uint4 ov;
+      ov.x = o16[0] | (o16[1] << 16); ov.y = o16[2] | (o16[3] << 16); ov.z = o16[4] | (o16[5] << 16); ov.w = o16[6] | (o16[7] << 16);
+      *reinterpret_cast<uint4*>(y + row * C + sub * 8) = ov;
+    }
+  }
 }
 
 extern "C" int td_vae_chan_rms(const void* x, const void* gamma, void* y, int64_t rows, int C, int silu, td_stream_t stream) {
@@ -518,9 +551,9 @@ extern "C" int td_vae_chan_rms(const void* x, const void* gamma, void* y, int64_
   TD_REQUIRE(rows > 0 && C >= 8 && C % 8 == 0 && C <= 512, TD_ERR_UNSUPPORTED, "td_vae_chan_rms: rows=%lld C=%d (multiple of 8, <= 512)", (long long)rows, C);
   const float scale = sqrtf((float)C);
   hipStream_t st = (hipStream_t)stream;
-  if (C <= 128) vae_chan_rms_kernel<16><<<(unsigned)td_cdiv(rows, 16), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
-  else if (C <= 256) vae_chan_rms_kernel<32><<<(unsigned)td_cdiv(rows, 8), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
-  else vae_chan_rms_kernel<64><<<(unsigned)td_cdiv(rows, 4), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
+  if (C <= 128) vae_chan_rms_kernel<16><<<(unsigned)td_cdiv(rows, 16 * 8), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
+  else if (C <= 256) vae_chan_rms_kernel<32><<<(unsigned)td_cdiv(rows, 8 * 8), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
+  else vae_chan_rms_kernel<64><<<(unsigned)td_cdiv(rows, 4 * 8), 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)gamma, (uint16_t*)y, rows, C, scale, silu);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
