@@ -210,14 +210,23 @@ __global__ __launch_bounds__(256, 2) void vae_conv_kernel(VaeConvP p) {
 // 512-register file of a single wave per SIMD — built to test whether LDS bandwidth is what bounds the kernel: it is not, the
 // 96-channel level runs at 549 instead of 700 TFLOP/s (one wave per SIMD has nothing to run beside its own LDS writes and
 // barriers).  Kept selectable (TD_TUNE_VAE_CONV = 3) and tested.
-template <int NB, int WR>
+// KC = channels per K chunk: 64 -> 128-byte LDS rows, ONE stage, two barriers per chunk (write phase, then multiply); 32 -> 64-byte
+// rows (slot swizzle by (row >> 2) & 3), TWO stages in the same 70 KB: chunk j + 1 is written to the other stage at the top of
+// iteration j (its global loads were issued an iteration earlier) while everyone multiplies chunk j — one barrier per chunk
+// and no wave waits for another's LDS writes before it may start its MFMAs.
+template <int KC> __device__ __forceinline__ uint32_t vc2_off(uint32_t row, uint32_t slot) {
+  if constexpr (KC == 64) return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
+  else return row * 64u + ((slot ^ ((row >> 2) & 3u)) << 4);
+}
+template <int NB, int WR, int KC = 64>
 __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConvP p) {
   constexpr int BM = 64 * WR * 2;                // columns per tile: 256 | 512
   constexpr int AROWS = BM + 8;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* a_s = smem;                              // [264][128 B]: LDS row r = column w0 - pw + r of the (up-sampled) source row
-  char* b_s = smem + AROWS * VC_ROWB;           // [kw][32 NB][128 B]
+  constexpr int ROWB = KC * 2, SLOTS = ROWB / 16, RPP = 256 / SLOTS;   // bytes per LDS row, 16-byte slots per row, rows per loader pass
   constexpr int NR = 32 * NB;
+  constexpr int STAGE = (AROWS + 3 * NR) * ROWB;
+  constexpr bool TWO = KC == 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hi = lane >> 5;
@@ -234,23 +243,23 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
   const int64_t ktot = (int64_t)p.halves * 32;
   const uint16_t* xb = p.x + (int64_t)b * p.xs_b;
 
-  // ---- loader roles: vector v = tid + 256 e -> (row tid / 8 + 32 e, 16-byte slot tid % 8) ----
-  const int slot = tid & 7, r8 = tid >> 3;
-  constexpr int AV = BM / 32 + 1;                // rows r8 + 32 e (the last e: rows BM.. : the right halo)
-  constexpr int BVT = (3 * NR * 8 + 255) / 256;  // B vectors per thread for kw = 3 (9 for NB = 3, 3 for NB = 1)
+  // ---- loader roles: vector v = tid + 256 e -> (row tid / SLOTS + RPP e, 16-byte slot tid % SLOTS) ----
+  const int slot = tid % SLOTS, r8 = tid / SLOTS;
+  constexpr int AV = (BM + 2 + RPP - 1) / RPP;   // the last pass: rows BM.. (the right halo)
+  constexpr int BVT = (3 * NR + RPP - 1) / RPP;  // B row passes for kw = 3
   uint4 pa[AV], pb[BVT];
   int a_col[AV];                                 // source column (after the up-sampling shift) or -1
 #pragma unroll
   for (int e = 0; e < AV; ++e) {
-    const int r = r8 + 32 * e, wu = w0 - pw + r;
+    const int r = r8 + RPP * e, wu = w0 - pw + r;
     const bool ok = r < BM + 2 * pw && wu >= 0 && wu < p.Wo;
     a_col[e] = ok ? (p.up2 ? (wu >> 1) : wu) : -1;
   }
-  const int nbv = p.kw * NR * 8;                 // B vectors in use
+  const int nbr = p.kw * NR;                     // B rows in use
   int64_t b_off[BVT];                            // element offset of (row n, tap dw) within the weights, without (dt, dh, c0)
 #pragma unroll
   for (int e = 0; e < BVT; ++e) {
-    const int ridx = r8 + 32 * e, dw = ridx / NR;
+    const int ridx = r8 + RPP * e, dw = ridx / NR;
     int n = n0 + (ridx - dw * NR);
     if (n >= p.Co) n = p.Co - 1;
     b_off[e] = (int64_t)n * ktot + (int64_t)dw * p.Ci + slot * 8;
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
       for (int r = 0; r < 16; ++r) acc[i][nb][r] = 0.f;
 
   // ---- the list of iterations (dt, dh, c0) whose source row exists ----
-  const int nc = (p.Ci + 63) >> 6;
+  const int nc = (p.Ci + KC - 1) / KC;
   int it_dt = 0, it_dh = 0, it_c = 0;            // position of the NEXT iteration to fetch
   auto row_ok = [&](int dt, int dh) {
     const int ts = t - (p.kt - 1) + dt, hu = h + dh - ph;
@@ -278,12 +287,12 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
     }
     return it_dt < p.kt;
   };
-  int f_kc = 0;                                  // channels of the fetched iteration (64 or the tail)
+  int f_kc = 0;                                  // channels of the fetched iteration (KC or the tail)
   auto fetch = [&]() {
     const int ts = t - (p.kt - 1) + it_dt, hu = h + it_dh - ph;
     const int hs = p.up2 ? (hu >> 1) : hu;
-    const int c0 = it_c * 64;
-    f_kc = min(64, p.Ci - c0);
+    const int c0 = it_c * KC;
+    f_kc = min(KC, p.Ci - c0);
     const uint16_t* srow = xb + (((int64_t)ts * p.Hi + hs) * p.Wi) * p.Ci + c0 + slot * 8;
     const bool sl_ok = slot * 8 < f_kc;
 #pragma unroll
@@ -292,47 +301,78 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
     const int64_t kbase = (int64_t)((it_dt * p.kh + it_dh) * p.kw) * p.Ci + c0;
 #pragma unroll
     for (int e = 0; e < BVT; ++e)
-      pb[e] = (sl_ok && tid + 256 * e < nbv) ? *reinterpret_cast<const uint4*>(p.w + b_off[e] + kbase) : make_uint4(0u, 0u, 0u, 0u);
+      pb[e] = (sl_ok && r8 + RPP * e < nbr) ? *reinterpret_cast<const uint4*>(p.w + b_off[e] + kbase) : make_uint4(0u, 0u, 0u, 0u);
     if (++it_c == nc) {
       it_c = 0;
       if (++it_dh == p.kh) { it_dh = 0; ++it_dt; }
     }
   };
-
-  bool have = advance_to_valid();
-  if (have) fetch();
-  while (have) {
-    const int kc = f_kc;
-    __syncthreads();   // the previous iteration has been multiplied by every wave
+  auto store = [&](char* st) {                   // the fetched chunk -> LDS stage st
+    char* a_w = st;
+    char* b_w = st + AROWS * ROWB;
 #pragma unroll
     for (int e = 0; e < AV; ++e) {
-      const int r = r8 + 32 * e;
-      if (r < AROWS) *reinterpret_cast<uint4*>(a_s + vc_off(r, slot)) = pa[e];
+      const int r = r8 + RPP * e;
+      if (r < AROWS) *reinterpret_cast<uint4*>(a_w + vc2_off<KC>(r, slot)) = pa[e];
     }
 #pragma unroll
     for (int e = 0; e < BVT; ++e)
-      if (tid + 256 * e < nbv) *reinterpret_cast<uint4*>(b_s + vc_off(r8 + 32 * e, slot)) = pb[e];
-    __syncthreads();
-    have = advance_to_valid();
-    if (have) fetch();
+      if (r8 + RPP * e < nbr) *reinterpret_cast<uint4*>(b_w + vc2_off<KC>(r8 + RPP * e, slot)) = pb[e];
+  };
+  // a wave whose columns all lie past the end of the image row (the last tile of a row: 832 = 3 x 256 + 64) only helps load
+  const bool wave_live = w0 + 32 * WR * wave < p.Wo;
+  auto multiply = [&](const char* st, int kc) {
+    const char* a_r = st;
+    const char* b_r = st + AROWS * ROWB;
     const int nks = kc >> 4;
-    // a wave whose 64 columns all lie past the end of the image row (the last tile of a row: 832 = 3 x 256 + 64) only helps load
-    if (w0 + 32 * WR * wave < p.Wo)
-    for (int dw = 0; dw < p.kw; ++dw) {
+    if (wave_live)
+      for (int dw = 0; dw < p.kw; ++dw) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < nks) {
-          v8bf af[WR], bf[NB];
+        for (int ks = 0; ks < KC / 16; ++ks) {
+          if (ks < nks) {
+            v8bf af[WR], bf[NB];
 #pragma unroll
-          for (int i = 0; i < WR; ++i) af[i] = *reinterpret_cast<const v8bf*>(a_s + vc_off(32 * WR * wave + 32 * i + li + dw, 2 * ks + hi));
+            for (int i = 0; i < WR; ++i) af[i] = *reinterpret_cast<const v8bf*>(a_r + vc2_off<KC>(32 * WR * wave + 32 * i + li + dw, 2 * ks + hi));
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const v8bf*>(b_s + vc_off(dw * NR + 32 * nb + li, 2 * ks + hi));
+            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const v8bf*>(b_r + vc2_off<KC>(dw * NR + 32 * nb + li, 2 * ks + hi));
 #pragma unroll
-          for (int i = 0; i < WR; ++i)
+            for (int i = 0; i < WR; ++i)
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[nb], acc[i][nb], 0, 0, 0);
+              for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[nb], acc[i][nb], 0, 0, 0);
+          }
         }
       }
+  };
+
+  if constexpr (!TWO) {
+    bool have = advance_to_valid();
+    if (have) fetch();
+    while (have) {
+      const int kc = f_kc;
+      __syncthreads();   // the previous iteration has been multiplied by every wave
+      store(smem);
+      __syncthreads();
+      have = advance_to_valid();
+      if (have) fetch();
+      multiply(smem, kc);
+    }
+  } else {
+    bool in_regs = advance_to_valid();            // (always true: the centre tap's row exists)
+    fetch();
+    store(smem);
+    in_regs = advance_to_valid();
+    if (in_regs) fetch();
+    __syncthreads();
+    int cur = 0;
+    while (true) {
+      const bool has_next = in_regs;
+      if (has_next) store(smem + (cur ^ 1) * STAGE);   // its last readers passed the barrier that ended the previous iteration
+      in_regs = has_next && advance_to_valid();
+      if (in_regs) fetch();
+      multiply(smem + cur * STAGE, KC);
+      __syncthreads();   // stage cur may be overwritten; the stores to the other stage are visible
+      if (!has_next) break;
+      cur ^= 1;
     }
   }
 
@@ -437,6 +477,11 @@ extern "C" int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void*
       static std::atomic<uint64_t> m21{0};
       td_ensure_dyn_lds((const void*)vae_conv2_kernel<1, 2>, lds, m21);
       vae_conv2_kernel<1, 2><<<(unsigned)t2, 256, lds, st>>>(p);
+    } else if (!wide && td_tuning(TD_TUNE_VAE_CONV) == 4) {
+      constexpr int lds = 2 * (264 + 3 * 96) * 64;
+      static std::atomic<uint64_t> m232{0};
+      td_ensure_dyn_lds((const void*)vae_conv2_kernel<3, 2, 32>, lds, m232);
+      vae_conv2_kernel<3, 2, 32><<<(unsigned)t2, 256, lds, st>>>(p);
     } else if (!wide) {
       constexpr int lds = (264 + 3 * 96) * VC_ROWB;
       static std::atomic<uint64_t> m23{0};
