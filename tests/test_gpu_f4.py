@@ -46,7 +46,7 @@ def _conv_ref(x, w, b, kt, kh, kw, res=None, up2=False, interleave=False):
     return y
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 3, 4])   # default (row tiles) | the first kernel | 512-column tiles | 32-channel chunks, two LDS stages
+@pytest.mark.parametrize("kernel", [0, 1, 3, 4, 6])   # default (row tiles) | first kernel | 512-column tiles | two LDS stages | two stages + unrolled multiply
 @pytest.mark.parametrize("case", ["3x3x3", "residual+tail", "up2", "time-interleave", "head", "1x3x3 Ci96", "wide rows", "time-interleave 192"])
 def test_vae_conv_kernel_vs_torch(K, case, kernel):
     """td_vae_conv (implicit GEMM on the bf16 matrix pipe, csrc/vae_conv.hip) against an fp32 torch convolution of the same

@@ -35,6 +35,7 @@ struct VaeConvP {
   int64_t M;              // B * To * Ho * Wo
   int halves;             // taps * Ci / 32
   int st, ss;             // output strides in time / space (the encoder's down-samplers: 2); 1 = plain
+  int t_fast;             // row-tile kernel: tile order (w tiles, FRAMES, rows) instead of (w tiles, rows, frames)
   int pt, ph, pw;         // zero frames / rows / columns on the LEFT (kt - 1, kh / 2, kw / 2 = causal in time, centred in space;
                           // the encoder's ZeroPad2d((0, 1, 0, 1)) and its unpadded stride-2 time convolution pass 0); whatever the
                           // output grid reaches beyond the right edge is zero too
@@ -218,7 +219,10 @@ template <int KC> __device__ __forceinline__ uint32_t vc2_off(uint32_t row, uint
   if constexpr (KC == 64) return row * 128u + ((slot ^ ((row >> 1) & 7u)) << 4);
   else return row * 64u + ((slot ^ ((row >> 2) & 3u)) << 4);
 }
-template <int NB, int WR, int KC = 64>
+// KW > 0 (with KC = 32): the tap count along w as a compile-time constant — the whole multiply of a chunk (KW x 2 k-steps) is ONE
+// basic block, so the fragment reads of a k-step can be scheduled over the MFMAs of the one before (with run-time bounds every
+// k-step is its own block: five reads, a wait, six MFMAs, nothing overlapping within the wave).
+template <int NB, int WR, int KC = 64, int KW = 0>
 __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConvP p) {
   constexpr int BM = 64 * WR * 2;                // columns per tile: 256 | 512
   constexpr int AROWS = BM + 8;
@@ -236,9 +240,18 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
   bid /= tiles_n;
   const int w0 = (int)(bid % tiles_w) * BM;
   bid /= tiles_w;
-  const int h = (int)(bid % p.Ho);
-  bid /= p.Ho;
-  const int t = (int)(bid % p.To), b = (int)(bid / p.To);
+  int h, t, b;
+  if (p.t_fast) {   // frames of one image row first: the (dt) neighbours of a tile are being read by the workgroups beside it
+    t = (int)(bid % p.To);
+    bid /= p.To;
+    h = (int)(bid % p.Ho);
+    b = (int)(bid / p.Ho);
+  } else {
+    h = (int)(bid % p.Ho);
+    bid /= p.Ho;
+    t = (int)(bid % p.To);
+    b = (int)(bid / p.To);
+  }
   const int ph = p.kh >> 1, pw = p.kw >> 1;
   const int64_t ktot = (int64_t)p.halves * 32;
   const uint16_t* xb = p.x + (int64_t)b * p.xs_b;
@@ -325,7 +338,24 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
     const char* a_r = st;
     const char* b_r = st + AROWS * ROWB;
     const int nks = kc >> 4;
-    if (wave_live)
+    if constexpr (KW > 0) {
+      if (wave_live) {
+#pragma unroll
+        for (int dw = 0; dw < KW; ++dw)
+#pragma unroll
+          for (int ks = 0; ks < KC / 16; ++ks) {
+            v8bf af[WR], bf[NB];
+#pragma unroll
+            for (int i = 0; i < WR; ++i) af[i] = *reinterpret_cast<const v8bf*>(a_r + vc2_off<KC>(32 * WR * wave + 32 * i + li + dw, 2 * ks + hi));
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) bf[nb] = *reinterpret_cast<const v8bf*>(b_r + vc2_off<KC>(dw * NR + 32 * nb + li, 2 * ks + hi));
+#pragma unroll
+            for (int i = 0; i < WR; ++i)
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[nb], acc[i][nb], 0, 0, 0);
+          }
+      }
+    } else if (wave_live)
       for (int dw = 0; dw < p.kw; ++dw) {
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
@@ -458,6 +488,7 @@ extern "C" int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void*
   TD_REQUIRE(plain || !interleave, TD_ERR_UNSUPPORTED, "td_vae_conv: the time up-sampler mapping needs the plain geometry");
   p.To = To; p.Ho = Ho; p.Wo = Wo; p.Co = Co;
   p.st = stride_t; p.ss = stride_hw; p.pt = pad_t; p.ph = pad_h; p.pw = pad_w;
+  p.t_fast = td_tuning(TD_TUNE_VAE_CONV) == 5 ? 1 : 0;
   p.kt = kt; p.kh = kh; p.kw = kw; p.up2 = up2; p.interleave = interleave;
   p.M = (int64_t)B * p.To * p.Ho * p.Wo;
   p.halves = kt * kh * kw * (Ci / 32);
@@ -482,6 +513,16 @@ extern "C" int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void*
       static std::atomic<uint64_t> m232{0};
       td_ensure_dyn_lds((const void*)vae_conv2_kernel<3, 2, 32>, lds, m232);
       vae_conv2_kernel<3, 2, 32><<<(unsigned)t2, 256, lds, st>>>(p);
+    } else if (!wide && td_tuning(TD_TUNE_VAE_CONV) == 6 && (kw == 3 || kw == 1)) {
+      constexpr int lds = 2 * (264 + 3 * 96) * 64;
+      static std::atomic<uint64_t> m2323{0}, m2321{0};
+      if (kw == 3) {
+        td_ensure_dyn_lds((const void*)vae_conv2_kernel<3, 2, 32, 3>, lds, m2323);
+        vae_conv2_kernel<3, 2, 32, 3><<<(unsigned)t2, 256, lds, st>>>(p);
+      } else {
+        td_ensure_dyn_lds((const void*)vae_conv2_kernel<3, 2, 32, 1>, lds, m2321);
+        vae_conv2_kernel<3, 2, 32, 1><<<(unsigned)t2, 256, lds, st>>>(p);
+      }
     } else if (!wide) {
       constexpr int lds = (264 + 3 * 96) * VC_ROWB;
       static std::atomic<uint64_t> m23{0};
