@@ -429,11 +429,19 @@ def main():
             msk = torch.zeros(1, 512, dtype=torch.long, device=dev)
             msk[0, :64] = 1                                                             # a 64-token prompt
 
+            i2v_enc = img = None
+            if cfg["model_type"] == "i2v":      # the conditioning channels come from the VAE encoder (wan2.2_i2v_infer.py:139-152)
+                from turbodiffusion_amd import vae_encode as VE
+                from turbodiffusion_amd.pipeline import i2v_condition
+                i2v_enc = VE.WanVaeEncoder(VE.synthetic_state_dict(), device=dev)
+                img = torch.rand(1, 3, h, w, device=dev, generator=gi) * 2 - 1
+
             def prompt_to_pixels():
                 emb = enc(ids, msk)
                 if emb.shape[-1] != cfg.get("text_dim", 4096):
                     raise RuntimeError("text width mismatch")
-                z = rcm_sample(run_net, init_noise, emb, num_steps=args.num_steps, generator=g, y=y, sigma_max=sigma_max,
+                yy = y if i2v_enc is None else i2v_condition(i2v_enc, img, 81)
+                z = rcm_sample(run_net, init_noise, emb, num_steps=args.num_steps, generator=g, y=yy, sigma_max=sigma_max,
                                net_low=run_low, boundary=0.9)
                 return vae.decode(z)
 
@@ -444,6 +452,11 @@ def main():
             emb = enc(ids, msk)
             sync()
             ts["umt5_ms"] = (time.perf_counter() - t0) * 1e3
+            if i2v_enc is not None:
+                t0 = time.perf_counter()
+                i2v_condition(i2v_enc, img, 81)
+                sync()
+                ts["vae_encode_ms"] = (time.perf_counter() - t0) * 1e3
             t0 = time.perf_counter()
             z = rcm_sample(run_net, init_noise, emb, num_steps=args.num_steps, generator=g, y=y, sigma_max=sigma_max,
                            net_low=run_low, boundary=0.9)
@@ -459,8 +472,9 @@ def main():
             sync()
             p2p = {"seconds_per_video": (time.perf_counter() - t0) / 3, **{k: round(v, 2) for k, v in ts.items()},
                    "video_shape": list(vid.shape), "finite": bool(torch.isfinite(vid).all()),
-                   "what": "64-token prompt ids -> umT5-XXL (random init) -> 4-step sampling (hipGraph) -> whole-clip VAE decode "
-                           "(random init), all resident; tokenisation and file writing excluded"}
+                   "what": "64-token prompt ids -> umT5-XXL (random init) -> [I2V: image -> VAE encode -> conditioning] -> 4-step "
+                           "sampling (hipGraph) -> whole-clip VAE decode (random init), all resident; tokenisation and file "
+                           "writing excluded"}
             del enc, vae, vid
             torch.cuda.empty_cache()
             phase("prompt-to-pixels leg done")
