@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256, 2) void vae_conv_kernel(VaeConvP p) {
 // 512-register file of a single wave per SIMD — built to test whether LDS bandwidth is what bounds the kernel: it is not, the
 // 96-channel level runs at 549 instead of 700 TFLOP/s (one wave per SIMD has nothing to run beside its own LDS writes and
 // barriers).  Kept selectable (TD_TUNE_VAE_CONV = 3) and tested.
+typedef unsigned int vc_u4 __attribute__((ext_vector_type(4)));
 // KC = channels per K chunk: 64 -> 128-byte LDS rows, ONE stage, two barriers per chunk (write phase, then multiply); 32 -> 64-byte
 // rows (slot swizzle by (row >> 2) & 3), TWO stages in the same 70 KB: chunk j + 1 is written to the other stage at the top of
 // iteration j (its global loads were issued an iteration earlier) while everyone multiplies chunk j — one barrier per chunk
@@ -222,8 +223,11 @@ template <int KC> __device__ __forceinline__ uint32_t vc2_off(uint32_t row, uint
 // KW > 0 (with KC = 32): the tap count along w as a compile-time constant — the whole multiply of a chunk (KW x 2 k-steps) is ONE
 // basic block, so the fragment reads of a k-step can be scheduled over the MFMAs of the one before (with run-time bounds every
 // k-step is its own block: five reads, a wait, six MFMAs, nothing overlapping within the wave).
+// (amdgpu_waves_per_eu: LDS allows two workgroups per CU whatever the registers; without the pin the compiler spills the
+// prefetch registers to scratch to reach the 168 VGPRs of three waves per SIMD.)
 template <int NB, int WR, int KC = 64, int KW = 0>
-__global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConvP p) {
+__global__ __launch_bounds__(256, WR == 4 ? 1 : 2) __attribute__((amdgpu_waves_per_eu(WR == 4 ? 1 : 2, WR == 4 ? 1 : 2)))
+void vae_conv2_kernel(VaeConvP p) {
   constexpr int BM = 64 * WR * 2;                // columns per tile: 256 | 512
   constexpr int AROWS = BM + 8;
   constexpr int ROWB = KC * 2, SLOTS = ROWB / 16, RPP = 256 / SLOTS;   // bytes per LDS row, 16-byte slots per row, rows per loader pass
@@ -260,22 +264,39 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
   const int slot = tid % SLOTS, r8 = tid / SLOTS;
   constexpr int AV = (BM + 2 + RPP - 1) / RPP;   // the last pass: rows BM.. (the right halo)
   constexpr int BVT = (3 * NR + RPP - 1) / RPP;  // B row passes for kw = 3
-  uint4 pa[AV], pb[BVT];
-  int a_col[AV];                                 // source column (after the up-sampling shift) or -1
+  vc_u4 pa[AV], pb[BVT];   // (a first-class vector type: arrays of the HIP uint4 STRUCT filled by plain loads stay in scratch)
+  // Loop-invariant 32-bit byte offsets from a UNIFORM base pointer (the source row's start, the weights' (dt, dh, c0) start):
+  // a load is one instruction with no address arithmetic and no branch.  Columns outside the image are never loaded into LDS
+  // (their rows are zeroed once, below, and their stores skipped), so those lanes just read the row's first vector.
+  uint32_t a_off[AV];
+  uint32_t a_mask = 0u;                          // bit e: row r8 + RPP e is a column of the image
 #pragma unroll
   for (int e = 0; e < AV; ++e) {
     const int r = r8 + RPP * e, wu = w0 - pw + r;
     const bool ok = r < BM + 2 * pw && wu >= 0 && wu < p.Wo;
-    a_col[e] = ok ? (p.up2 ? (wu >> 1) : wu) : -1;
+    a_mask |= ok ? (1u << e) : 0u;
+    const int col = ok ? (p.up2 ? (wu >> 1) : wu) : 0;
+    a_off[e] = (uint32_t)(col * p.Ci) * 2u;
   }
   const int nbr = p.kw * NR;                     // B rows in use
-  int64_t b_off[BVT];                            // element offset of (row n, tap dw) within the weights, without (dt, dh, c0)
+  uint32_t b_off[BVT];                           // byte offset of (row n, tap dw) within the weights, without (dt, dh, c0)
 #pragma unroll
   for (int e = 0; e < BVT; ++e) {
-    const int ridx = r8 + RPP * e, dw = ridx / NR;
+    int ridx = r8 + RPP * e;
+    if (ridx >= nbr) ridx = nbr - 1;             // rows past the taps in use are never read: any valid address will do
+    const int dw = ridx / NR;
     int n = n0 + (ridx - dw * NR);
     if (n >= p.Co) n = p.Co - 1;
-    b_off[e] = (int64_t)n * ktot + (int64_t)dw * p.Ci + slot * 8;
+    b_off[e] = (uint32_t)((int64_t)n * ktot + (int64_t)dw * p.Ci) * 2u;
+  }
+  // zero the A rows of both stages once: out-of-image columns (and the unused tail rows) stay zero for the whole kernel
+  {
+    constexpr int NST = KC == 32 ? 2 : 1;
+    constexpr int STG = (AROWS + 3 * (32 * NB)) * ROWB;
+    for (int st_ = 0; st_ < NST; ++st_)
+      for (int v = tid; v < AROWS * SLOTS; v += 256)
+        *reinterpret_cast<uint4*>(smem + st_ * STG + v * 16) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
   }
 
   v16f acc[WR][NB];
@@ -306,15 +327,14 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
     const int hs = p.up2 ? (hu >> 1) : hu;
     const int c0 = it_c * KC;
     f_kc = min(KC, p.Ci - c0);
-    const uint16_t* srow = xb + (((int64_t)ts * p.Hi + hs) * p.Wi) * p.Ci + c0 + slot * 8;
-    const bool sl_ok = slot * 8 < f_kc;
+    // slots past the chunk's channels (the 32-channel tail of C_in = 96) are never read by the multiply: they load slot 0
+    const uint32_t soff = (uint32_t)((slot * 8 < f_kc ? slot : 0) * 16);
+    const char* srow = reinterpret_cast<const char*>(xb + (((int64_t)ts * p.Hi + hs) * p.Wi) * p.Ci + c0);
 #pragma unroll
-    for (int e = 0; e < AV; ++e)
-      pa[e] = (sl_ok && a_col[e] >= 0) ? *reinterpret_cast<const uint4*>(srow + (int64_t)a_col[e] * p.Ci) : make_uint4(0u, 0u, 0u, 0u);
-    const int64_t kbase = (int64_t)((it_dt * p.kh + it_dh) * p.kw) * p.Ci + c0;
+    for (int e = 0; e < AV; ++e) pa[e] = *reinterpret_cast<const vc_u4*>(srow + (a_off[e] + soff));
+    const char* wrow = reinterpret_cast<const char*>(p.w + (int64_t)((it_dt * p.kh + it_dh) * p.kw) * p.Ci + c0);
 #pragma unroll
-    for (int e = 0; e < BVT; ++e)
-      pb[e] = (sl_ok && r8 + RPP * e < nbr) ? *reinterpret_cast<const uint4*>(p.w + b_off[e] + kbase) : make_uint4(0u, 0u, 0u, 0u);
+    for (int e = 0; e < BVT; ++e) pb[e] = *reinterpret_cast<const vc_u4*>(wrow + (b_off[e] + soff));
     if (++it_c == nc) {
       it_c = 0;
       if (++it_dh == p.kh) { it_dh = 0; ++it_dt; }
@@ -326,11 +346,11 @@ __global__ __launch_bounds__(256, WR == 4 ? 1 : 2) void vae_conv2_kernel(VaeConv
 #pragma unroll
     for (int e = 0; e < AV; ++e) {
       const int r = r8 + RPP * e;
-      if (r < AROWS) *reinterpret_cast<uint4*>(a_w + vc2_off<KC>(r, slot)) = pa[e];
+      if ((a_mask >> e) & 1u) *reinterpret_cast<vc_u4*>(a_w + vc2_off<KC>(r, slot)) = pa[e];
     }
 #pragma unroll
     for (int e = 0; e < BVT; ++e)
-      if (r8 + RPP * e < nbr) *reinterpret_cast<uint4*>(b_w + vc2_off<KC>(r8 + RPP * e, slot)) = pb[e];
+      if (r8 + RPP * e < nbr) *reinterpret_cast<vc_u4*>(b_w + vc2_off<KC>(r8 + RPP * e, slot)) = pb[e];
   };
   // a wave whose columns all lie past the end of the image row (the last tile of a row: 832 = 3 x 256 + 64) only helps load
   const bool wave_live = w0 + 32 * WR * wave < p.Wo;
