@@ -19,6 +19,7 @@
 // Epilogue: + bias (fp32) -> bf16 -> optional residual add in bf16 (the reference's rounding points) -> channels-last store;
 // for the time up-sampler the output channel n lands in frame 2 t + n / (N/2), channel n % (N/2).
 #include "td_common.h"
+#include <type_traits>
 
 struct VaeConvP {
   const uint16_t* x;      // [B, Ti, Hi, Wi, Ci] bf16 (batch stride xs_b elements)
@@ -359,11 +360,12 @@ void vae_conv2_kernel(VaeConvP p) {
     const char* b_r = st + AROWS * ROWB;
     const int nks = kc >> 4;
     if constexpr (KW > 0) {
-      if (wave_live) {
+      auto steps = [&](auto nks_c) {
+        constexpr int NKS = decltype(nks_c)::value;
 #pragma unroll
         for (int dw = 0; dw < KW; ++dw)
 #pragma unroll
-          for (int ks = 0; ks < KC / 16; ++ks) {
+          for (int ks = 0; ks < NKS; ++ks) {
             v8bf af[WR], bf[NB];
 #pragma unroll
             for (int i = 0; i < WR; ++i) af[i] = *reinterpret_cast<const v8bf*>(a_r + vc2_off<KC>(32 * WR * wave + 32 * i + li + dw, 2 * ks + hi));
@@ -374,6 +376,10 @@ void vae_conv2_kernel(VaeConvP p) {
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[nb], acc[i][nb], 0, 0, 0);
           }
+      };
+      if (wave_live) {
+        if (KC == 32 || nks == KC / 16) steps(std::integral_constant<int, KC / 16>{});
+        else steps(std::integral_constant<int, 2>{});      // the 32-channel tail chunk of C_in = 96
       }
     } else if (wave_live)
       for (int dw = 0; dw < p.kw; ++dw) {
