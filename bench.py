@@ -5,8 +5,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload turbo|c2|c3|original]
 
 A "step" is one whole video: the 4 DiT forwards + sampler updates on latents already resident in
-HBM (text encoding / VAE are outside the metric, reference README.md:207).  For N > 1 launch with
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``.
+HBM (text encoding / VAE are outside the metric, reference README.md:207).  For N > 1 either launch with
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`` or just run ``python bench.py --gpus N``: without
+a launcher's environment (WORLD_SIZE unset) the script re-executes itself under ``torch.distributed.run`` on 127.0.0.1 and
+passes rank 0's JSON line through.  ``--emulate-rank r/N`` (one GPU): ONE rank's work of an N-way sequence split with locally
+fabricated gathered buffers and no communication — the measured compute term of the scaling table in DESIGN.md §6.
 
 Multi-GPU (one process per GPU, RCCL over xGMI).  BASELINE.json's configs are ONE sample and its north star shards
 the DiT forward by SEQUENCE, so for N > 1 the timed region is one video sharded over all N ranks
@@ -123,13 +126,46 @@ def pmc_traffic(prefixes):
     return (b / n) if n else None
 
 
+_PMC_SOURCES = ("gemm_w8a8_fi.hip", "gemm_w8a8.hip", "gemm_w8a8_m32.hip", "attn.hip", "td_common.h")
+
+
+def kernel_source_digest():
+    """sha1 over the sources of the kernels the PMC summary describes — what tools/pmc_traffic.py stamps into the summary
+    and what ``pmc_meta`` compares (the GPU box has no .git, so a commit hash could not be checked there)."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in _PMC_SOURCES:
+        with open(os.path.join(ROOT, "turbodiffusion_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_meta():
+    """{"traffic_file", "traffic_commit", "traffic_stale"}: which committed counter summary `traffic` came from and
+    whether the GEMM / attention kernel sources are still the ones it was collected on (None: the summary predates the
+    stamp — treat as stale)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")))
+    if not cands:
+        return {}
+    j = json.load(open(cands[-1]))
+    dig = j.get("kernel_source_digest")
+    return {"traffic_file": os.path.relpath(cands[-1], ROOT), "traffic_commit": j.get("commit"),
+            "traffic_stale": (dig != kernel_source_digest()) if dig else None}
+
+
 def cpu_baseline(cfg, lat_shape, topk, reps=3):
-    """Oracle port of the reference's ORIGINAL eager path (config C1: SDPA, plain Linear, eager norms; bit-pinned to the
-    real reference by tests/test_oracle_cpu.py) timed on the host cores on a bounded sample of the same workload:
-    the embeddings once (a forward with 0 blocks) and ONE block of ONE DiT step at the full token count, ``reps`` times
-    (BASELINE.md §3 asks for repetitions; a whole video on these cores is ~45 min, far beyond a default bench run); only
-    the per-block time (median of the repetitions) is extrapolated (x num_layers x 4 steps)."""
+    """The reference's ORIGINAL eager path (config C1: SDPA, plain Linear, eager norms) timed on the host cores on a bounded
+    sample of the same workload: the embeddings once (a forward with 0 blocks) and ONE block of ONE DiT step at the full
+    token count, ``reps`` times (BASELINE.md §3 asks for repetitions; a whole video on these cores is ~45 min, far beyond a
+    default bench run); only the per-block time (median of the repetitions) is extrapolated (x num_layers x 4 steps).
+
+    kind "reference": the reference's own ``WanModel`` (rcm/networks/wan2pt1.py:598-721), imported unmodified through
+    oracle/ref_harness.py — only where the reference tree exists (``TD_REFERENCE_ROOT`` / ``/root/reference``: the build
+    container, never the GPU box).  kind "port": the oracle's restatement of that path (oracle/wan_ref.py), bit-pinned to the
+    real reference by tests/test_oracle_cpu.py.  The record says which one ran."""
     from oracle import wan_ref as W
+    from oracle import ref_harness as RH
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
@@ -140,22 +176,41 @@ def cpu_baseline(cfg, lat_shape, topk, reps=3):
     ctx = torch.randn(1, 512, cfg.get("text_dim", 4096), generator=g).bfloat16()
     t = torch.tensor([[987.654]]).bfloat16()
 
+    kind, nets = "port", None
+    if RH.available() and os.environ.get("TD_CPU_BASELINE", "") != "port":
+        try:
+            nets = {}
+            for nl in (0, 1):
+                cn = dict(cfg, num_layers=nl)
+                sdn = {k: v for k, v in sd.items() if nl or not k.startswith("blocks.")}
+                nets[nl] = RH.reference_wan_from_sd(cn, sdn, act_dtype=torch.bfloat16)
+            kind = "reference"
+        except Exception as e:   # the reference tree is there but does not import here: say so, time the port
+            phase(f"cpu baseline: the reference WanModel could not be built ({e!r}); timing the oracle port")
+            nets = None
+
     def run(nl):
         t0 = time.time()
         with torch.no_grad():
-            W.wan_forward(sd, c1, x, t, ctx, mode="eager", act_dtype=torch.bfloat16, return_tokens=True, num_layers=nl)
+            if nets is not None:
+                nets[nl](x.bfloat16(), t, ctx)
+            else:
+                W.wan_forward(sd, c1, x, t, ctx, mode="eager", act_dtype=torch.bfloat16, return_tokens=True, num_layers=nl)
         return time.time() - t0
 
+    run(0)             # untimed: one-time costs (the reference's rope tables, first-call dispatch) are not the workload
     t_emb = run(0)
     blks = []
     for r in range(reps):
         blks.append(run(1) - t_emb)
-        phase(f"cpu baseline: block repetition {r + 1} of {reps}: {blks[-1]:.1f} s")
+        phase(f"cpu baseline ({kind}): block repetition {r + 1} of {reps}: {blks[-1]:.1f} s")
     blk = sorted(blks)[len(blks) // 2]
     video_s = 4 * (t_emb + cfg["num_layers"] * blk)
-    return {"value": 1.0 / video_s, "unit": "videos/s", "cores": cores, "kind": "port",
+    what = ("the reference's own WanModel (rcm/networks/wan2pt1.py, imported unmodified; bf16 weights, SDPA + nn.Linear)"
+            if kind == "reference" else "oracle eager bf16 DiT (SDPA + nn.Linear; the port pinned bit for bit to the reference)")
+    return {"value": 1.0 / video_s, "unit": "videos/s", "cores": cores, "kind": kind,
             "embeddings_s": t_emb, "block_s": blk, "block_s_repetitions": blks,
-            "sample": f"oracle eager bf16 DiT (SDPA + nn.Linear): embeddings {t_emb:.1f} s (measured once, not "
+            "sample": f"{what}: embeddings + head {t_emb:.1f} s (measured once, not "
                       f"extrapolated) + 1 of {cfg['num_layers']} blocks of 1 of 4 steps at full L, {reps} repetitions "
                       f"({', '.join('%.1f' % b for b in blks)} s; median {blk:.1f} s per block), blocks x{cfg['num_layers']}, steps x4"}
 
@@ -207,6 +262,10 @@ def main():
                     "one captured hipGraph per DiT forward (sequence-parallel runs are always eager)")
     ap.add_argument("--sp", type=int, default=0, help="sequence-parallel group size of the TIMED region (GPUs sharing "
                     "one video); N/sp groups run independent videos.  Default 0 = N: ONE video sharded over all GPUs")
+    ap.add_argument("--emulate-rank", default="", metavar="r/N", help="ONE GPU: run rank r's work of an N-way sequence-parallel "
+                    "split (its token shard, its launches, gathered buffers of the real size filled with copies of its own shard, "
+                    "no communication) and report the measured per-rank time beside a modelled wire term (`emulated_rank`); "
+                    "a measurement tool for DESIGN.md §6 — the line is marked and carries no vs_baseline")
     ap.add_argument("--no-replica-leg", action="store_true", help="N > 1: skip the throughput-mode measurement (N "
                     "independent videos) that follows the timed region")
     ap.add_argument("--prompt-to-pixels", action="store_true", help="N = 1: after the timed region also time the user-visible "
@@ -228,10 +287,31 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(wd, repeat=True, file=sys.stderr, exit=False)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one.  `python bench.py --gpus N` re-executes itself as N ranks under
+        # torch.distributed.run (rendezvous on 127.0.0.1, a free port); the children's stdout / stderr are ours, so rank 0's
+        # ONE JSON line is this process's output; the exit code is the launcher's.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        phase(f"no launcher environment: re-executing as {args.gpus} ranks under torch.distributed.run (port {port})")
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    emu = None
+    if args.emulate_rank:
+        er, en = (int(v) for v in args.emulate_rank.split("/"))
+        assert world == 1 and 0 <= er < en and en > 1, "--emulate-rank r/N runs on ONE GPU, 0 <= r < N, N > 1"
+        emu = (er, en)
     # TD_BENCH_BACKEND=gloo: development rig only — several ranks on the GPUs that exist (one, on the test box), gloo
     # collectives through host memory; exercises every line of the multi-rank path without an 8-GPU node
     backend = os.environ.get("TD_BENCH_BACKEND", "nccl")
@@ -275,6 +355,10 @@ def main():
         seqpar.enable(net, sp_group)
         if net_low is not None:
             seqpar.enable(net_low, sp_group)
+    if emu is not None:
+        from turbodiffusion_amd import seqpar
+        for m_ in filter(None, (net, net_low)):
+            seqpar.enable(m_, seqpar.EmulatedGroup(*emu))
 
     w, h = RES[args.res]
     lat_shape = (1, 16, 21, h // 8, w // 8)  # 81 frames -> 21 latent frames, VAE 8x spatial
@@ -337,7 +421,8 @@ def main():
     box = None
     if rank == 0 and not args.no_box_calibration:
         try:
-            box = box_record(net, cfg, L_tok if sp == 1 else -(-L_tok // 128 // sp) * 128, dev)
+            sp_eff = emu[1] if emu is not None else sp
+            box = box_record(net, cfg, L_tok if sp_eff == 1 else -(-L_tok // 128 // sp_eff) * 128, dev)
             phase(f"box calibration: {box['i8_pops']:.2f} POP/s int8 MFMA, {box['hbm_read_tbps']:.2f} TB/s HBM read, "
                   f"shader clock {box.get('sclk_mhz_gemm', float('nan')):.0f} MHz under the ffn.2 GEMM ({box['sclk_mhz_idle']:.0f} alone)")
         except Exception as e:   # a reported extra
@@ -531,7 +616,8 @@ def main():
                     "traffic": pmc_traffic(("gemm_w8a8_",)), "traffic_unit": "B/launch (HBM-side fetch+write, PMC)",
                     "algorithmic_bytes": sum(m * k + n * k + 2.0 * m * n for (m, n, k) in gs["metas"]) / gs["launches"],
                     "traffic_source": "committed rocprofv3 PMC summary of this command (profiles/, latest round) — not "
-                                      "collected in this run",
+                                      "collected in this run; traffic_stale says whether the kernel sources changed since",
+                    **pmc_meta(),
                     "avg_launch_ms": gs["avg_ms"], "launches": gs["launches"],
                     # GEMM time of one video (events, eager video) over the TIMED video (graph replay); the GEMMs run
                     # back to back on the main stream, so this is the fraction of the step they occupy
@@ -558,10 +644,18 @@ def main():
                          "achieved": fl / t_l / 1e12, "peak": fl / mt / 1e12, "unit": f"TFLOP/s (int8 QK^T + {args.sage_pv} PV, harmonic)",
                          "frac": mt / t_l, "traffic": pmc_traffic(("attn_kernel<true",)),
                          "traffic_unit": "B/launch (HBM-side fetch+write, PMC)",
-                         "streamed_bytes": by, "streamed_GBps": by / t_l / 1e9,
-                         "streamed_note": "K/V tiles re-read per Q block, served by L2 / Infinity Cache — not HBM traffic",
+                         # K/V tiles are re-read per Q block from L2 / the Infinity Cache: that stream is CACHE traffic, not
+                         # HBM traffic — the HBM-side rate is `hbm_frac` below
+                         "cache_streamed_bytes": by, "cache_streamed_GBps": by / t_l / 1e9,
                          "avg_launch_ms": a["avg_ms"], "launches": a["launches"],
                          "share_of_step": a["total_ms"] * 1e-3 / per_video}
+            if roof_attn["traffic"]:
+                # HBM side of the attention kernel: counter bytes per launch / launch time / 8 TB/s.  The north star's ">= 60 %
+                # of the HBM roofline" is NOT met and cannot be by a kernel whose K/V re-reads hit in cache: it is
+                # issue-bound on the matrix / VALU port, so its roofline is `frac` (matrix pipe)
+                roof_attn["hbm_GBps"] = roof_attn["traffic"] / t_l / 1e9
+                roof_attn["hbm_frac"] = roof_attn["traffic"] / t_l / HBM_PEAK
+                roof_attn.update(pmc_meta())
         if roof is None:
             roof = roof_attn
         res = {
@@ -582,7 +676,8 @@ def main():
                                    "(steps: " + "/".join(__import__("turbodiffusion_amd.sampler", fromlist=["x"]).expert_schedule(
                                        args.num_steps, sigma_max, 0.9)) + ")") if net_low is not None else 1,
                        "global_batch": dp,
-                       "parallelism": "single GPU" if world == 1 else (
+                       "parallelism": (f"EMULATION of rank {emu[0]} of {emu[1]} (sequence-parallel) on one GPU" if emu is not None
+                                       else "single GPU") if world == 1 else (
                            f"dp{dp} x sp{sp}: {dp} independent videos, each sharded by sequence over {sp} GPUs "
                            f"(RCCL all-gather of the quantised K/V per layer)" if sp > 1 else f"dp{dp}: {dp} independent videos")},
             "roofline": roof, "roofline_attention": roof_attn,
@@ -591,6 +686,31 @@ def main():
                             "; kernel events from one eager video (full-size launches, token-half split off) after the timed region"
                             if use_graph else "eager enqueue; kernel events inside the timed region"),
         }
+        if use_graph and getattr(run_net, "sp_graph_mode", None):
+            res["launch_mode"] = "hipGraph replay: " + run_net.sp_graph_mode + "; kernel events from one eager video after the timed region"
+            if getattr(run_net, "sp_whole_graph_error", None):
+                res["sp_whole_graph_error"] = run_net.sp_whole_graph_error
+        if emu is not None:
+            from turbodiffusion_amd.seqpar import PackLayout
+            spo = net.seq_parallel.sp
+            at = wl["attention_type"]
+            lay = PackLayout(cfg["num_heads"], spo.per, 128, spo.head_groups, at in ("sage", "sagesla"), at in ("original", "sage"),
+                             torch.bfloat16)
+            pack = lay.gb * lay.G                       # bytes a rank sends to EVERY peer per self-attention layer
+            link = 120e9                                # effective B/s of one xGMI link (153 GB/s peak; full mesh: one link per peer)
+            nl = cfg["num_layers"]
+            wire_layer = pack / link                    # every peer's pack arrives over its own link, all in parallel
+            res["metric"] = "EMULATED rank: " + res["metric"]
+            res["vs_baseline"] = None
+            res["emulated_rank"] = {
+                "rank": emu[0], "of": emu[1], "tokens_of_rank": spo.stop - spo.start, "tokens_per_rank_padded": spo.per,
+                "measured_compute_ms_per_dit_step": per_video * 1e3 / args.num_steps,
+                "pack_bytes_per_layer": pack, "head_groups": lay.G,
+                "modelled_wire_ms_per_dit_step": {"link_GBps": link / 1e9, "fully_exposed": nl * wire_layer * 1e3,
+                                                  "first_head_group_exposed": nl * wire_layer / lay.G * 1e3},
+                "what": "one rank's kernels of an N-way sequence split on one GPU: its token shard, gathered buffers of the real "
+                        "size filled by device copies of its own pack (the HBM writes of the incoming xGMI traffic, NOT overlapped), "
+                        "no communication; the step of a real N-GPU run = this compute term + the exposed part of the wire term"}
         if use_graph and getattr(run_net, "sp_capture_error", None):
             res["launch_mode"] = "eager enqueue (segmented hipGraph capture failed: " + run_net.sp_capture_error + ")"
         if box is not None:

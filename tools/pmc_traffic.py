@@ -44,7 +44,12 @@ def main():
             "write_bytes_per_launch": 1024.0 * sum(w) / max(1, len(w)),
             "fetch_size_raw_kib_per_launch": sum(f) / max(1, len(f)),
         }
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 0 "
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = open(os.path.join(root, ".td_head")).read().strip() if os.path.exists(os.path.join(root, ".td_head")) else None
+    sys.path.insert(0, root)
+    from bench import kernel_source_digest
+    json.dump({"commit": head, "kernel_source_digest": kernel_source_digest(), "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 1 --warmup 0 "
                        "--no-graph; fetch = 2 x FETCH_SIZE x 1024 B (gfx950 16-B-lane correction), write = WRITE_SIZE x 1024 B; "
                        "Infinity-Cache hits are counted", "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in list(out.items())[:14]:

@@ -115,15 +115,28 @@ def agree_on_capture_outcome(group, failed: bool, eager_points: int, timeout_s: 
     world = dist.get_world_size(group)
     if world == 1:
         return failed
-    store = dist.distributed_c10d._get_default_store()
+    try:
+        store = dist.distributed_c10d._get_default_store()    # (private accessor: there is no public one)
+    except Exception as e:
+        raise RuntimeError("the sequence-parallel capture needs the default process group's key-value store to agree on the "
+                           f"capture outcome across ranks, and torch does not expose it here ({e!r})") from e
     ranks = dist.get_process_group_ranks(group)
     me = dist.get_rank()
-    seq = _AGREE_SEQ[ranks[0]] = _AGREE_SEQ.get(ranks[0], 0) + 1
-    pre = f"td_sp_capture/{ranks[0]}-{len(ranks)}/{seq}/"
+    gkey = tuple(ranks)           # the FULL rank tuple: a strided and a contiguous group with the same first rank and size differ
+    seq = _AGREE_SEQ[gkey] = _AGREE_SEQ.get(gkey, 0) + 1
+    import hashlib
+    pre = f"td_sp_capture/{hashlib.sha1(repr(gkey).encode()).hexdigest()[:16]}/{seq}/"
     store.set(pre + str(me), f"{int(failed)},{eager_points}")
     keys = [pre + str(r) for r in ranks]
     store.wait(keys, datetime.timedelta(seconds=timeout_s))
     reports = {r: store.get(pre + str(r)).decode() for r in ranks}
+    # housekeeping: everyone has read exchange seq-1 by the time anyone writes seq+1's keys AFTER passing this wait, so the
+    # PREVIOUS exchange's own key can go (deleting the current one could race a slower rank's get)
+    if seq > 1:
+        try:
+            store.delete_key(f"td_sp_capture/{hashlib.sha1(repr(gkey).encode()).hexdigest()[:16]}/{seq - 1}/{me}")
+        except Exception:   # a store without delete support (FileStore): the keys are a few bytes each
+            pass
     if len(set(reports.values())) != 1:
         raise RuntimeError("segmented hipGraph capture of the sequence-parallel forward ended differently on the ranks of the "
                            f"group (rank -> failed,collectives issued: {reports}); their collective sequences are misaligned and "
@@ -141,6 +154,10 @@ class GraphedModel(torch.nn.Module):
         self._epoch = getattr(net, "_weights_epoch", 0)
         self._sp_eager = False        # set when a segmented capture failed: eager from then on (sp_capture_error says why)
         self.sp_capture_error = None
+        self.sp_whole_graph_error = None   # why the collectives could not be captured inside ONE graph (None: they were / not tried)
+        self.sp_graph_mode = None          # how the sequence-parallel forward is replayed (set at capture)
+        import os
+        self._no_whole_graph = os.environ.get("TD_SP_WHOLE_GRAPH", "1") == "0"   # A/B switch: segments even where capture works
 
     def _key(self, x, t, ctx, y):
         return (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype,
@@ -191,27 +208,56 @@ class GraphedModel(torch.nn.Module):
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             if getattr(self.net, "seq_parallel", None) is not None:
-                # segments between the collectives (identical chain on every rank: the eager points are collective calls)
-                g = SegmentRecorder()
-                err = None
-                try:
-                    so = g.capture(lambda: self.net(sx, st, sc, y_B_C_T_H_W=sy))
-                except Exception as e:
-                    err = e
-                # the ranks compare outcomes through the store BEFORE anyone issues another collective (a rank-local
-                # failure raises on every rank; a common one falls back to eager enqueue everywhere)
-                sp_group = getattr(getattr(self.net.seq_parallel, "sp", None), "group", None)
-                if sp_group is not None:
-                    agree_on_capture_outcome(sp_group, err is not None, sum(1 for k_, _ in g.chain if k_ == "eager"))
-                if err is not None:
-                    e = err
-                    import warnings
-                    warnings.warn(f"segmented hipGraph capture of the sequence-parallel forward failed ({e!r}); "
-                                  f"this model now enqueues eagerly (slower, same results)")
-                    torch.cuda.synchronize()
-                    self.sp_capture_error = repr(e)
-                    self._sp_eager = True
-                    return self.net(x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=y_B_C_T_H_W, **kwargs)
+                sp_obj = getattr(self.net.seq_parallel, "sp", None)
+                sp_group = getattr(sp_obj, "group", None)
+                real_group = sp_group is not None and not type(sp_group).__name__ == "EmulatedGroup"
+                g = None
+                if getattr(sp_obj, "capturable", False) and not self._no_whole_graph:
+                    # (1) ONE graph for the whole sharded forward, the collectives inside it: the nccl (= RCCL) backend issues
+                    # them on its communicator stream, which forks off the capturing stream and joins it again at
+                    # ``work.wait()`` — stream-ordered work like any kernel.  No host work between the ~1100 launches of a
+                    # rank's forward (the segmented form below re-issues ~6 collectives per layer from Python).
+                    err = None
+                    try:
+                        wg = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(wg, capture_error_mode="thread_local"):
+                            so = self.net(sx, st, sc, y_B_C_T_H_W=sy)
+                        g = wg
+                    except Exception as e:   # e.g. a communicator that refuses capture on this stack
+                        err = e
+                        torch.cuda.synchronize()
+                    if real_group:
+                        agree_on_capture_outcome(sp_group, err is not None, 0)
+                    if err is not None:
+                        import warnings
+                        self.sp_whole_graph_error = repr(err)
+                        warnings.warn(f"whole-graph capture of the sequence-parallel forward (collectives inside the hipGraph) "
+                                      f"failed ({err!r}); falling back to graph segments around eager collectives")
+                    else:
+                        self.sp_graph_mode = "one hipGraph, collectives captured"
+                if g is None:
+                    # (2) segments between the collectives (identical chain on every rank: the eager points are collective calls)
+                    g = SegmentRecorder()
+                    err = None
+                    try:
+                        so = g.capture(lambda: self.net(sx, st, sc, y_B_C_T_H_W=sy))
+                    except Exception as e:
+                        err = e
+                    # the ranks compare outcomes through the store BEFORE anyone issues another collective (a rank-local
+                    # failure raises on every rank; a common one falls back to eager enqueue everywhere)
+                    if real_group:
+                        agree_on_capture_outcome(sp_group, err is not None, sum(1 for k_, _ in g.chain if k_ == "eager"))
+                    if err is not None:
+                        e = err
+                        import warnings
+                        warnings.warn(f"segmented hipGraph capture of the sequence-parallel forward failed ({e!r}); "
+                                      f"this model now enqueues eagerly (slower, same results)")
+                        torch.cuda.synchronize()
+                        self.sp_capture_error = repr(e)
+                        self._sp_eager = True
+                        self.sp_graph_mode = "eager enqueue"
+                        return self.net(x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=y_B_C_T_H_W, **kwargs)
+                    self.sp_graph_mode = f"{g.n_segments} hipGraph segments, collectives eager between them"
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):

@@ -36,17 +36,35 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
+class EmulatedGroup:
+    """Stands in for a process group when ONE rank of an N-way split is run alone on one GPU (``bench.py --emulate-rank``,
+    ``tools/emulate_ranks.py``): no communication — an all-gather fills every rank's slot of its output with THIS rank's
+    shard (a device copy on the compute stream: the HBM writes a real gather's incoming xGMI traffic would cause, not
+    overlapped with anything, so the compute term it measures is on the pessimistic side).  Results are meaningless as
+    attention outputs (every rank's K side is a copy of this rank's); shapes, launches, LUT sizes and kernel work are those of
+    the real rank.  Test / measurement infrastructure: never selected implicitly."""
+
+    def __init__(self, rank: int, world: int):
+        assert 0 <= rank < world
+        self.rank, self.world = rank, world
+
+
 class _Gather:
-    """One all-gather on fixed buffers: ``issue()`` / ``wait()`` may be called again (graph replay) — same tensors."""
+    """One all-gather on fixed buffers: ``issue()`` / ``wait()`` may be called again (graph replay) — same tensors.
+    Issue and wait are ``graph.eager_point``s: a plain call, except under a SEGMENTED capture (graph.SegmentRecorder),
+    where they stay between the graph segments and are re-issued at every replay."""
 
     def __init__(self, group, out, src, async_op):
         self.group, self.out, self.src, self.async_op = group, out, src, async_op
         self.work = None
+        self.emulated = isinstance(group, EmulatedGroup)
         # single-GPU test rig (several ranks on one device, tests/test_gpu_seqpar.py): gloo gathers host memory
-        self.via_host = src.is_cuda and dist.get_backend(group) == "gloo"
+        self.via_host = (not self.emulated) and src.is_cuda and dist.get_backend(group) == "gloo"
 
     def issue(self):
-        if self.via_host:
+        if self.emulated:
+            self.out.view(self.group.world, -1).copy_(self.src.view(1, -1).expand(self.group.world, -1))
+        elif self.via_host:
             host = torch.empty(self.out.shape, dtype=self.out.dtype)
             dist.all_gather_into_tensor(host.view(-1), self.src.cpu(), group=self.group)
             self.out.copy_(host)
@@ -59,7 +77,7 @@ class _Gather:
             self.work = None
 
     def wait(self):
-        if self.async_op and not self.via_host:
+        if self.async_op and not self.via_host and not self.emulated:
             eager_point(self._wait)
 
 
@@ -104,9 +122,17 @@ class PackLayout:
 
 class SeqParallel:
     def __init__(self, group=None, ops=None):
-        self.group = group if group is not None else dist.group.WORLD
-        self.rank = dist.get_rank(self.group)
-        self.world = dist.get_world_size(self.group)
+        if isinstance(group, EmulatedGroup):
+            self.group, self.rank, self.world = group, group.rank, group.world
+        else:
+            self.group = group if group is not None else dist.group.WORLD
+            self.rank = dist.get_rank(self.group)
+            self.world = dist.get_world_size(self.group)
+        # collectives INSIDE the captured hipGraph (graph.GraphedModel): RCCL's calls are stream-ordered, torch's nccl
+        # backend forks its communicator stream off the capturing stream and joins it back at ``work.wait()``, so the whole
+        # sharded forward is ONE graph with no host work between its kernels.  gloo (the CPU / one-GPU rig) moves bytes on
+        # the host and cannot be captured: there the forward stays a chain of graph segments around eager collectives.
+        self.capturable = isinstance(group, EmulatedGroup) or dist.get_backend(self.group) == "nccl"
         if ops is None:
             from . import kernels as ops  # HIP; raises on CPU tensors
         self.ops = ops
@@ -141,6 +167,29 @@ class SeqParallel:
         h = _Gather(self.group, out, t.contiguous().view(-1), async_op)
         eager_point(h.issue)
         return (out, h) if async_op else out
+
+    def broadcast(self, t):
+        """The group's first rank's contents of ``t`` on every rank (``broadcast`` of rcm/utils/context_parallel.py:167-184 as
+        ``WanModel.forward`` uses it, wan2pt1.py:629-636).  Data only: the reference also ships the SHAPE first, which costs a
+        host synchronisation per input; here a shape mismatch between ranks is the caller's error.  The caller's tensor is
+        not written on the receiving ranks (they get a copy)."""
+        if t is None:
+            return None
+        if isinstance(self.group, EmulatedGroup):
+            return t
+        src = min(dist.get_process_group_ranks(self.group))
+        buf = t if dist.get_rank() == src else t.clone()
+        via_host = buf.is_cuda and dist.get_backend(self.group) == "gloo"
+
+        def fn():
+            if via_host:
+                host = buf.cpu()
+                dist.broadcast(host, src, group=self.group)
+                buf.copy_(host)
+            else:
+                dist.broadcast(buf, src, group=self.group)
+        eager_point(fn)
+        return buf
 
     def gather_tokens(self, out_loc, L):
         """[B, L_loc, C] -> [B, L, C] on every rank (cat_outputs_cp)."""
@@ -237,8 +286,14 @@ class SeqParallel:
 class _ModelAdapter:
     """What ``WanModel._self_attention`` calls when ``model.seq_parallel`` is set."""
 
-    def __init__(self, sp: SeqParallel):
+    def __init__(self, sp: SeqParallel, broadcast_inputs: bool = False):
         self.sp = sp
+        self.broadcast_inputs = broadcast_inputs
+
+    def broadcast(self, *tensors):
+        """Inputs of one forward from the group's first rank (only when enabled through the reference's hook,
+        ``WanModel.enable_context_parallel``; ``seqpar.enable`` callers hand identical inputs to every rank)."""
+        return tuple(self.sp.broadcast(t) for t in tensors)
 
     def shard_tokens(self, x, cos, sin):
         return self.sp.shard_tokens(x, cos, sin)
@@ -256,9 +311,11 @@ class _ModelAdapter:
                                       model.sla_topk, fused.get("proj_w"), fused.get("proj_b"))
 
 
-def enable(model, group=None, ops=None):
-    """Mirror of ``WanModel.enable_context_parallel`` (wan2pt1.py:786-792)."""
-    model.seq_parallel = _ModelAdapter(SeqParallel(group, ops))
+def enable(model, group=None, ops=None, broadcast_inputs=False):
+    """What ``WanModel.enable_context_parallel`` (wan2pt1.py:786-792; same name on this repo's WanModel) does.
+    broadcast_inputs: replicate x / t / text / y from the group's first rank at the top of every forward, as the
+    reference's forward does (wan2pt1.py:627-636); off when the caller already holds identical inputs on every rank."""
+    model.seq_parallel = _ModelAdapter(SeqParallel(group, ops), broadcast_inputs)
     return model
 
 

@@ -44,6 +44,14 @@ class AttnOp(nn.Module):
         super().__init__()
         if local_attn is not None:
             self.local_attn = local_attn
+        self.pg = None
+        self.stream = None
+
+    def set_context_parallel_group(self, process_group, ranks=None, stream=None):
+        """a2a_cp.py:184-196: remembered only — the exchange itself is the model's (``WanModel.enable_context_parallel``
+        -> seqpar: one packed all-gather of the K side per layer instead of the reference's four all-to-alls)."""
+        del ranks
+        self.pg, self.stream = process_group, stream
 
 
 def _linear(in_f, out_f, quant, dtype):
@@ -174,6 +182,33 @@ class WanModel(nn.Module):
         d["_side_streams"] = {}
         d["_text_states"] = {}
         return d
+
+    # ------------------------------------------------------------------ context (sequence) parallelism: the reference's hooks
+    def enable_context_parallel(self, process_group=None):
+        """``WanModel.enable_context_parallel`` (rcm/networks/wan2pt1.py:786-792): shard the flattened (t h w) token axis over
+        the ranks of ``process_group``.  Same hook name and the same observable behaviour — inputs are broadcast from the
+        group's first rank (wan2pt1.py:627-636), every rank returns the full ``[B, C, T, H, W]`` output (``cat_outputs_cp``,
+        :703-707) — with this repo's exchange underneath (``seqpar``: per self-attention layer one packed RCCL all-gather of
+        the rank's quantised K side; no ``H % cp`` or ``L % cp`` constraint, where the reference's Ulysses all-to-all needs
+        both, a2a_cp.py:49-51, wan2pt1.py:663)."""
+        from . import seqpar
+        seqpar.enable(self, process_group, broadcast_inputs=True)
+        for blk in self.blocks:
+            blk.self_attn.attn_op.set_context_parallel_group(process_group, None, None)
+        return self
+
+    def disable_context_parallel(self):
+        """wan2pt1.py:774-784."""
+        from . import seqpar
+        seqpar.disable(self)
+        for blk in self.blocks:
+            blk.self_attn.attn_op.set_context_parallel_group(None, None, None)
+        return self
+
+    @property
+    def is_context_parallel_enabled(self):
+        """wan2pt1.py:794-796."""
+        return self.seq_parallel is not None
 
     # ------------------------------------------------------------------ derived weight copies
     def invalidate_caches(self):
@@ -523,7 +558,7 @@ class WanModel(nn.Module):
         hq, hs = K.gemm_w8a8_quant(h2[0], h2[1], lin1.int8_weight, lin1.scale, x2h.dtype, bias=lin1.bias, gelu_tanh=True)
         K.gemm_w8a8_stats(hq, hs, lin2.int8_weight, lin2.scale, lin2.bias, x=x2h, gate=ec[5], ws=ws_h)
 
-    def _tail_two_halves(self, i, blk, x2, y, ec, context, kvt, ms):
+    def _tail_two_halves(self, i, blk, x2, y, ec, context, kvt, ms, tkv=None):
         """After self-attention a block is token-local (o projection, cross-attention against the 512 text keys, FFN; SURVEY
         §8e): rows [0, ms) run on the current stream, rows [ms, L) on the model's second stream, fork / join with events
         (graph edges under capture).  One video then keeps two kernels in flight most of the time — the launch ramps, store
@@ -533,6 +568,8 @@ class WanModel(nn.Module):
         ``ws`` belong to the current stream and outlive the join."""
         L_loc, dim = x2.shape
         yq, ys = y
+        if kvt is None:     # uncached text: the block's text K / V^T ONCE, before the fork (not once per half)
+            kvt = self._text_kvt(i, blk, context, tkv)
         ws = torch.empty((L_loc, dim // 64, 2), dtype=torch.float32, device=x2.device)
         main, side = torch.cuda.current_stream(), self._side()
         e_fork = torch.cuda.Event()
@@ -575,7 +612,8 @@ class WanModel(nn.Module):
         ms = self._split_rows(L_loc) if (fstats and qo and isinstance(blk.norm3, FastLayerNorm) and isinstance(y, tuple)
                                          and isinstance(blk.ffn[0], Int8Linear)) else 0
         if ms:
-            self._carry_stats = self._tail_two_halves(i, blk, x2, y, ec, context[0], None if kvts is None else kvts[0][i], ms)
+            self._carry_stats = self._tail_two_halves(i, blk, x2, y, ec, context[0], None if kvts is None else kvts[0][i], ms,
+                                                      None if tkv is None else tkv[0])
             return x
         st3 = self._residual_lin_(x2, blk.self_attn.o, y, ec[2], stats=fstats)
         # ---- cross attention ----
@@ -620,6 +658,9 @@ class WanModel(nn.Module):
             raise NotImplementedError("CLIP image-context branch (Wan2.1 I2V) is outside the hot path; "
                                       "Wan2.2-A14B I2V conditions through y_B_C_T_H_W only")
         assert timesteps_B_T.shape[1] == 1
+        if self.seq_parallel is not None and getattr(self.seq_parallel, "broadcast_inputs", False):
+            x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W = self.seq_parallel.broadcast(
+                x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W)     # wan2pt1.py:629-636
         t_B = timesteps_B_T[:, 0]
         kt, kh, kw = self.patch_size
         B, C1, T_in, H_in, W_in = x_B_C_T_H_W.shape
@@ -633,7 +674,10 @@ class WanModel(nn.Module):
         # f3 in HIP (csrc/embed_head.hip): patchify + patch_embedding, the time MLPs, the AdaLN vectors, head + unpatchify —
         # no library GEMM and no torch elementwise kernel inside a captured forward
         fe = (self.fuse_embed_head and (kt, kh, kw) == (1, 2, 2) and C % 4 == 0 and C <= 64 and dt in (torch.bfloat16, torch.float16)
-              and self.patch_embedding.weight.dtype == dt and timesteps_B_T.dtype in (torch.bfloat16, torch.float16)
+              and self.patch_embedding.weight.dtype == dt and self.patch_embedding.bias.dtype == dt
+              and all(m.weight.dtype in (torch.bfloat16, torch.float16)       # K.gemv_f32 reads 16-bit weights
+                      for m in (self.time_embedding[0], self.time_embedding[2], self.time_projection[1]))
+              and timesteps_B_T.dtype in (torch.bfloat16, torch.float16)
               and self.dim % 8 == 0 and self.out_dim * 4 <= 64)
         row0 = 0
         if fe:
@@ -694,10 +738,11 @@ class WanModel(nn.Module):
         L_loc = x.shape[1]
         if fe:
             hw = self._fused.get("head")
-            if hw is None:   # the fp32 island's up-cast of the (bf16) head parameters, made once
+            hver = (self.head.head.weight._version, self.head.head.bias._version, self.head.modulation._version)
+            if hw is None or hw[3] != hver:   # the fp32 island's up-cast of the (bf16) head parameters; in-place updates noticed
                 hw = self._fused["head"] = (self.head.head.weight.detach().float().contiguous(),
                                            self.head.head.bias.detach().float().contiguous(),
-                                           self.head.modulation.detach().float().contiguous().view(1, 2, self.dim))
+                                           self.head.modulation.detach().float().contiguous().view(1, 2, self.dim), hver)
             em = K.bcast_add(hw[2], e_B_D.view(B, 1, self.dim))[0]    # [B, 2, dim] = modulation + e
             out = K.head(x, em[:, 1].contiguous(), em[:, 0].contiguous(), hw[0], hw[1], self.eps, self.out_dim, T, H, W,
                          unpatchify=sp is None, row0=row0)
