@@ -21,6 +21,8 @@
  *                                              -> td_attn_i8   [sparse via LUT / dense]
  *   Triton _attn_fwd SLA/kernel.py:21-82       -> td_attn_16   [sparse via LUT / dense]
  *   SLA linear branch SLA/core.py:243-253      -> td_sla_linear_kv, td_sla_linear_out
+ *   nn.Linear / F.linear in 16-bit (text MLP wan2pt1.py:678; C3's bf16 linears :226-232,375; umT5 rcm/utils/umt5.py:145-214;
+ *     the VAE attention's products rcm/tokenizers/wan2pt1.py:229-248)      -> td_gemm_bf16, td_softmax_rows, td_t5_norm
  *
  * Tensor conventions: row-major contiguous unless a stride argument says otherwise;
  * 16-byte aligned base pointers; dtype codes below.
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TD_ABI_VERSION 2
+#define TD_ABI_VERSION 3
 
 /* status codes */
 #define TD_OK 0
@@ -112,6 +114,28 @@ int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void* w, const v
                    int interleave, int To, int Ho, int Wo, int stride_t, int stride_hw, int pad_t, int pad_h, int pad_w,
                    td_stream_t stream);
 int td_vae_chan_rms(const void* x, const void* gamma, void* y, int64_t rows, int C, int silu, td_stream_t stream);
+
+/* ---- 16-bit GEMM, row softmax, T5LayerNorm (csrc/gemm_bf16.hip; ABI v3) ----
+ * td_gemm_bf16: D[b][m, n] = sum_k A[b][m, k] * B[b][n, k] (+ bias[n]) (+ epilogue) on the 16-bit matrix pipe, fp32
+ *   accumulate; `dtype` (TD_BF16 | TD_F16) = A, B, bias, res; `out_dtype` = dtype or TD_F32.  Row strides lda / ldb / ldd /
+ *   ldr and batch strides in ELEMENTS (batch = 1: strides ignored); k % 64 == 0 (zero-pad shorter rows), lda, ldb % 8 == 0,
+ *   16-bit outputs ldd % 8 == 0.  Rounding points = the reference's operator sequence (F.linear rounds, then each
+ *   elementwise op rounds): cast(acc) -> + bias, cast -> epilogue, cast -> + res, cast; fp32 output: acc + bias, unrounded.
+ *   epilogue: 0 none; 1 GELU-tanh (nn.GELU(approximate="tanh"), wan2pt1.py:375,678); 2 gated GELU of umT5's T5FeedForward
+ *   (umt5.py:125-127,210: d [m, n/2] = fc1(x) * GELU(gate(x)) with B's rows = gate / fc1 interleaved in blocks of 32 rows
+ *   — rows [64p, 64p+32) gate columns [32p, 32p+32), rows [64p+32, 64p+64) fc1 columns of the same range — and the 16-bit
+ *   rounding of every elementwise step of the reference's explicit tanh formula); res (16-bit, plain epilogue only): x + Linear.
+ * td_softmax_rows: p[r, c] = softmax_c(scale * (s[r, c] (+ bias[r % bias_rows, c]))) in fp32, rounded once; columns
+ *   [cols, ldp) of p are zero-filled (the next GEMM's k runs over the padded width).  s f32 or p's dtype (16-bit s: the
+ *   bias add is rounded to that dtype first — `einsum(q, k) + attn_bias`, umt5.py:183); in place when s == p and lds == ldp.
+ * td_t5_norm: T5LayerNorm (umt5.py:130-142): cast(x * rsqrt(mean(float(x)^2) + eps)) then w * that in the 16-bit dtype. */
+int td_gemm_bf16(const void* a, const void* b, const void* bias, const void* res, void* d, int dtype, int out_dtype, int epilogue,
+                 int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int64_t ldd, int64_t ldr, int64_t batch,
+                 int64_t stride_a, int64_t stride_b, int64_t stride_d, int64_t stride_r, td_stream_t stream);
+int td_softmax_rows(const void* s, int s_dtype, void* p, int p_dtype, const void* bias, int64_t rows, int64_t cols, int64_t lds,
+                    int64_t ldp, int64_t bias_rows, int64_t ldb, float scale, td_stream_t stream);
+int td_t5_norm(const void* x, const void* w, void* y, int dtype, float eps, int64_t rows, int64_t n, int64_t ldx, int64_t ldy,
+               td_stream_t stream);
 
 /* time embedding (wan2pt1.py:144-153, 671-674) and the AdaLN vectors of all blocks:
  * td_time_sinusoid: t [B] (`dtype`, the bf16-rounded timesteps) -> out f32 [B, freq_dim] = cat(cos, sin)(t * 10000^(-j/half)), fp64;

@@ -55,3 +55,35 @@ def test_bench_prompt_to_pixels_extra():
     assert "error" not in p, p
     assert p["finite"] and p["video_shape"] == [1, 3, 81, 480, 832] and 0 < p["seconds_per_video"] < 60
     assert p["umt5_ms"] > 0 and p["sampling_ms"] > 0 and p["vae_decode_ms"] > 0 and r["value"] > 0
+
+
+def test_bench_self_spawns_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no launcher environment (the driver's N = 1 command form with another N) re-executes
+    itself as 2 ranks under torch.distributed.run and still prints ONE JSON line (rank 0's).  On the one-GPU box the ranks
+    share the device and talk gloo through host memory (TD_BENCH_BACKEND=gloo: the development rig)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TD_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                          "--layers", "2", "--no-cpu-baseline", "--no-box-calibration", "--no-replica-leg"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "strong"
+    assert "sp2" in r["config"]["parallelism"]
+
+
+def test_bench_emulated_rank_reports_compute_and_wire_terms():
+    """--emulate-rank r/N: one rank's work of an N-way sequence split on the one GPU (no communication), replayed as ONE
+    hipGraph; the line is marked as an emulation and carries the measured compute term and the modelled wire term."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--emulate-rank", "7/8", "--steps", "1", "--warmup", "1",
+                          "--layers", "2", "--no-cpu-baseline", "--no-box-calibration"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    e = r["emulated_rank"]
+    assert r["metric"].startswith("EMULATED") and r["vs_baseline"] is None
+    assert e["rank"] == 7 and e["of"] == 8 and e["tokens_per_rank_padded"] == 4096 and e["tokens_of_rank"] == 32760 - 7 * 4096
+    assert e["measured_compute_ms_per_dit_step"] > 0 and e["pack_bytes_per_layer"] > 4096 * 1536 * 3
+    assert "one hipGraph" in r["launch_mode"], r["launch_mode"]

@@ -134,19 +134,28 @@ def _nccl_worker(rank, world, port, attention, ret):
         seqpar.enable(net, dist.group.WORLD)
         ret["backend"] = dist.get_backend(dist.group.WORLD)
         eager = [net(x, t, ctx).clone() for x, t in zip(xs, ts)]
-        gm = GraphedModel(net)
-        outs = [gm(x, t, ctx).clone() for x, t in zip(xs, ts)]
-        outs.append(gm(xs[0], ts[0], ctx).clone())
-        torch.cuda.synchronize()
-        ret["capture_error"] = gm.sp_capture_error
-        if gm.sp_capture_error is None:
-            rec = next(iter(gm._graphs.values()))[0]
-            ret["segments"] = rec.n_segments
-            ret["eager_points"] = len(rec.chain) - rec.n_segments
+        # (1) segments around eager collectives (TD_SP_WHOLE_GRAPH=0), (2) the default: ONE graph, collectives captured
+        ret["same"] = []
+        for whole in (False, True):
+            gm = GraphedModel(net)
+            gm._no_whole_graph = not whole
+            outs = [gm(x, t, ctx).clone() for x, t in zip(xs, ts)]
+            outs.append(gm(xs[0], ts[0], ctx).clone())
+            torch.cuda.synchronize()
+            if not whole:
+                ret["capture_error"] = gm.sp_capture_error
+                if gm.sp_capture_error is None:
+                    rec = next(iter(gm._graphs.values()))[0]
+                    ret["segments"] = rec.n_segments
+                    ret["eager_points"] = len(rec.chain) - rec.n_segments
+            else:
+                ret["whole_mode"] = gm.sp_graph_mode
+                ret["whole_error"] = gm.sp_whole_graph_error
+                ret["whole_is_one_graph"] = isinstance(next(iter(gm._graphs.values()))[0], torch.cuda.CUDAGraph)
+            ret["same"] = ret["same"] + [bool(torch.equal(outs[0], eager[0])), bool(torch.equal(outs[1], eager[1])),
+                                         bool(torch.equal(outs[2], eager[0]))]
         ret["rel"] = rel_l2(eager[0], ref)
         ret["cos"] = cosine(eager[0], ref)
-        ret["same"] = [bool(torch.equal(outs[0], eager[0])), bool(torch.equal(outs[1], eager[1])),
-                       bool(torch.equal(outs[2], eager[0]))]
         ret["differ"] = not torch.equal(eager[0], eager[1])
     finally:
         dist.destroy_process_group()
@@ -163,5 +172,9 @@ def test_seqpar_over_rccl_one_rank(attention):
     assert ret["backend"] == "nccl", dict(ret)
     assert ret["rel"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
     assert ret["capture_error"] is None, dict(ret)      # the segmented capture must work on the real RCCL stack
-    assert ret["differ"] and all(ret["same"]), dict(ret)
+    assert ret["differ"] and all(ret["same"]) and len(ret["same"]) == 6, dict(ret)
     assert ret["segments"] >= 5 and ret["eager_points"] >= 5, dict(ret)
+    # round 4: the RCCL all-gathers INSIDE the hipGraph.  If this RCCL / torch stack refuses the capture the model falls back
+    # to segments (and still replays bit-identically, asserted above); the error text is then printed for the record.
+    print(f"\n[seqpar over RCCL, {attention}] whole-graph capture: mode = {ret['whole_mode']!r}, error = {ret['whole_error']!r}")
+    assert ret["whole_is_one_graph"] == (ret["whole_error"] is None), dict(ret)

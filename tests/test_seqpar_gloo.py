@@ -231,3 +231,68 @@ def test_capture_outcome_is_agreed_through_the_store(scenario):
         want = scenario == "all_fail_same_point"
         assert ret[0] == ("agreed", want) and ret[1] == ("agreed", want), dict(ret)
         assert ret[10] == ("agreed", False) and ret[11] == ("agreed", False), dict(ret)
+
+
+def test_reference_hook_names_on_wanmodel():
+    """``WanModel.enable_context_parallel`` / ``disable_context_parallel`` / ``is_context_parallel_enabled`` — the reference's
+    hook names (rcm/networks/wan2pt1.py:774-796) — wire the sequence-parallel adapter in and out, and hand the group to every
+    block's ``attn_op`` as ``MinimalA2AAttnOp.set_context_parallel_group`` would (a2a_cp.py:193-196)."""
+    from turbodiffusion_amd.seqpar import EmulatedGroup
+    from turbodiffusion_amd.wan import WanModel
+    net = WanModel(dim=256, ffn_dim=512, num_heads=2, num_layers=2, quant_linear=False, attention_type="sagesla")
+    assert net.is_context_parallel_enabled is False
+    grp = EmulatedGroup(1, 4)
+    assert net.enable_context_parallel(grp) is net
+    assert net.is_context_parallel_enabled is True and net.seq_parallel.broadcast_inputs is True
+    assert net.seq_parallel.sp.rank == 1 and net.seq_parallel.sp.world == 4
+    assert all(b.self_attn.attn_op.pg is grp for b in net.blocks)
+    net.disable_context_parallel()
+    assert net.is_context_parallel_enabled is False and all(b.self_attn.attn_op.pg is None for b in net.blocks)
+
+
+def test_emulated_rank_runs_one_ranks_work_without_communication():
+    """seqpar.EmulatedGroup (bench.py --emulate-rank): rank r of N alone — the plan, the packed layout and the gathered
+    buffers have the real sizes, every peer slot holds a copy of this rank's shard, no process group exists."""
+    from turbodiffusion_amd.seqpar import EmulatedGroup, SeqParallel
+    assert not dist.is_initialized()
+    H, L, D, W = 2, 900, 128, 4
+    q, k, v = (t[0].contiguous() for t in qkv(H, L, 21))
+    g = torch.Generator().manual_seed(3)
+    wp, bp = torch.randn(D, D, generator=g) * 0.05, torch.randn(D, generator=g) * 0.05
+    for r in (0, 3):
+        sp = SeqParallel(EmulatedGroup(r, W), ops=oracle_ops)
+        s, e = sp.plan(L)
+        assert (s, e) == (r * 256, min(L, (r + 1) * 256)) and sp.capturable
+        L_loc = e - s
+        out = torch.zeros(L_loc, H, D, dtype=q.dtype)
+        sp.self_attention(q[:, s:e].contiguous(), k[:, s:e].contiguous(), v[:, s:e].contiguous(), (L_loc * D, D), out, D, H * D,
+                          "sagesla", 0.3, wp, bp)
+        assert torch.isfinite(out.float()).all() and out.float().abs().sum() > 0
+        full = sp.gather_tokens(out.reshape(1, L_loc, H * D), L)
+        assert full.shape == (1, L, H * D)
+        allg = sp.all_gather(torch.arange(6.0).view(2, 3))
+        assert allg.shape == (W, 2, 3) and all(torch.equal(allg[i], allg[0]) for i in range(W))
+
+
+def _bcast_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from turbodiffusion_amd.seqpar import SeqParallel
+        sp = SeqParallel(ops=oracle_ops)
+        mine = torch.full((2, 3), float(rank + 1))
+        got = sp.broadcast(mine)
+        ret[rank] = (got.tolist(), mine.tolist(), sp.broadcast(None) is None, sp.capturable)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_input_broadcast_from_the_groups_first_rank():
+    """SeqParallel.broadcast (the reference forward's input broadcast, wan2pt1.py:629-636): every rank gets the first rank's
+    data; a receiving rank's own tensor is not written."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bcast_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    ones, twos = [[1.0] * 3] * 2, [[2.0] * 3] * 2
+    assert ret[0] == (ones, ones, True, False) and ret[1] == (ones, twos, True, False), dict(ret)

@@ -1,4 +1,5 @@
-"""f4 on the CPU: turbodiffusion_amd.vae_decode / text_encoder against
+"""f4 on the CPU: the ORACLE's library-operator restatements (oracle/f4_ref.py: whole-clip VAE decoder /
+encoder, valid-rows-only umT5 encoder — the graphs turbodiffusion_amd.vae_decode / vae_encode / text_encoder run on HIP kernels) against
   (a) the LIVE reference — ``WanVAE_.decode`` (chunked, rcm/tokenizers/wan2pt1.py:520-537) and ``T5Encoder``
       (rcm/utils/umt5.py:308-337) imported unmodified through oracle/ref_harness.py — where /root/reference exists, and
   (b) the committed fixture those same reference modules produced (oracle/make_golden_f4.py), everywhere.
@@ -14,8 +15,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import ref_harness as rh  # noqa: E402
 from oracle.make_golden_f4 import randomise  # noqa: E402
-from turbodiffusion_amd.text_encoder import Umt5Encoder, relative_buckets  # noqa: E402
-from turbodiffusion_amd.vae_decode import WanVaeDecoder  # noqa: E402
+from oracle.f4_ref import Umt5EncoderRef as Umt5Encoder, VaeDecoderRef as WanVaeDecoder, VaeEncoderRef as WanVaeEncoder  # noqa: E402
+from turbodiffusion_amd.text_encoder import relative_buckets  # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f4_vae_umt5.pt")
 needs_ref = pytest.mark.skipif(not rh.available(), reason="/root/reference not present (GPU box)")
@@ -46,7 +47,6 @@ def test_whole_clip_vae_decode_equals_the_reference_chunked_decode(dim, zd, T, H
 def test_whole_clip_vae_encode_equals_the_reference_chunked_encode(dim, zd, T, H, W):
     """One pass over all frames == the reference's 1 + 4 + 4 + ... chunked encode with its feature caches, incl. the temporal
     down-samplers' first-frame rule (the first frame passes, frames 1.. come from stride-2 windows starting at even frames)."""
-    from turbodiffusion_amd.vae_encode import WanVaeEncoder
     v = rh.load_aux("tokenizers.wan2pt1")
     vae = v.WanVAE_(dim=dim, z_dim=zd, dim_mult=[1, 2, 4, 4], num_res_blocks=2, attn_scales=[],
                     temperal_downsample=[False, True, True], dropout=0.0).eval()
@@ -99,7 +99,7 @@ def test_f4_modules_against_the_reference_fixture():
     fx = torch.load(GOLD)
     dec = WanVaeDecoder(fx["vae"]["state_dict"], dtype=torch.float32, device="cpu")
     torch.testing.assert_close(dec.decode(fx["vae"]["z"]), fx["vae"]["video"], rtol=1e-5, atol=2e-5)
-    from turbodiffusion_amd.vae_encode import WanVaeEncoder, synthetic_state_dict as enc_sd
+    from turbodiffusion_amd.vae_encode import synthetic_state_dict as enc_sd
     from turbodiffusion_amd.vae_decode import synthetic_state_dict as dec_sd
     hd, he = fx["vae_hip_size"], fx["vae_enc_hip_size"]     # the seeded weights the GPU tests rebuild reproduce the fixture
     dec2 = WanVaeDecoder(dec_sd(dim=hd["dim"], seed=hd["seed"], dtype=torch.float32), dtype=torch.float32, device="cpu")
@@ -118,3 +118,35 @@ def test_f4_modules_against_the_reference_fixture():
         enc(t5["ids"], bad)
     with pytest.raises(ValueError):
         WanVaeDecoder({"x": torch.zeros(1)}, device="cpu")
+
+
+def test_product_f4_classes_are_hip_only():
+    """The product classes have ONE backend: without a GPU (or in a dtype the kernels do not take) the constructors raise —
+    the library-operator graphs above live under oracle/ (round-3 verdict: no silent second backend)."""
+    from turbodiffusion_amd.text_encoder import Umt5Encoder as E
+    from turbodiffusion_amd.vae_decode import WanVaeDecoder as D, synthetic_state_dict as dec_sd
+    from turbodiffusion_amd.vae_encode import WanVaeEncoder as V, synthetic_state_dict as enc_sd
+    fx = torch.load(GOLD)
+    for make in (lambda: D(dec_sd(dim=32), device="cpu"), lambda: V(enc_sd(dim=32), device="cpu"),
+                 lambda: E(fx["umt5"]["state_dict"], device="cpu"),
+                 lambda: D(dec_sd(dim=32), dtype=torch.float32, device="cuda"),
+                 lambda: E(fx["umt5"]["state_dict"], dtype=torch.float32, device="cuda")):
+        with pytest.raises(ValueError, match="HIP kernels only"):
+            make()
+
+
+def test_latent_statistics_are_formed_like_the_reference():
+    """WanVAE builds (mean, 1 / std) as ``torch.tensor(std, dtype=dtype)`` then ``1.0 / self.std`` (wan2pt1.py:643-645): in
+    bf16 the reciprocal of the ROUNDED std, taken in bf16 — not the rounded fp64 reciprocal (6 of the 16 real channels differ by
+    one ulp).  Product helper and oracle agree with that construction bit for bit."""
+    from oracle.f4_ref import _stats
+    from turbodiffusion_amd.vae_decode import LATENT_MEAN, LATENT_STD, latent_stats
+    ref_inv = 1.0 / torch.tensor(LATENT_STD, dtype=torch.bfloat16)
+    naive = torch.tensor([1.0 / s for s in LATENT_STD], dtype=torch.bfloat16)
+    assert int((ref_inv != naive).sum()) == 6
+    for fn in (latent_stats, _stats):
+        m, inv = fn(LATENT_MEAN, LATENT_STD, 16, torch.bfloat16, "cpu")
+        assert torch.equal(inv.flatten(), ref_inv) and torch.equal(m.flatten(), torch.tensor(LATENT_MEAN, dtype=torch.bfloat16))
+    if rh.available():     # and the reference's own decode / encode in bf16 with those statistics use exactly these tensors
+        z = torch.randn(1, 16, 1, 2, 2).bfloat16()
+        assert torch.equal(z / ref_inv.view(1, 16, 1, 1, 1), z / inv)

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("TD_LIB_PATH") or os.path.join(_HERE, "libturbodiffusi
 
 TD_F16, TD_BF16, TD_F32 = 0, 1, 2
 TD_EPI_NONE, TD_EPI_GELU_TANH = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -33,6 +33,9 @@ SIGNATURES = {
     "td_vae_conv": [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp],
     "td_vae_conv_ex": [_vp, _i64, _vp, _vp, _vp, _vp, _i64] + [_i32] * 19 + [_vp],
     "td_vae_chan_rms": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
+    "td_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32] + [_i64] * 12 + [_vp],
+    "td_softmax_rows": [_vp, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
+    "td_t5_norm": [_vp, _vp, _vp, _i32, _f32, _i64, _i64, _i64, _i64, _vp],
     "td_gemv_f32": [_vp, _vp, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp],
     "td_bcast_add": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
     "td_calib_mfma_i8": [_i32, _i32, _vp, _vp],

@@ -1,0 +1,497 @@
+// 16-bit GEMM on the bf16 / fp16 matrix pipe:  D[b][m, n] = sum_k A[b][m, k] * B[b][n, k]  (+ bias[n]) (+ epilogue)
+//
+// What it is for (all PyTorch-library GEMMs of the product path until round 3):
+//   * f4: the umT5 encoder's linears (rcm/utils/umt5.py:145-214: q|k|v, o, gate|fc1 with the gated-GELU product in the
+//     epilogue, fc2), its per-head score / value products (batched), the Wan VAE middle-block attention as two batched
+//     GEMMs around td_softmax_rows (rcm/tokenizers/wan2pt1.py:229-248);
+//   * the text MLP of the DiT (wan2pt1.py:678) and the "bf16 linears" configuration (BASELINE config 3: nn.Linear in the
+//     blocks, wan2pt1.py:226-232,375) — so that C3's number is this repo's kernel, not hipBLASLt's.
+//
+// Design: the W8A8 kernel's skeleton (gemm_w8a8_fi.hip) without its dequant.  A K step of 64 16-bit elements is 128 bytes
+// per row — exactly the int8 kernel's 128-deep K block — so the LDS image (256 x 128 B per operand and stage, bank swizzle
+// applied on the GLOBAL side of the LDS-DMA), the LDS-DMA piece schedule, the fragment addresses (one ds_read_b128 per
+// 16-row x 32-k fragment: v_mfma_f32_16x16x32 takes 8 consecutive k per lane = 16 bytes, as v_mfma_i32_16x16x64_i8 takes
+// 16), the one-barrier-per-K-step pipeline and the lane <-> (m, n) map of the results are the same; the accumulators are
+// the MFMA's own fp32 C/D registers and the main loop contains no VALU at all.  256x256 tile, 512 threads (8 waves, wave
+// tile 128 x 64), two stages of 64 KB.
+//
+// Arithmetic: fp32 accumulation in MFMA order (k ascending in steps of 32), one rounding to the output dtype, then the
+// reference's operator sequence with its rounding points: + bias (rounded), GELU-tanh (rounded) | gated-GELU, + residual
+// (rounded).  Parity is stated against an fp32 matmul of the same 16-bit operands (tests/test_gpu_f4.py).
+#include "td_common.h"
+
+#define G_BM 256
+#define G_BN 256
+#define G_TILE (256 * 128)
+#define G_STAGE (2 * G_TILE)
+#define G_LDS (2 * G_STAGE)
+
+typedef __attribute__((address_space(3))) void* g_lptr_t;
+
+__device__ __forceinline__ uint32_t g_swz(uint32_t row, uint32_t chunk) {
+  return row * 128u + ((chunk ^ ((row >> 1) & 7u)) << 4);
+}
+
+#define G_FENCE()                             \
+  {                                           \
+    __builtin_amdgcn_sched_barrier(0);        \
+    asm volatile("" ::: "memory");            \
+  }
+#define G_BARRIER()                           \
+  {                                           \
+    G_FENCE()                                 \
+    __builtin_amdgcn_s_barrier();             \
+    asm volatile("" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);        \
+  }
+
+struct Gemm16P {
+  const uint16_t* A; const uint16_t* B; const uint16_t* bias; const uint16_t* R; void* D;
+  int64_t M, N, K;                  // K % 64 == 0
+  int64_t lda, ldb, ldd, ldr;       // row strides, elements
+  int64_t sA, sB, sD, sR;           // batch strides, elements
+  int tiles_m, tiles_n, group_m;
+};
+
+#define G_EPI_NONE 0
+#define G_EPI_GELU 1     // GELU-tanh of the (bias-added, rounded) result, as the W8A8 kernels (td_gelu_tanh)
+#define G_EPI_GEGLU 2    // umT5 T5FeedForward (umt5.py:197-214): B's rows are gate / fc1 interleaved in blocks of 32
+                         // (rows [64 p, 64 p + 32) = gate columns [32 p, 32 p + 32), rows [64 p + 32, 64 p + 64) = fc1
+                         // columns of the same range); D [M, N / 2] = fc1(x) * GELU(gate(x)) with the reference's 16-bit
+                         // rounding after every elementwise operation of its explicit tanh formula (umt5.py:125-127)
+
+// umt5.py:125-127 on a value already rounded to the 16-bit dtype, every torch op rounding its result to that dtype:
+// 0.5 * x * (1.0 + tanh(sqrt(2/pi) * (x + 0.044715 * pow(x, 3))))
+template <int DT> __device__ __forceinline__ float g_t5_gelu(float x) {
+  const float p3 = round_half<DT>(x * x * x);                       // torch.pow(x, 3.0): computed in fp32, one rounding
+  const float a = round_half<DT>(0.044715f * p3);
+  const float s = round_half<DT>(x + a);
+  const float u = round_half<DT>(0.7978845608028654f * s);
+  const float t = round_half<DT>(tanhf(u));
+  const float o = round_half<DT>(1.0f + t);
+  const float h = round_half<DT>(0.5f * x);
+  return round_half<DT>(h * o);
+}
+
+template <int IDT> struct g_mma;
+template <> struct g_mma<TD_BF16> {
+  __device__ static __forceinline__ void run(v4f& d, const v4i& a, const v4i& b) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+  }
+};
+template <> struct g_mma<TD_F16> {
+  __device__ static __forceinline__ void run(v4f& d, const v4i& a, const v4i& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+  }
+};
+
+// IDT: operand dtype (bf16 | f16); ODT: output dtype (bf16 | f16 | f32; f32: plain epilogue only, no bias rounding games:
+// acc + bias in fp32).  RES: D = round(D' + R) with D' the rounded epilogue result (x + Linear(...), 16-bit outputs only).
+template <int IDT, int ODT, int EPI, bool HAS_BIAS, bool RES>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const Gemm16P p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int64_t M = p.M, N = p.N;
+  const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
+  const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
+
+  // ---- tile assignment: XCD remap, then m-grouped raster (as gemm_w8a8_fi.hip) ----
+  const uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_group = p.group_m * p.tiles_n;
+  const int gid = vid / per_group;
+  const int first_m = gid * p.group_m;
+  const int gsz = min(p.group_m, p.tiles_m - first_m);
+  const int in_g = vid % per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int64_t m0 = (int64_t)tm * G_BM, n0 = (int64_t)tn * G_BN;
+  const int nk = (int)(p.K / 64);
+  const int64_t ldab = p.lda * 2, ldbb = p.ldb * 2;   // bytes
+
+  // ---- LDS-DMA pieces: wave w moves chunks c = w + 8t (8 rows x 128 B) of both operand tiles ----
+  uint32_t ga[4], gb[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int c = wave + 8 * t;
+    const int row = 8 * c + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (LDS image is lane-linear)
+    int64_t am = m0 + row; if (am > M - 1) am = M - 1;   // tail rows: clamp (never stored)
+    int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
+    ga[t] = (uint32_t)(am * ldab + chunk * 16);
+    gb[t] = (uint32_t)(bn * ldbb + chunk * 16);
+  }
+  const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(uint32_t)((M - 1) * ldab + p.K * 2), 0x00020000);
+  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(uint32_t)((N - 1) * ldbb + p.K * 2), 0x00020000);
+#define G_PIECE(kb_, p_)                                                                          \
+  {                                                                                               \
+    char* sb_ = smem + ((kb_) & 1) * G_STAGE + wave * 1024;                                       \
+    if ((p_) < 4)                                                                                 \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (g_lptr_t)(sb_ + ((p_) & 3) * 8192), 16,   \
+                                               ga[(p_) & 3], (kb_) * 128, 0, 0);                  \
+    else                                                                                          \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (g_lptr_t)(sb_ + G_TILE + ((p_) & 3) * 8192), \
+                                               16, gb[(p_) & 3], (kb_) * 128, 0, 0);              \
+  }
+
+  // ---- fragment read offsets (within a stage); B rows use the bit-2/3-swapped order so that after the MFMA a lane
+  //      holds 4 CONSECUTIVE n (see the epilogue) ----
+  const int pr = (l16 & 3) | ((l16 & 4) << 1) | ((l16 & 8) >> 1);
+  uint32_t xoff[2], woff[2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    xoff[kc] = g_swz(wm * 128 + l16, 4 * kc + lq);
+    woff[kc] = G_TILE + g_swz(wn * 64 + pr, 4 * kc + lq);
+  }
+
+  v4f acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  v4i wf[4][2], xf[2][2];
+
+#define G_LOAD_X(st_, i_, slot_)                                                                  \
+  _Pragma("unroll") for (int kc = 0; kc < 2; ++kc)                                                \
+    xf[slot_][kc] = *reinterpret_cast<const v4i*>((st_) + xoff[kc] + (i_) * 2048);
+#define G_LOAD_W(st_, kc_)                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+    wf[j][kc_] = *reinterpret_cast<const v4i*>((st_) + woff[kc_] + j * 2048);
+
+  // ---- prologue: stage 0 and stage 1 in flight; wait for stage 0; fragments of group (0, 0) ----
+#pragma unroll
+  for (int q = 0; q < 8; ++q) G_PIECE(0, q)
+  if (nk > 1) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) G_PIECE(1, q)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  G_BARRIER()
+  G_LOAD_W(smem, 0)
+  G_LOAD_W(smem, 1)
+  G_LOAD_X(smem, 0, 0)
+
+  for (int kb = 0; kb < nk; ++kb) {
+    const char* st = smem + (kb & 1) * G_STAGE;
+    const char* stn = smem + ((kb + 1) & 1) * G_STAGE;
+    const bool more = kb + 1 < nk;
+    const bool dma_tail = (kb >= 1) && more;   // rest of stage kb+1 (stage 1 was issued by the prologue)
+    const bool dma_head = kb + 2 < nk;         // first pieces of stage kb+2, after this step's barrier
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int cur = i & 1, prv = cur ^ 1;
+      // fragment of the next 16-row group into the other ring slot (its last readers were issued a group ago)
+      if (i < 7) { G_LOAD_X(st, i + 1, prv) }
+      else if (more) { G_LOAD_X(stn, 0, prv) }
+      G_FENCE()
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g_mma<IDT>::run(acc[i][j], wf[j][0], xf[cur][0]);
+      G_FENCE()
+      if (i == 7 && more) { G_LOAD_W(stn, 0) }
+      // LDS-DMA issue, spread over the groups (VMEM issue slots of this wave only)
+      if (i == 7) { if (dma_head) { G_PIECE(kb + 2, 0) G_PIECE(kb + 2, 4) } }
+      else if (i == 0) { if (dma_tail) { G_PIECE(kb + 1, 1) G_PIECE(kb + 1, 5) } }
+      else if (i == 1) { if (dma_tail) { G_PIECE(kb + 1, 2) } }
+      else if (i == 2) { if (dma_tail) { G_PIECE(kb + 1, 6) } }
+      else if (i == 3) { if (dma_tail) { G_PIECE(kb + 1, 3) } }
+      else if (i == 4) { if (dma_tail) { G_PIECE(kb + 1, 7) } }
+      G_FENCE()
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g_mma<IDT>::run(acc[i][j], wf[j][1], xf[cur][1]);
+      G_FENCE()
+      if (i == 7 && more) { G_LOAD_W(stn, 1) }
+      if (i == 6) {
+        // every LDS read of stage kb has returned (group 7's fragment was read at the top of this group), this wave's
+        // pieces of stage kb+1 have landed; after the barrier: everyone's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        G_BARRIER()
+      }
+    }
+  }
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last MFMAs' results before the VALU reads them
+
+  // ---- epilogue.  A lane owns m = .. + l16; accumulator (i, j) holds n_local = 16 j + 8 (lq & 1) + 4 (lq >> 1) + r ----
+  const int hi = lq >> 1;
+  const uint16_t* bias = p.bias;
+  if constexpr (ODT == TD_F32) {
+    float* D = reinterpret_cast<float*>(p.D) + (int64_t)blockIdx.y * p.sD;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t m = m0 + wm * 128 + i * 16 + l16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t n = n0 + wn * 64 + j * 16 + 8 * (lq & 1) + 4 * hi;
+        float o[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if constexpr (HAS_BIAS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < N) o[r] += half_bits_to_f32<IDT>(bias[n + r]);
+        }
+        if (m < M) {
+          if (n + 3 < N && (p.ldd & 3) == 0) *reinterpret_cast<float4*>(D + m * p.ldd + n) = make_float4(o[0], o[1], o[2], o[3]);
+          else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < N) D[m * p.ldd + n + r] = o[r];
+          }
+        }
+      }
+    }
+    return;
+  } else if constexpr (EPI == G_EPI_GEGLU) {
+    uint16_t* D = reinterpret_cast<uint16_t*>(p.D) + (int64_t)blockIdx.y * p.sD;
+    const int64_t No = N >> 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t m = m0 + wm * 128 + i * 16 + l16;
+      uint32_t pk[2][2];
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        float h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = round_half<ODT>(acc[i][jj][r]);         // gate(x), rounded by the Linear
+          const float f = round_half<ODT>(acc[i][jj + 2][r]);     // fc1(x)
+          h[r] = f * g_t5_gelu<ODT>(g);                           // rounded at the pack
+        }
+        pk[jj][0] = pack2<ODT>(h[0], h[1]);
+        pk[jj][1] = pack2<ODT>(h[2], h[3]);
+      }
+      auto s0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+      auto s1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
+      const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      const int jt = hi;   // lanes with lq < 2 hold 8 consecutive n of sub-tile 0, the others of sub-tile 1
+      const int64_t n = (n0 >> 1) + wn * 32 + jt * 16 + 8 * (lq & 1);
+      if (m < M && n < No) *reinterpret_cast<uint4*>(D + m * p.ldd + n) = v;
+    }
+    return;
+  } else {
+    uint16_t* D = reinterpret_cast<uint16_t*>(p.D) + (int64_t)blockIdx.y * p.sD;
+    const uint16_t* R = RES ? p.R + (int64_t)blockIdx.y * p.sR : nullptr;
+    __syncthreads();                    // every wave has read its last fragments: the stages may be overwritten
+    float* ep_bias = reinterpret_cast<float*>(smem + 8 * (64 * 72) * 2);   // behind the 8 waves' staging regions
+    if (tid < 256) {
+      const int64_t n = n0 + tid;
+      float bv = 0.f;
+      if constexpr (HAS_BIAS) { if (n < N) bv = half_bits_to_f32<ODT>(bias[n]); }
+      ep_bias[tid] = bv;
+    }
+    __syncthreads();
+    uint16_t* stg = reinterpret_cast<uint16_t*>(smem) + wave * (64 * 72);
+    constexpr int EP = EPI == G_EPI_GELU ? TD_EPI_GELU_TANH : TD_EPI_NONE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t pk[4][2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float bf[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (HAS_BIAS) {
+          const float4 bb = *reinterpret_cast<const float4*>(ep_bias + wn * 64 + j * 16 + 8 * (lq & 1) + 4 * hi);
+          bf[0] = bb.x; bf[1] = bb.y; bf[2] = bb.z; bf[3] = bb.w;
+        }
+        pk[j][0] = td_gemm_epilogue2<ODT, EP, HAS_BIAS>(acc[i][j][0], acc[i][j][1], bf[0], bf[1]);
+        pk[j][1] = td_gemm_epilogue2<ODT, EP, HAS_BIAS>(acc[i][j][2], acc[i][j][3], bf[2], bf[3]);
+      }
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        const int ja = 2 * jp, jb = 2 * jp + 1;
+        auto s0 = __builtin_amdgcn_permlane32_swap(pk[ja][0], pk[jb][0], false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(pk[ja][1], pk[jb][1], false, false);
+        const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        const int jt = hi ? jb : ja;
+        *reinterpret_cast<uint4*>(stg + ((i & 3) * 16 + l16) * 72 + jt * 16 + 8 * (lq & 1)) = v;
+      }
+      if ((i & 3) == 3) {   // a 64-row half is complete in LDS: 8 rows x one full 128-byte line per store instruction
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + (lane >> 3), chunk = lane & 7;
+          const int64_t mm = m0 + wm * 128 + (i >> 2) * 64 + row, nn = n0 + wn * 64 + chunk * 8;
+          uint4 r = *reinterpret_cast<const uint4*>(stg + row * 72 + chunk * 8);
+          if (mm < M && nn < N) {
+            if constexpr (RES) {
+              float xf8[8], yf8[8];
+              unpack8<ODT>(*reinterpret_cast<const uint4*>(R + mm * p.ldr + nn), xf8);
+              unpack8<ODT>(r, yf8);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) xf8[e] += yf8[e];
+              r = pack8<ODT>(xf8);
+            }
+            if (nn + 8 <= N) *reinterpret_cast<uint4*>(D + mm * p.ldd + nn) = r;
+            else {   // ragged N (not a multiple of 8): element stores for the last piece
+              const uint32_t w4[4] = {r.x, r.y, r.z, r.w};
+              for (int e = 0; e < 8 && nn + e < N; ++e) D[mm * p.ldd + nn + e] = (uint16_t)(w4[e >> 1] >> ((e & 1) * 16));
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+  }
+}
+
+template <int IDT, int ODT, int EPI, bool HAS_BIAS, bool RES>
+static int launch_gemm16(const Gemm16P& p0, int batch, hipStream_t st) {
+  auto kern = gemm_bf16_kernel<IDT, ODT, EPI, HAS_BIAS, RES>;
+  static std::atomic<uint64_t> attr_mask{0};
+  td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), G_LDS, attr_mask);
+  Gemm16P p = p0;
+  p.tiles_m = (int)td_cdiv(p.M, G_BM);
+  p.tiles_n = (int)td_cdiv(p.N, G_BN);
+  p.group_m = td_tuning(TD_TUNE_GEMM_GROUP_M) > 0 ? td_tuning(TD_TUNE_GEMM_GROUP_M) : 4;
+  const dim3 grid((unsigned)p.tiles_m * (unsigned)p.tiles_n, (unsigned)batch, 1);
+  kern<<<grid, 512, G_LDS, st>>>(p);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+template <int IDT>
+static int dispatch_gemm16(const Gemm16P& p, int out_dtype, int epilogue, int batch, hipStream_t st) {
+  const bool hb = p.bias != nullptr, res = p.R != nullptr;
+  if (out_dtype == TD_F32) {
+    return hb ? launch_gemm16<IDT, TD_F32, G_EPI_NONE, true, false>(p, batch, st)
+              : launch_gemm16<IDT, TD_F32, G_EPI_NONE, false, false>(p, batch, st);
+  }
+  if (epilogue == G_EPI_GEGLU) return launch_gemm16<IDT, IDT, G_EPI_GEGLU, false, false>(p, batch, st);
+  if (epilogue == G_EPI_GELU) {
+    return hb ? launch_gemm16<IDT, IDT, G_EPI_GELU, true, false>(p, batch, st)
+              : launch_gemm16<IDT, IDT, G_EPI_GELU, false, false>(p, batch, st);
+  }
+  if (res) {
+    return hb ? launch_gemm16<IDT, IDT, G_EPI_NONE, true, true>(p, batch, st)
+              : launch_gemm16<IDT, IDT, G_EPI_NONE, false, true>(p, batch, st);
+  }
+  return hb ? launch_gemm16<IDT, IDT, G_EPI_NONE, true, false>(p, batch, st)
+            : launch_gemm16<IDT, IDT, G_EPI_NONE, false, false>(p, batch, st);
+}
+
+extern "C" int td_gemm_bf16(const void* a, const void* b, const void* bias, const void* res, void* d, int dtype, int out_dtype,
+                            int epilogue, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int64_t ldd, int64_t ldr,
+                            int64_t batch, int64_t stride_a, int64_t stride_b, int64_t stride_d, int64_t stride_r,
+                            td_stream_t stream) {
+  TD_REQUIRE(a && b && d, TD_ERR_INVALID, "td_gemm_bf16: null pointer");
+  TD_REQUIRE(dtype == TD_BF16 || dtype == TD_F16, TD_ERR_UNSUPPORTED, "td_gemm_bf16: operand dtype %d (bf16 | f16)", dtype);
+  TD_REQUIRE(out_dtype == dtype || out_dtype == TD_F32, TD_ERR_UNSUPPORTED, "td_gemm_bf16: output dtype %d (the operand dtype | f32)", out_dtype);
+  TD_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536, TD_ERR_INVALID, "td_gemm_bf16: empty problem or batch >= 65536");
+  TD_REQUIRE(k % 64 == 0, TD_ERR_UNSUPPORTED, "td_gemm_bf16: k = %lld must be a multiple of 64 (pad the operands' rows with zeros)", (long long)k);
+  TD_REQUIRE(lda >= k && ldb >= k && lda % 8 == 0 && ldb % 8 == 0, TD_ERR_INVALID, "td_gemm_bf16: lda / ldb must be >= k and multiples of 8");
+  TD_REQUIRE(epilogue >= G_EPI_NONE && epilogue <= G_EPI_GEGLU, TD_ERR_INVALID, "td_gemm_bf16: epilogue %d", epilogue);
+  const int64_t n_out = epilogue == G_EPI_GEGLU ? n / 2 : n;
+  TD_REQUIRE(ldd >= n_out, TD_ERR_INVALID, "td_gemm_bf16: ldd < n");
+  TD_REQUIRE(out_dtype == TD_F32 || ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_bf16: 16-bit output rows must start 16-byte aligned (ldd %% 8 == 0)");
+  TD_REQUIRE(epilogue != G_EPI_GEGLU || (n % 64 == 0 && !bias && !res && out_dtype == dtype), TD_ERR_UNSUPPORTED,
+             "td_gemm_bf16: the gated-GELU epilogue takes n %% 64 == 0 interleaved gate|fc1 rows, no bias, no residual");
+  TD_REQUIRE(!res || (out_dtype == dtype && epilogue == G_EPI_NONE && ldr >= n && ldr % 8 == 0), TD_ERR_UNSUPPORTED,
+             "td_gemm_bf16: the residual epilogue is 16-bit, plain, ldr %% 8 == 0");
+  TD_REQUIRE(out_dtype != TD_F32 || epilogue == G_EPI_NONE, TD_ERR_UNSUPPORTED, "td_gemm_bf16: fp32 output has the plain epilogue only");
+  // 32-bit byte offsets inside one batch entry's operands (buffer addressing)
+  TD_REQUIRE((m - 1) * lda * 2 + k * 2 < (1ll << 32) && (n - 1) * ldb * 2 + k * 2 < (1ll << 32), TD_ERR_UNSUPPORTED,
+             "td_gemm_bf16: an operand of one batch entry exceeds 4 GiB");
+  Gemm16P p;
+  p.A = (const uint16_t*)a; p.B = (const uint16_t*)b; p.bias = (const uint16_t*)bias; p.R = (const uint16_t*)res; p.D = d;
+  p.M = m; p.N = n; p.K = k; p.lda = lda; p.ldb = ldb; p.ldd = ldd; p.ldr = ldr;
+  p.sA = stride_a; p.sB = stride_b; p.sD = stride_d; p.sR = stride_r;
+  p.tiles_m = p.tiles_n = p.group_m = 0;
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == TD_BF16 ? dispatch_gemm16<TD_BF16>(p, out_dtype, epilogue, (int)batch, st)
+                          : dispatch_gemm16<TD_F16>(p, out_dtype, epilogue, (int)batch, st);
+}
+
+// ---- row softmax (VAE middle-block attention: F.scaled_dot_product_attention's softmax(q k^T / sqrt(C)); umT5:
+//      softmax(float(scores + position bias)), umt5.py:183-185) ----
+// S [rows, lds] (f32, or the 16-bit dtype) -> P [rows, ldp] 16-bit: P[r, c] = softmax_c(scale * S[r, c] (+ bias[r % bias_rows, c])),
+// columns [cols, ldp) are written as zeros (the P.V GEMM's K runs over the padded width).  With a 16-bit S the bias is added
+// in that dtype first (one rounding: the reference's `einsum(...) + attn_bias`), the softmax itself is fp32 and rounded once.
+template <int SDT, int PDT>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const void* __restrict__ S_, uint16_t* __restrict__ P, const uint16_t* __restrict__ bias,
+                                                           int64_t rows, int cols, int64_t lds, int64_t ldp, int64_t bias_rows,
+                                                           int64_t ldb, float scale) {
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ float red[8];
+  auto load = [&](int c) -> float {
+    float v;
+    if constexpr (SDT == TD_F32) v = reinterpret_cast<const float*>(S_)[row * lds + c];
+    else v = half_bits_to_f32<SDT>(reinterpret_cast<const uint16_t*>(S_)[row * lds + c]);
+    if (bias != nullptr) {
+      const float b = half_bits_to_f32<PDT>(bias[(row % bias_rows) * ldb + c]);
+      v = (SDT == TD_F32) ? v + b : round_half<PDT>(v + b);
+    }
+    return v * scale;
+  };
+  float mx = -INFINITY;
+  for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, load(c));
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid; c < cols; c += 256) sum += expf(load(c) - mx);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) red[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  sum = (red[4] + red[5]) + (red[6] + red[7]);
+  const float inv = 1.0f / sum;
+  for (int c = tid; c < (int)ldp; c += 256) {
+    uint32_t o = 0;
+    if (c < cols) o = f32_to_half_bits<PDT>(expf(load(c) - mx) * inv);
+    P[row * ldp + c] = (uint16_t)o;
+  }
+}
+
+extern "C" int td_softmax_rows(const void* s, int s_dtype, void* p, int p_dtype, const void* bias, int64_t rows, int64_t cols,
+                               int64_t lds, int64_t ldp, int64_t bias_rows, int64_t ldb, float scale, td_stream_t stream) {
+  TD_REQUIRE(s && p, TD_ERR_INVALID, "td_softmax_rows: null pointer");
+  TD_REQUIRE(p_dtype == TD_BF16 || p_dtype == TD_F16, TD_ERR_UNSUPPORTED, "td_softmax_rows: P dtype %d", p_dtype);
+  TD_REQUIRE(s_dtype == TD_F32 || s_dtype == p_dtype, TD_ERR_UNSUPPORTED, "td_softmax_rows: S dtype %d (f32 or P's)", s_dtype);
+  TD_REQUIRE(rows > 0 && rows < (1ll << 31) && cols > 0 && cols < (1 << 30) && lds >= cols && ldp >= cols, TD_ERR_INVALID,
+             "td_softmax_rows: shape");
+  TD_REQUIRE(!bias || (bias_rows > 0 && ldb >= cols), TD_ERR_INVALID, "td_softmax_rows: bias shape");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = (unsigned)rows;
+#define TD_SM_CASE(SD, PD) \
+  softmax_rows_kernel<SD, PD><<<g, 256, 0, st>>>(s, (uint16_t*)p, (const uint16_t*)bias, rows, (int)cols, lds, ldp, bias_rows ? bias_rows : 1, ldb, scale)
+  if (p_dtype == TD_BF16) { if (s_dtype == TD_F32) TD_SM_CASE(TD_F32, TD_BF16); else TD_SM_CASE(TD_BF16, TD_BF16); }
+  else { if (s_dtype == TD_F32) TD_SM_CASE(TD_F32, TD_F16); else TD_SM_CASE(TD_F16, TD_F16); }
+#undef TD_SM_CASE
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// ---- T5LayerNorm (umt5.py:130-142): x * rsqrt(mean(float(x)^2) + eps) in fp32, cast to the weight's 16-bit dtype, THEN
+//      multiplied by the weight in that dtype — two roundings (FastRMSNorm / td_rmsnorm multiplies in fp32 and rounds once).
+//      x [rows, n] 16-bit (row stride ldx) -> y [rows, n] (row stride ldy); one 256-thread workgroup per row. ----
+template <int DT>
+__global__ __launch_bounds__(256) void t5_norm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                      uint16_t* __restrict__ y, int n, int64_t ldx, int64_t ldy, float eps) {
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x;
+  __shared__ float red[4];
+  const uint16_t* xr = x + row * ldx;
+  float ss = 0.f;
+  for (int c = tid; c < n; c += 256) { const float v = half_bits_to_f32<DT>(xr[c]); ss = fmaf(v, v, ss); }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) red[tid >> 6] = ss;
+  __syncthreads();
+  ss = (red[0] + red[1]) + (red[2] + red[3]);
+  const float r = 1.0f / sqrtf(ss / (float)n + eps);
+  for (int c = tid; c < n; c += 256) {
+    const float xn = round_half<DT>(half_bits_to_f32<DT>(xr[c]) * r);
+    y[row * ldy + c] = (uint16_t)f32_to_half_bits<DT>(half_bits_to_f32<DT>(w[c]) * xn);
+  }
+}
+
+extern "C" int td_t5_norm(const void* x, const void* w, void* y, int dtype, float eps, int64_t rows, int64_t n, int64_t ldx,
+                          int64_t ldy, td_stream_t stream) {
+  TD_REQUIRE(x && w && y, TD_ERR_INVALID, "td_t5_norm: null pointer");
+  TD_REQUIRE(dtype == TD_BF16 || dtype == TD_F16, TD_ERR_UNSUPPORTED, "td_t5_norm: dtype %d (bf16 | f16)", dtype);
+  TD_REQUIRE(rows > 0 && rows < (1ll << 31) && n > 0 && n < (1 << 30) && ldx >= n && ldy >= n, TD_ERR_INVALID, "td_t5_norm: shape");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == TD_BF16) t5_norm_kernel<TD_BF16><<<(unsigned)rows, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (int)n, ldx, ldy, eps);
+  else t5_norm_kernel<TD_F16><<<(unsigned)rows, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)w, (uint16_t*)y, (int)n, ldx, ldy, eps);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}

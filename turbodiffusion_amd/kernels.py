@@ -837,3 +837,103 @@ def vae_chan_rms(x, gamma, silu=True):
     y = torch.empty_like(x)
     call("td_vae_chan_rms", ptr(x), ptr(gamma), ptr(y), x.numel() // x.shape[-1], x.shape[-1], int(silu), stream_ptr())
     return y
+
+
+# ----------------------------------------------------------------------------- 16-bit GEMM / softmax / T5 norm (gemm_bf16.hip)
+GEMM16_EPI = {"none": 0, "gelu_tanh": 1, "geglu": 2}
+
+
+def _pad_k64(t):
+    """[.., k] -> [.., ceil64(k)] zero-padded copy when k is not a multiple of 64 or the rows are not 16-byte aligned
+    (toy shapes only: every production width here is a multiple of 64)."""
+    k = t.shape[-1]
+    kp = cdiv(k, 64) * 64
+    if kp == k and t.stride(-1) == 1 and t.stride(-2) % 8 == 0 and t.data_ptr() % 16 == 0 and (t.dim() < 3 or t.stride(0) % 8 == 0):
+        return t
+    out = torch.zeros(t.shape[:-1] + (kp,), dtype=t.dtype, device=t.device)
+    out[..., :k] = t
+    return out
+
+
+def gemm_bf16(a, w, bias=None, res=None, epilogue="none", out_dtype=None, out=None):
+    """a [m, k] @ w [n, k]^T (+ bias [n]) -> [m, n] (``epilogue="geglu"``: [m, n / 2], w = interleaved gate|fc1 rows,
+    ``geglu_interleave``) in the operands' 16-bit dtype or fp32.  Row-strided 2-D views are taken as they are (last dim
+    contiguous, 16-byte aligned rows); res [m, n]: x + Linear(a)."""
+    require_gpu(a, w, bias, res, out)
+    assert a.dim() == 2 and w.dim() == 2 and a.dtype == w.dtype and a.dtype in (torch.bfloat16, torch.float16)
+    assert a.shape[1] == w.shape[1], (a.shape, w.shape)
+    a, w = _pad_k64(a), _pad_k64(w)
+    m, k = a.shape
+    n = w.shape[0]
+    odt = out_dtype or a.dtype
+    n_out = n // 2 if epilogue == "geglu" else n
+    if out is None:
+        out = torch.empty((m, n_out), dtype=odt, device=a.device)
+    assert tuple(out.shape) == (m, n_out) and out.dtype == odt and out.stride(1) == 1
+    if bias is not None:
+        assert bias.dtype == a.dtype and bias.numel() == n and bias.is_contiguous()
+    if res is not None:
+        assert res.dtype == a.dtype and tuple(res.shape) == (m, n) and res.stride(1) == 1
+    call("td_gemm_bf16", ptr(a), ptr(w), ptr(bias), ptr(res), ptr(out), L.dt_code(a.dtype), L.dt_code(odt), GEMM16_EPI[epilogue],
+         m, n, k, a.stride(0), w.stride(0), out.stride(0), 0 if res is None else res.stride(0), 1, 0, 0, 0, 0, stream_ptr())
+    return out
+
+
+def gemm_bf16_batched(a, b, out_dtype=None, out=None, bias=None):
+    """a [B, m, k] x b [B, n, k]^T (+ bias [n]) -> [B, m, n] per batch entry; a, b may be strided views (batch and row
+    strides free — batch stride 0 = one operand shared by all entries — last dim contiguous)."""
+    require_gpu(a, b, out, bias)
+    assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.shape[2] == b.shape[2] and a.dtype == b.dtype
+    a, b = _pad_k64(a), _pad_k64(b)
+    B, m, k = a.shape
+    n = b.shape[1]
+    odt = out_dtype or a.dtype
+    if out is None:
+        npad = n if odt == torch.float32 else cdiv(n, 8) * 8
+        out = torch.empty((B, m, npad), dtype=odt, device=a.device)[:, :, :n]
+    assert tuple(out.shape) == (B, m, n) and out.dtype == odt and out.stride(2) == 1
+    if bias is not None:
+        assert bias.dtype == a.dtype and bias.numel() == n and bias.is_contiguous()
+    call("td_gemm_bf16", ptr(a), ptr(b), ptr(bias), None, ptr(out), L.dt_code(a.dtype), L.dt_code(odt), 0, m, n, k, a.stride(1),
+         b.stride(1), out.stride(1), 0, B, a.stride(0), b.stride(0), out.stride(0), 0, stream_ptr())
+    return out
+
+
+def geglu_interleave(gate_w, fc1_w):
+    """[f, k], [f, k] -> [2 f, k] in the row order td_gemm_bf16's gated-GELU epilogue reads: blocks of 32 gate rows followed
+    by the 32 fc1 rows of the same output columns (f % 32 == 0)."""
+    f, k = gate_w.shape
+    assert fc1_w.shape == gate_w.shape and f % 32 == 0
+    return torch.stack([gate_w.view(f // 32, 32, k), fc1_w.view(f // 32, 32, k)], dim=1).reshape(2 * f, k).contiguous()
+
+
+def softmax_rows(s, scale=1.0, bias=None, out=None, out_dtype=None, padded=False):
+    """softmax over the last dim of s [rows, cols] (row stride free) -> out [rows, cols] 16-bit whose PADDED row (out's row
+    stride) is zero-filled behind ``cols``; bias [bias_rows, cols] 16-bit is added first (rows cycle).  padded: return the
+    [rows, ceil64(cols)] storage (what a following GEMM contracts over) instead of the [rows, cols] view."""
+    require_gpu(s, bias, out)
+    assert s.dim() == 2 and s.stride(1) == 1
+    rows, cols = s.shape
+    pdt = out_dtype or (torch.bfloat16 if s.dtype == torch.float32 else s.dtype)
+    full = None
+    if out is None:
+        ldp = cdiv(cols, 64) * 64
+        full = torch.empty((rows, ldp), dtype=pdt, device=s.device)
+        out = full[:, :cols]
+    assert tuple(out.shape) == (rows, cols) and out.dtype == pdt and out.stride(1) == 1
+    assert not padded or full is not None
+    if bias is not None:
+        assert bias.dim() == 2 and bias.dtype == pdt and bias.shape[1] == cols and bias.stride(1) == 1
+    call("td_softmax_rows", ptr(s), L.dt_code(s.dtype), ptr(out), L.dt_code(pdt), ptr(bias), rows, cols, s.stride(0), out.stride(0),
+         0 if bias is None else bias.shape[0], 0 if bias is None else bias.stride(0), float(scale), stream_ptr())
+    return full if padded else out
+
+
+def t5_norm(x, w, eps=1e-6):
+    """T5LayerNorm on [rows, n] 16-bit (two roundings, umt5.py:130-142)."""
+    require_gpu(x, w)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.dtype == x.dtype and w.numel() == x.shape[1] and w.is_contiguous()
+    y = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
+    call("td_t5_norm", ptr(x), ptr(w), ptr(y), L.dt_code(x.dtype), float(eps), x.shape[0], x.shape[1], x.stride(0), y.stride(0),
+         stream_ptr())
+    return y

@@ -17,26 +17,20 @@ What is different here, and why (results are the reference's — ``tests/test_va
     embedding, as umT5 does).
 The rounding points of the reference's 16-bit path are kept: T5LayerNorm scales in fp32, casts, then multiplies by the
 weight in the weight's dtype; scores are rounded before the bias is added; the softmax runs in fp32 and is cast back; the
-GELU is the same chain of element-wise operations.  Compute is PyTorch-ROCm library code (hipBLASLt GEMMs); no hand-written
-kernel — this row is outside the benchmark's metric.  Tokenisation (a HuggingFace tokenizer the reference downloads,
-umt5.py:58-89) is not part of this module: it takes ids and mask."""
+GELU is the same chain of element-wise operations, each rounded.  Compute is hand-written HIP (round 4; csrc/gemm_bf16.hip):
+every Linear is ``td_gemm_bf16`` (the residual adds in the o / fc2 epilogues, the gated GELU in the gate|fc1 epilogue, whose
+weight rows are interleaved once at load time), the per-head score and value products are batched ``td_gemm_bf16`` calls on
+strided views of the fused q|k|v output, ``td_softmax_rows`` adds the position bias (rounded, as the reference's 16-bit
+add) and normalises in fp32, ``td_t5_norm`` is T5LayerNorm with its two roundings.  torch is left with the token-embedding
+and position-table gathers (index plumbing).  HIP only: 16-bit on a GPU; the library-operator restatement the CPU pins run
+is ``oracle/f4_ref.py``.  Tokenisation (a HuggingFace tokenizer the reference downloads, umt5.py:58-89) is not part of
+this module: it takes ids and mask."""
 from __future__ import annotations
 
 import math
 
 import torch
 import torch.nn.functional as F
-
-
-def _t5_norm(x, w, eps=1e-6):
-    y = x * torch.rsqrt(x.float().pow(2).mean(dim=-1, keepdim=True) + eps)
-    if w.dtype in (torch.float16, torch.bfloat16):
-        y = y.type_as(w)
-    return w * y
-
-
-def _gelu_tanh(x):
-    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * torch.pow(x, 3.0))))
 
 
 def _fp16_clamp(x):
@@ -82,13 +76,18 @@ def synthetic_state_dict(layers=24, dim=4096, dim_ffn=10240, heads=64, vocab=256
 class Umt5Encoder:
     """``encoder(ids, mask)`` -> [B, L_pad, dim]: ``ids`` / ``mask`` [B, L_pad] as the reference's tokenizer returns them
     (padding on the right).  ``state_dict``: the reference encoder's (``models_t5_umt5-xxl-enc-bf16.pth`` layout); the
-    configuration is read off the tensors."""
+    configuration is read off the tensors.  16-bit on a GPU (the reference loads the bf16 checkpoint, umt5.py:478-488)."""
 
     def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", max_dist=128, eps=1e-6):
         self.dtype, self.device, self.max_dist, self.eps = dtype, torch.device(device), max_dist, eps
+        if dtype not in (torch.bfloat16, torch.float16) or self.device.type != "cuda":
+            raise ValueError("Umt5Encoder runs on the HIP kernels only: bf16 / fp16 on a GPU; the library-operator restatement "
+                             "for CPU checks is oracle/f4_ref.py")
+        from . import kernels as K_     # raises if the HIP library is missing
+        self.K = K_
 
         def t(k):
-            return state_dict[k].detach().to(device=self.device, dtype=dtype)
+            return state_dict[k].detach().to(device=self.device, dtype=dtype).contiguous()
 
         self.emb = t("token_embedding.weight")
         self.dim = self.emb.shape[1]
@@ -99,6 +98,9 @@ class Umt5Encoder:
             raise ValueError("not a T5 encoder state dict: blocks.0.norm1.weight missing")
         self.shared_pos = "pos_embedding.embedding.weight" in state_dict
         self.pos = t("pos_embedding.embedding.weight") if self.shared_pos else None
+        self.dim_ffn = state_dict["blocks.0.ffn.fc2.weight"].shape[1]
+        if self.dim_ffn % 32:
+            raise ValueError(f"dim_ffn = {self.dim_ffn}: the gated-GELU epilogue interleaves gate / fc1 in blocks of 32 columns")
         self.layers = []
         for i in range(n):
             p = f"blocks.{i}."
@@ -106,7 +108,7 @@ class Umt5Encoder:
                 "n1": t(p + "norm1.weight"), "n2": t(p + "norm2.weight"),
                 "qkv": torch.cat([t(p + "attn.q.weight"), t(p + "attn.k.weight"), t(p + "attn.v.weight")], 0).contiguous(),
                 "o": t(p + "attn.o.weight"),
-                "gf": torch.cat([t(p + "ffn.gate.0.weight"), t(p + "ffn.fc1.weight")], 0).contiguous(),
+                "gf": K_.geglu_interleave(t(p + "ffn.gate.0.weight"), t(p + "ffn.fc1.weight")),
                 "fc2": t(p + "ffn.fc2.weight"),
                 "pos": None if self.shared_pos else t(p + "pos_embedding.embedding.weight"),
             }
@@ -115,7 +117,6 @@ class Umt5Encoder:
         pos0 = self.pos if self.shared_pos else self.layers[0]["pos"]
         self.num_buckets, self.num_heads = pos0.shape
         self.dim_attn = self.layers[0]["o"].shape[1]
-        self.dim_ffn = self.layers[0]["fc2"].shape[1]
         assert self.dim_attn % self.num_heads == 0
 
     @classmethod
@@ -125,22 +126,31 @@ class Umt5Encoder:
 
     def _rows(self, ids):
         """ids [n] (one prompt's valid tokens) -> [n, dim]"""
+        K = self.K
         n, H, c = ids.shape[0], self.num_heads, self.dim_attn // self.num_heads
-        x = F.embedding(ids, self.emb)
+        n64 = K.cdiv(n, 64) * 64
+        x = F.embedding(ids, self.emb)                                             # gather (plumbing)
         buckets = relative_buckets(n, self.num_buckets, self.max_dist, self.device)
-        shared = None if not self.shared_pos else F.embedding(buckets, self.pos).permute(2, 0, 1)
+
+        def bias_of(table):   # [H, n, n] -> rows of the score matrix [H * n, n] (gather: plumbing)
+            return F.embedding(buckets, table).permute(2, 0, 1).contiguous().view(H * n, n)
+
+        shared = bias_of(self.pos) if self.shared_pos else None
+        s_buf = torch.empty((H, n, n64), dtype=self.dtype, device=self.device)     # scores, then probabilities, in place
+        vt = torch.zeros((H, c, n64), dtype=self.dtype, device=self.device)        # V^T, zero behind the n valid keys
         for lay in self.layers:
-            bias = shared if shared is not None else F.embedding(buckets, lay["pos"]).permute(2, 0, 1)   # [H, n, n]
-            qkv = F.linear(_t5_norm(x, lay["n1"], self.eps), lay["qkv"]).view(n, 3, H, c)
-            q, k, v = qkv[:, 0].transpose(0, 1), qkv[:, 1].transpose(0, 1), qkv[:, 2].transpose(0, 1)   # [H, n, c]
-            s = torch.matmul(q, k.transpose(1, 2)) + bias                      # no scaling (umt5.py:183)
-            a = F.softmax(s.float(), dim=-1).type_as(s)
-            o = torch.matmul(a, v).transpose(0, 1).reshape(n, H * c)
-            x = _fp16_clamp(x + F.linear(o, lay["o"]))
-            gf = F.linear(_t5_norm(x, lay["n2"], self.eps), lay["gf"])
-            h = gf[:, self.dim_ffn:] * _gelu_tanh(gf[:, :self.dim_ffn])        # fc1(x) * gelu(gate(x)), umt5.py:210
-            x = _fp16_clamp(x + F.linear(h, lay["fc2"]))
-        return _t5_norm(x, self.final_norm, self.eps)
+            bias = shared if shared is not None else bias_of(lay["pos"])
+            qkv = K.gemm_bf16(K.t5_norm(x, lay["n1"], self.eps), lay["qkv"]).view(n, 3, H, c)
+            q, k = qkv[:, 0].transpose(0, 1), qkv[:, 1].transpose(0, 1)            # [H, n, c] strided views
+            vt[:, :, :n] = qkv[:, 2].permute(1, 2, 0)
+            s = K.gemm_bf16_batched(q, k, out=s_buf[:, :, :n])                     # no 1/sqrt(d) scaling (umt5.py:183)
+            K.softmax_rows(s_buf.view(H * n, n64)[:, :n], 1.0, bias=bias, out=s_buf.view(H * n, n64)[:, :n])
+            o = K.gemm_bf16_batched(s_buf, vt)                                     # [H, n, c]  (k = n64: zero columns x zero rows)
+            o = o.transpose(0, 1).reshape(n, H * c)
+            x = _fp16_clamp(K.gemm_bf16(o, lay["o"], res=x))                       # x + o(attn)
+            h = K.gemm_bf16(K.t5_norm(x, lay["n2"], self.eps), lay["gf"], epilogue="geglu")   # fc1(x) * gelu(gate(x)), umt5.py:210
+            x = _fp16_clamp(K.gemm_bf16(h, lay["fc2"], res=x))
+        return K.t5_norm(x, self.final_norm, self.eps)
 
     @torch.no_grad()
     def __call__(self, ids, mask=None):

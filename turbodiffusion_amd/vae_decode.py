@@ -14,14 +14,16 @@ convolution, no doubling — the reference marks its cache ``"Rep"``, wan2pt1.py
 frames 1.. with zeros to the left (frame 0 is not part of that window).  ``tests/test_vae_umt5_cpu.py`` pins this module to
 the reference's own chunked ``WanVAE_.decode`` (live import, random weights, fp32).
 
-Two backends.  ``"hip"`` (the default on a GPU, bf16 only): activations channels-last [B, T, H, W, C]; every 3x3x3 / 3x3 /
-(3,1,1) convolution is ``td_vae_conv`` — one implicit-GEMM kernel on the bf16 matrix pipe (csrc/vae_conv.hip) with the
-causal / spatial zero padding, the nearest x2 up-sampling and the time up-sampler's frame interleave folded into its gather
-and store, bias and the residual add in its epilogue; the channel RMS-norm + SiLU is ``td_vae_chan_rms``; the 1x1
-convolutions are GEMMs on the same layout (hipBLASLt) and the single-head per-frame attention of the middle block is SDPA.
+HIP only (bf16 on a GPU; without the HIP library or off the GPU the constructor raises, like every operator of this
+package — the library-operator restatement of the same whole-clip graph that the CPU pins run is test infrastructure:
+``oracle/f4_ref.py``).  Activations channels-last [B, T, H, W, C]; every 3x3x3 / 3x3 / (3,1,1) convolution is ``td_vae_conv`` —
+one implicit-GEMM kernel on the bf16 matrix pipe (csrc/vae_conv.hip) with the causal / spatial zero padding, the nearest x2
+up-sampling and the time up-sampler's frame interleave folded into its gather and store, bias and the residual add in its
+epilogue; the channel RMS-norm + SiLU is ``td_vae_chan_rms``; the 1x1 convolutions (shortcuts, to_qkv, proj, conv2) run on
+the same layout through ``td_gemm_bf16`` (csrc/gemm_bf16.hip) and the single-head per-frame attention of the middle block as
+two of those GEMMs around ``td_softmax_rows`` (the [hw, hw] score matrix of a frame is 78 MB at 480p: it simply lives in HBM).
 (MIOpen's 3-D convolutions are not an option here: a 480p decode did not finish in 8 minutes on a fresh box — per-shape
-solver search and kernel compilation, then naive fallbacks.)  ``"torch"``: the same graph from library operators in NCDHW,
-any dtype — what the CPU pins run.  Weights: the reference's own ``state_dict`` (keys ``decoder.*`` and ``conv2.*``; the
+solver search and kernel compilation, then naive fallbacks.)  Weights: the reference's own ``state_dict`` (keys ``decoder.*`` and ``conv2.*``; the
 architecture is read off the keys, no config needed)."""
 from __future__ import annotations
 
@@ -29,7 +31,6 @@ import math
 import re
 
 import torch
-import torch.nn.functional as F
 
 # per-channel statistics of the 16 latent channels (rcm/tokenizers/wan2pt1.py:607-642): z_model = z * std + mean
 LATENT_MEAN = (-0.7571, -0.7089, -0.9113, 0.1075, -0.1745, 0.9653, -0.1517, 1.5508,
@@ -38,71 +39,24 @@ LATENT_STD = (2.8184, 1.4541, 2.3275, 2.6558, 1.2196, 1.7708, 2.6052, 2.0743,
               3.2687, 2.1526, 2.8652, 1.5579, 1.6382, 1.1253, 2.8251, 1.9160)
 
 
-def _chan_rms(x, gamma):
-    """RMS_norm, channel first (wan2pt1.py:69-70): x / max(||x||_2 over C, 1e-12) * sqrt(C) * gamma."""
-    return F.normalize(x, dim=1) * (x.shape[1] ** 0.5) * gamma
+# channels-last stages on csrc/vae_conv.hip
+def latent_stats(mean, std, z_dim, dtype, device):
+    """(mean, 1 / std) [1, C, 1, 1, 1] as the reference forms them (wan2pt1.py:643-645: ``torch.tensor(std, dtype=dtype)``,
+    then ``1.0 / self.std``): the statistics are rounded to ``dtype`` FIRST and the reciprocal is taken IN ``dtype`` — in
+    bf16 that is one ulp away from the rounded fp64 reciprocal on 6 of the 16 channels (0.4-0.8 %)."""
+    if len(mean) != z_dim or len(std) != z_dim:   # (tests use a 4-channel toy)
+        mean, std = (0.0,) * z_dim, (1.0,) * z_dim
+    m = torch.tensor(mean, dtype=dtype, device=device).view(1, -1, 1, 1, 1)
+    inv = (1.0 / torch.tensor(std, dtype=dtype, device=device)).view(1, -1, 1, 1, 1)
+    return m, inv
 
 
-def _causal_conv(x, w, b):
-    """CausalConv3d over the WHOLE clip: (kt - 1) zero frames on the left, symmetric spatial padding (wan2pt1.py:42-55)."""
-    kt, kh, kw = w.shape[2:]
-    if kt > 1 or kh > 1 or kw > 1:
-        x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, kt - 1, 0))
-    return F.conv3d(x, w, b)
+def pointwise_conv(K, x, w, b, res=None):
+    """1x1(x1) convolution on channels-last activations [B, T, H, W, Ci] (Ci % 32 == 0): td_vae_conv with ONE tap — the same
+    implicit-GEMM kernel as the 3x3x3 convolutions (bias and the residual add in its epilogue)."""
+    return K.vae_conv(x, w, b, 1, 1, 1, res=res)
 
 
-class _Res:
-    def __init__(self, g):
-        self.n1, self.w1, self.b1 = g("residual.0.gamma"), g("residual.2.weight"), g("residual.2.bias")
-        self.n2, self.w2, self.b2 = g("residual.3.gamma"), g("residual.6.weight"), g("residual.6.bias")
-        self.ws, self.bs = g("shortcut.weight", None), g("shortcut.bias", None)
-
-    def __call__(self, x):
-        h = x if self.ws is None else F.conv3d(x, self.ws, self.bs)
-        y = _causal_conv(F.silu(_chan_rms(x, self.n1)), self.w1, self.b1)
-        y = _causal_conv(F.silu(_chan_rms(y, self.n2)), self.w2, self.b2)
-        return y + h
-
-
-class _FrameAttention:
-    """single-head self-attention over the h*w positions of every frame (wan2pt1.py:229-248)"""
-
-    def __init__(self, g):
-        self.n, self.wq, self.bq, self.wp, self.bp = g("norm.gamma"), g("to_qkv.weight"), g("to_qkv.bias"), g("proj.weight"), g("proj.bias")
-
-    def __call__(self, x):
-        B, C, T, H, W = x.shape
-        f = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
-        qkv = F.conv2d(_chan_rms(f, self.n), self.wq, self.bq).reshape(B * T, 1, 3 * C, H * W).transpose(2, 3)
-        q, k, v = qkv.contiguous().chunk(3, dim=-1)
-        o = F.scaled_dot_product_attention(q, k, v).squeeze(1).transpose(1, 2).reshape(B * T, C, H, W)
-        o = F.conv2d(o, self.wp, self.bp)
-        return o.reshape(B, T, C, H, W).permute(0, 2, 1, 3, 4) + x
-
-
-class _Up:
-    """Resample 'upsample2d' / 'upsample3d' (wan2pt1.py:94-131): [time: frame 0 untouched, frames 1.. -> causal (3,1,1)
-    convolution to 2C channels, the two halves interleaved in time]; then per frame nearest x2 + 3x3 conv to C/2."""
-
-    def __init__(self, g):
-        self.w, self.b = g("resample.1.weight"), g("resample.1.bias")
-        self.wt, self.bt = g("time_conv.weight", None), g("time_conv.bias", None)
-
-    def __call__(self, x):
-        B, C, T, H, W = x.shape
-        if self.wt is not None and T > 1:
-            y = _causal_conv(x[:, :, 1:], self.wt, self.bt)                       # [B, 2C, T-1, H, W]
-            y = y.reshape(B, 2, C, T - 1, H, W).permute(0, 2, 3, 1, 4, 5).reshape(B, C, 2 * (T - 1), H, W)
-            x = torch.cat([x[:, :, :1], y], dim=2)
-            T = x.shape[2]
-        f = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
-        f = F.interpolate(f, scale_factor=2.0, mode="nearest-exact")
-        f = F.conv2d(f, self.w, self.b, padding=1)
-        return f.reshape(B, T, f.shape[1], 2 * H, 2 * W).permute(0, 2, 1, 3, 4)
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# "hip" backend: channels-last stages on csrc/vae_conv.hip
 def _k2d(w):
     """[Co, Ci, (kt,) kh, kw] -> [Co, kt*kh*kw*Ci], K ordered (dt, dh, dw, c) (td_vae_conv)"""
     if w.dim() == 4:
@@ -121,25 +75,44 @@ class _HipRes:
 
     def __call__(self, x):
         K = self.K
-        h = x if self.ws is None else F.linear(x, self.ws, self.bs)
+        h = x if self.ws is None else pointwise_conv(K, x, self.ws, self.bs)
         y = K.vae_conv(K.vae_chan_rms(x, self.n1), self.w1, self.b1, 3, 3, 3)
         return K.vae_conv(K.vae_chan_rms(y, self.n2), self.w2, self.b2, 3, 3, 3, res=h)
 
 
 class _HipFrameAttention:
+    """single-head self-attention over the h*w positions of every frame (AttentionBlock, wan2pt1.py:212-248): S = q k^T per
+    frame in fp32 (td_gemm_bf16, batched over the frames: the [hw, hw] score matrix of a frame is 156 MB at 480p and simply
+    lives in HBM), row softmax with the 1/sqrt(C) scale (td_softmax_rows -> bf16 P, zero-padded to a multiple of 64 keys),
+    O = P v (td_gemm_bf16 against v^T, which a batched GEMM with the roles swapped produces directly: v^T = W_v x^T), proj +
+    residual in td_vae_conv's epilogue.  The v bias rides on the P.v product's epilogue (rows of P sum to 1: P (v + b) =
+    P v + b; one rounding of v + b less than the reference's bf16 path)."""
+
     def __init__(self, g, K):
         self.K = K
         self.n = g("norm.gamma").reshape(-1).contiguous()
-        wq, wp = g("to_qkv.weight"), g("proj.weight")
-        self.wq, self.bq = wq.reshape(wq.shape[0], -1).contiguous(), g("to_qkv.bias")
-        self.wp, self.bp = wp.reshape(wp.shape[0], -1).contiguous(), g("proj.bias")
+        wq, bq, wp = g("to_qkv.weight"), g("to_qkv.bias"), g("proj.weight")
+        C = wp.shape[0]
+        wq = wq.reshape(3 * C, C)
+        self.wq, self.wk, self.wv = (wq[i * C:(i + 1) * C].contiguous() for i in range(3))
+        self.bq, self.bk, self.bv = (bq[i * C:(i + 1) * C].contiguous() for i in range(3))
+        self.wp, self.bp = wp.reshape(C, C).contiguous(), g("proj.bias")
 
     def __call__(self, x):
+        K = self.K
         B, T, H, W, C = x.shape
-        qkv = F.linear(self.K.vae_chan_rms(x, self.n, silu=False).view(B * T, 1, H * W, C), self.wq, self.bq)
-        q, k, v = qkv.chunk(3, dim=-1)
-        o = F.scaled_dot_product_attention(q.contiguous(), k.contiguous(), v.contiguous())
-        return F.linear(o, self.wp, self.bp).view(B, T, H, W, C) + x
+        n, hw = B * T, H * W
+        hwp = K.cdiv(hw, 64) * 64
+        xn = K.vae_chan_rms(x, self.n, silu=False)
+        q = pointwise_conv(K, xn, self.wq, self.bq).view(n, hw, C)
+        k = pointwise_conv(K, xn, self.wk, self.bk).view(n, hw, C)
+        vt = torch.zeros((n, C, hwp), dtype=x.dtype, device=x.device)         # V^T per frame, zero behind the hw positions
+        K.gemm_bf16_batched(self.wv.unsqueeze(0).expand(n, C, C), xn.view(n, hw, C), out=vt[:, :, :hw])
+        s = K.gemm_bf16_batched(q, k, out_dtype=torch.float32)                # [n, hw, hw] fp32
+        p = K.softmax_rows(s.view(n * hw, hw), C ** -0.5, out_dtype=x.dtype, padded=True)   # [n * hw, hwp]
+        del s
+        o = K.gemm_bf16_batched(p.view(n, hw, hwp), vt, bias=self.bv)         # [n, hw, C]
+        return pointwise_conv(K, o.reshape(B, T, H, W, C), self.wp, self.bp, res=x)
 
 
 class _HipUp:
@@ -215,27 +188,20 @@ def synthetic_state_dict(dim=96, z_dim=16, seed=0, dtype=torch.bfloat16, device=
 class WanVaeDecoder:
     """``decode(z)``: normalised latents (what the sampler returns) -> video in about [-1, 1], dtype of ``z``
     (WanVAE.decode, wan2pt1.py:674-681).  ``state_dict``: the reference VAE's (``WanVAE_``); only ``conv2.*`` and
-    ``decoder.*`` are used."""
+    ``decoder.*`` are used.  bf16 on a GPU (the reference interface's dtype, wan2pt1.py:686-690); anything else raises."""
 
-    def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", mean=LATENT_MEAN, std=LATENT_STD, backend=None):
+    def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", mean=LATENT_MEAN, std=LATENT_STD):
         self.dtype, self.device = dtype, torch.device(device)
-        self.backend = backend or ("hip" if self.device.type == "cuda" and dtype == torch.bfloat16 else "torch")
-        if self.backend not in ("hip", "torch"):
-            raise ValueError(f"backend {backend!r}")
-        if self.backend == "hip":
-            if dtype != torch.bfloat16 or self.device.type != "cuda":
-                raise ValueError("the hip backend is bf16 on a GPU (the reference interface's dtype, wan2pt1.py:686-690)")
-            from . import kernels as K_     # raises if the HIP library is missing
+        if dtype != torch.bfloat16 or self.device.type != "cuda":
+            raise ValueError("WanVaeDecoder runs on the HIP kernels only: bf16 on a GPU (the reference interface's dtype, "
+                             "wan2pt1.py:686-690); the library-operator restatement for CPU checks is oracle/f4_ref.py")
+        from . import kernels as K_     # raises if the HIP library is missing
         sd = {k: v.detach().to(device=self.device, dtype=dtype) for k, v in state_dict.items()
               if k.startswith(("decoder.", "conv2."))}
         if "decoder.conv1.weight" not in sd or "conv2.weight" not in sd:
             raise ValueError("not a Wan VAE state dict: decoder.conv1.weight / conv2.weight missing")
         self.z_dim = sd["conv2.weight"].shape[0]
-        if len(mean) != self.z_dim or len(std) != self.z_dim:   # (tests use a 4-channel toy)
-            mean, std = (0.0,) * self.z_dim, (1.0,) * self.z_dim
-        self.mean = torch.tensor(mean, dtype=dtype, device=self.device).view(1, -1, 1, 1, 1)
-        self.inv_scale = torch.tensor([1.0 / s for s in std], dtype=dtype, device=self.device)   # the reference divides by 1/std
-        self.inv_scale = self.inv_scale.view(1, -1, 1, 1, 1)
+        self.mean, self.inv_scale = latent_stats(mean, std, self.z_dim, dtype, self.device)
         self.sd = sd
 
         def getter(prefix):
@@ -248,36 +214,33 @@ class WanVaeDecoder:
                 raise KeyError(key)
             return g
 
-        hipb = self.backend == "hip"
-        mk_res = (lambda g: _HipRes(g, K_)) if hipb else _Res
-        mk_att = (lambda g: _HipFrameAttention(g, K_)) if hipb else _FrameAttention
-        mk_up = (lambda g: _HipUp(g, K_)) if hipb else _Up
-        self.stages = [mk_res(getter("decoder.middle.0.")), mk_att(getter("decoder.middle.1.")), mk_res(getter("decoder.middle.2."))]
+        self.stages = [_HipRes(getter("decoder.middle.0."), K_), _HipFrameAttention(getter("decoder.middle.1."), K_),
+                       _HipRes(getter("decoder.middle.2."), K_)]
         idx = sorted({int(m.group(1)) for k in sd for m in [re.match(r"decoder\.upsamples\.(\d+)\.", k)] if m})
         for i in idx:
             p = f"decoder.upsamples.{i}."
             if p + "residual.0.gamma" in sd:
-                self.stages.append(mk_res(getter(p)))
+                self.stages.append(_HipRes(getter(p), K_))
             elif p + "resample.1.weight" in sd:
-                self.stages.append(mk_up(getter(p)))
+                self.stages.append(_HipUp(getter(p), K_))
             elif p + "to_qkv.weight" in sd:
-                self.stages.append(mk_att(getter(p)))
+                self.stages.append(_HipFrameAttention(getter(p), K_))
             else:
                 raise ValueError(f"unrecognised decoder stage {p}*")
-        self.t_up = sum(1 for s in self.stages if isinstance(s, (_Up, _HipUp)) and s.wt is not None)
-        self.s_up = sum(1 for s in self.stages if isinstance(s, (_Up, _HipUp)))
-        if hipb:
-            self.K = K_
-            zc = self.z_dim
-            zp = -(-zc // 32) * 32              # td_vae_conv wants C_in % 32 == 0: conv2 writes zero channels up to there
-            w2 = torch.zeros(zp, zc, dtype=dtype, device=self.device)
-            b2 = torch.zeros(zp, dtype=dtype, device=self.device)
-            w2[:zc], b2[:zc] = sd["conv2.weight"].reshape(zc, zc), sd["conv2.bias"]
-            w1 = sd["decoder.conv1.weight"]
-            w1p = torch.zeros(w1.shape[0], zp, *w1.shape[2:], dtype=dtype, device=self.device)
-            w1p[:, :zc] = w1
-            self.h_conv2, self.h_conv1 = (w2, b2), (_k2d(w1p), sd["decoder.conv1.bias"])
-            self.h_head = (sd["decoder.head.0.gamma"].reshape(-1).contiguous(), _k2d(sd["decoder.head.2.weight"]), sd["decoder.head.2.bias"])
+        self.t_up = sum(1 for s in self.stages if isinstance(s, _HipUp) and s.wt is not None)
+        self.s_up = sum(1 for s in self.stages if isinstance(s, _HipUp))
+        self.K = K_
+        zc = self.z_dim
+        zp = -(-zc // 32) * 32              # td_vae_conv wants C_in % 32 == 0: zero channels up to there, in and out of conv2
+        w2 = torch.zeros(zp, zp, dtype=dtype, device=self.device)
+        b2 = torch.zeros(zp, dtype=dtype, device=self.device)
+        w2[:zc, :zc], b2[:zc] = sd["conv2.weight"].reshape(zc, zc), sd["conv2.bias"]
+        self.zp = zp
+        w1 = sd["decoder.conv1.weight"]
+        w1p = torch.zeros(w1.shape[0], zp, *w1.shape[2:], dtype=dtype, device=self.device)
+        w1p[:, :zc] = w1
+        self.h_conv2, self.h_conv1 = (w2, b2), (_k2d(w1p), sd["decoder.conv1.bias"])
+        self.h_head = (sd["decoder.head.0.gamma"].reshape(-1).contiguous(), _k2d(sd["decoder.head.2.weight"]), sd["decoder.head.2.bias"])
 
     @classmethod
     def from_reference(cls, vae_module_or_state_dict, **kw):
@@ -290,22 +253,15 @@ class WanVaeDecoder:
     @torch.no_grad()
     def decode(self, z):
         in_dtype = z.dtype
-        sd = self.sd
+        K = self.K
         x = z.to(device=self.device, dtype=self.dtype)
         x = x / self.inv_scale + self.mean                                     # WanVAE_.decode, wan2pt1.py:523-526
-        if self.backend == "hip":
-            K = self.K
-            x = F.linear(x.permute(0, 2, 3, 4, 1), *self.h_conv2)             # channels-last from here on; conv2 is 1x1x1
-            x = K.vae_conv(x.contiguous(), self.h_conv1[0], self.h_conv1[1], 3, 3, 3)
-            for st in self.stages:
-                x = st(x)
-            g, w, b = self.h_head
-            x = K.vae_conv(K.vae_chan_rms(x, g), w, b, 3, 3, 3)                # [B, T, H, W, 3]
-            return x.permute(0, 4, 1, 2, 3).contiguous().to(in_dtype)
-        x = F.conv3d(x, sd["conv2.weight"], sd["conv2.bias"])
-        x = _causal_conv(x, sd["decoder.conv1.weight"], sd["decoder.conv1.bias"])
+        xz = torch.zeros(x.shape[0], *x.shape[2:], self.zp, dtype=self.dtype, device=self.device)
+        xz[..., :self.z_dim] = x.permute(0, 2, 3, 4, 1)                        # channels-last from here on, 16 -> 32 zero-padded
+        x = pointwise_conv(K, xz, *self.h_conv2)                               # conv2 is 1x1x1
+        x = K.vae_conv(x, self.h_conv1[0], self.h_conv1[1], 3, 3, 3)
         for st in self.stages:
             x = st(x)
-        x = F.silu(_chan_rms(x, sd["decoder.head.0.gamma"]))
-        x = _causal_conv(x, sd["decoder.head.2.weight"], sd["decoder.head.2.bias"])
-        return x.to(in_dtype)
+        g, w, b = self.h_head
+        x = K.vae_conv(K.vae_chan_rms(x, g), w, b, 3, 3, 3)                # [B, T, H, W, 3]
+        return x.permute(0, 4, 1, 2, 3).contiguous().to(in_dtype)

@@ -11,8 +11,9 @@ convolution of the whole clip; the temporal down-samplers are the one special ca
 passes through unconvolved and frames 1.. are produced by the stride-2, unpadded (3,1,1) convolution over the whole
 sequence — windows (0,1,2), (2,3,4), ... — which is what the reference's "last frame of the previous chunk + this chunk"
 computes when the chunks are 1, 4, 4, ... frames (so T must be 1 + 4k, the only lengths the reference's chunking accepts).
-The spatial down-sampler is ZeroPad2d((0, 1, 0, 1)) + 3x3 stride 2.  Backends as in vae_decode.py: ``"hip"`` (bf16 on a GPU:
-td_vae_conv / td_vae_conv_ex / td_vae_chan_rms, channels-last) and ``"torch"`` (library operators, any dtype; the CPU pins).
+The spatial down-sampler is ZeroPad2d((0, 1, 0, 1)) + 3x3 stride 2.  HIP only, as vae_decode.py (bf16 on a GPU: td_vae_conv /
+td_vae_conv_ex / td_vae_chan_rms / td_gemm_bf16, channels-last); the library-operator restatement for the CPU pins is
+``oracle/f4_ref.py``.
 Weights: the reference's ``state_dict`` (keys ``encoder.*`` and ``conv1.*``)."""
 from __future__ import annotations
 
@@ -20,27 +21,8 @@ import math
 import re
 
 import torch
-import torch.nn.functional as F
 
-from .vae_decode import (LATENT_MEAN, LATENT_STD, _FrameAttention, _HipFrameAttention, _HipRes, _Res, _causal_conv, _chan_rms,
-                         _k2d)
-
-
-class _Down:
-    """Resample 'downsample2d' / 'downsample3d' (wan2pt1.py:133-149), NCDHW"""
-
-    def __init__(self, g):
-        self.w, self.b = g("resample.1.weight"), g("resample.1.bias")
-        self.wt, self.bt = g("time_conv.weight", None), g("time_conv.bias", None)
-
-    def __call__(self, x):
-        B, C, T, H, W = x.shape
-        f = x.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
-        f = F.conv2d(F.pad(f, (0, 1, 0, 1)), self.w, self.b, stride=2)
-        x = f.reshape(B, T, C, f.shape[2], f.shape[3]).permute(0, 2, 1, 3, 4)
-        if self.wt is not None and T > 1:
-            x = torch.cat([x[:, :, :1], F.conv3d(x, self.wt, self.bt, stride=(2, 1, 1))], dim=2)
-        return x
+from .vae_decode import LATENT_MEAN, LATENT_STD, _HipFrameAttention, _HipRes, _k2d, latent_stats, pointwise_conv
 
 
 class _HipDown:
@@ -112,27 +94,20 @@ def synthetic_state_dict(dim=96, z_dim=16, seed=0, dtype=torch.bfloat16, device=
 class WanVaeEncoder:
     """``encode(video)`` -> normalised latent mean (``WanVAE.encode``, wan2pt1.py:661-672; ``WanVAE_.encode`` :479-511)."""
 
-    def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", mean=LATENT_MEAN, std=LATENT_STD, backend=None):
+    def __init__(self, state_dict, dtype=torch.bfloat16, device="cuda", mean=LATENT_MEAN, std=LATENT_STD):
         self.dtype, self.device = dtype, torch.device(device)
-        self.backend = backend or ("hip" if self.device.type == "cuda" and dtype == torch.bfloat16 else "torch")
-        if self.backend not in ("hip", "torch"):
-            raise ValueError(f"backend {backend!r}")
-        hipb = self.backend == "hip"
-        if hipb:
-            if dtype != torch.bfloat16 or self.device.type != "cuda":
-                raise ValueError("the hip backend is bf16 on a GPU")
-            from . import kernels as K_     # raises if the HIP library is missing
-            self.K = K_
+        if dtype != torch.bfloat16 or self.device.type != "cuda":
+            raise ValueError("WanVaeEncoder runs on the HIP kernels only: bf16 on a GPU; the library-operator restatement for "
+                             "CPU checks is oracle/f4_ref.py")
+        from . import kernels as K_     # raises if the HIP library is missing
+        self.K = K_
         sd = {k: v.detach().to(device=self.device, dtype=dtype) for k, v in state_dict.items()
               if k.startswith(("encoder.", "conv1."))}
         if "encoder.conv1.weight" not in sd or "conv1.weight" not in sd:
             raise ValueError("not a Wan VAE state dict: encoder.conv1.weight / conv1.weight missing")
         self.sd = sd
         self.z_dim = sd["conv1.weight"].shape[0] // 2
-        if len(mean) != self.z_dim or len(std) != self.z_dim:
-            mean, std = (0.0,) * self.z_dim, (1.0,) * self.z_dim
-        self.mean = torch.tensor(mean, dtype=dtype, device=self.device).view(1, -1, 1, 1, 1)
-        self.inv_std = torch.tensor([1.0 / s for s in std], dtype=dtype, device=self.device).view(1, -1, 1, 1, 1)
+        self.mean, self.inv_std = latent_stats(mean, std, self.z_dim, dtype, self.device)
 
         def getter(prefix):
             def g(name, *default):
@@ -144,30 +119,27 @@ class WanVaeEncoder:
                 raise KeyError(key)
             return g
 
-        mk_res = (lambda g: _HipRes(g, K_)) if hipb else _Res
-        mk_att = (lambda g: _HipFrameAttention(g, K_)) if hipb else _FrameAttention
-        mk_down = (lambda g: _HipDown(g, K_)) if hipb else _Down
         self.stages = []
         for i in sorted({int(m.group(1)) for k in sd for m in [re.match(r"encoder\.downsamples\.(\d+)\.", k)] if m}):
             p = f"encoder.downsamples.{i}."
             if p + "residual.0.gamma" in sd:
-                self.stages.append(mk_res(getter(p)))
+                self.stages.append(_HipRes(getter(p), K_))
             elif p + "resample.1.weight" in sd:
-                self.stages.append(mk_down(getter(p)))
+                self.stages.append(_HipDown(getter(p), K_))
             elif p + "to_qkv.weight" in sd:
-                self.stages.append(mk_att(getter(p)))
+                self.stages.append(_HipFrameAttention(getter(p), K_))
             else:
                 raise ValueError(f"unrecognised encoder stage {p}*")
-        self.stages += [mk_res(getter("encoder.middle.0.")), mk_att(getter("encoder.middle.1.")), mk_res(getter("encoder.middle.2."))]
-        self.t_down = sum(1 for s in self.stages if isinstance(s, (_Down, _HipDown)) and s.wt is not None)
-        if hipb:
-            w1 = sd["encoder.conv1.weight"]                    # [dim, 3, 3, 3, 3]: td_vae_conv wants C_in % 32 == 0
-            w1p = torch.zeros(w1.shape[0], 32, *w1.shape[2:], dtype=dtype, device=self.device)
-            w1p[:, :w1.shape[1]] = w1
-            self.h_conv1 = (_k2d(w1p), sd["encoder.conv1.bias"])
-            self.h_head = (sd["encoder.head.0.gamma"].reshape(-1).contiguous(), _k2d(sd["encoder.head.2.weight"]), sd["encoder.head.2.bias"])
-            wc = sd["conv1.weight"]
-            self.h_out = (wc.reshape(wc.shape[0], -1).contiguous(), sd["conv1.bias"])
+        self.stages += [_HipRes(getter("encoder.middle.0."), K_), _HipFrameAttention(getter("encoder.middle.1."), K_),
+                        _HipRes(getter("encoder.middle.2."), K_)]
+        self.t_down = sum(1 for s in self.stages if isinstance(s, _HipDown) and s.wt is not None)
+        w1 = sd["encoder.conv1.weight"]                    # [dim, 3, 3, 3, 3]: td_vae_conv wants C_in % 32 == 0
+        w1p = torch.zeros(w1.shape[0], 32, *w1.shape[2:], dtype=dtype, device=self.device)
+        w1p[:, :w1.shape[1]] = w1
+        self.h_conv1 = (_k2d(w1p), sd["encoder.conv1.bias"])
+        self.h_head = (sd["encoder.head.0.gamma"].reshape(-1).contiguous(), _k2d(sd["encoder.head.2.weight"]), sd["encoder.head.2.bias"])
+        wc = sd["conv1.weight"]
+        self.h_out = (wc.reshape(wc.shape[0], -1).contiguous(), sd["conv1.bias"])
 
     @classmethod
     def from_reference(cls, vae_module_or_state_dict, **kw):
@@ -183,25 +155,16 @@ class WanVaeEncoder:
         T = video.shape[2]
         if (T - 1) % 2 ** self.t_down:
             raise ValueError(f"{T} frames: the encoder takes 1 + {2 ** self.t_down} k frames (the reference's chunking, wan2pt1.py:483-499)")
-        sd = self.sd
         x = video.to(device=self.device, dtype=self.dtype)
-        if self.backend == "hip":
-            K = self.K
-            B, C, _, H, W = x.shape
-            xc = torch.zeros((B, T, H, W, 32), dtype=self.dtype, device=self.device)     # channels-last, 3 -> 32 zero-padded
-            xc[..., :C] = x.permute(0, 2, 3, 4, 1)
-            x = K.vae_conv(xc, self.h_conv1[0], self.h_conv1[1], 3, 3, 3)
-            for st in self.stages:
-                x = st(x)
-            g, w, b = self.h_head
-            x = K.vae_conv(K.vae_chan_rms(x, g), w, b, 3, 3, 3)
-            x = F.linear(x, *self.h_out)[..., :self.z_dim].permute(0, 4, 1, 2, 3)          # conv1 (1x1x1), mu = first half
-        else:
-            x = _causal_conv(x, sd["encoder.conv1.weight"], sd["encoder.conv1.bias"])
-            for st in self.stages:
-                x = st(x)
-            x = F.silu(_chan_rms(x, sd["encoder.head.0.gamma"]))
-            x = _causal_conv(x, sd["encoder.head.2.weight"], sd["encoder.head.2.bias"])
-            x = F.conv3d(x, sd["conv1.weight"], sd["conv1.bias"])[:, :self.z_dim]
+        K = self.K
+        B, C, _, H, W = x.shape
+        xc = torch.zeros((B, T, H, W, 32), dtype=self.dtype, device=self.device)     # channels-last, 3 -> 32 zero-padded
+        xc[..., :C] = x.permute(0, 2, 3, 4, 1)
+        x = K.vae_conv(xc, self.h_conv1[0], self.h_conv1[1], 3, 3, 3)
+        for st in self.stages:
+            x = st(x)
+        g, w, b = self.h_head
+        x = K.vae_conv(K.vae_chan_rms(x, g), w, b, 3, 3, 3)
+        x = pointwise_conv(K, x, *self.h_out)[..., :self.z_dim].permute(0, 4, 1, 2, 3)     # conv1 (1x1x1), mu = first half
         mu = (x - self.mean) * self.inv_std                                                # wan2pt1.py:505-508
         return mu.contiguous().to(in_dtype)

@@ -168,6 +168,7 @@ class WanModel(nn.Module):
         self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
         self.fuse_embed_head = True  # patchify+patch_embedding, time MLPs, AdaLN vectors, head+unpatchify in HIP (embed_head.hip)
         self.split_tokens = True    # everything after self-attention is token-local: two token halves on two streams (_block)
+        self.hip_gemm16 = True      # plain 16-bit Linears (text MLP, C3's bf16 linears) on td_gemm_bf16; False: the library GEMM (A/B only)
         self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
         self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
@@ -274,7 +275,17 @@ class WanModel(nn.Module):
         if isinstance(mod, Int8Linear):
             xq, xs = K.quant_i8_block128(x)
             return K.gemm_w8a8(xq, xs, mod.int8_weight, mod.scale, x.dtype, bias=mod.bias, gelu_tanh=gelu)
-        y = F.linear(x, mod.weight, mod.bias)
+        return self._lin16(x, mod.weight, mod.bias, gelu)
+
+    def _lin16(self, x, w, b, gelu=False):
+        """A plain 16-bit Linear (BASELINE config 3's "bf16 linears", the text MLP, C1's arithmetic on the GPU) on
+        ``td_gemm_bf16`` — bias and GELU-tanh in the GEMM's epilogue with the operator sequence's rounding points."""
+        if (self.hip_gemm16 and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and x.shape[-1] % 64 == 0
+                and w.shape[0] % 8 == 0 and (b is None or b.dtype == x.dtype)):
+            x2 = x.reshape(-1, x.shape[-1])
+            y = K.gemm_bf16(x2, w.detach(), None if b is None else b.detach(), epilogue="gelu_tanh" if gelu else "none")
+            return y.view(*x.shape[:-1], w.shape[0])
+        y = F.linear(x, w, b)
         return F.gelu(y, approximate="tanh") if gelu else y
 
     def _lin_q(self, mod, xq, xs, dtype, gelu=False):
@@ -395,7 +406,7 @@ class WanModel(nn.Module):
         if s is not None:
             xq, xs = K.quant_i8_block128(x)
             return K.gemm_w8a8(xq, xs, w, s, x.dtype, bias=b)
-        return F.linear(x, w, b)
+        return self._lin16(x, w, b)
 
     # ------------------------------------------------------------------ one transformer block
     def _self_attention(self, i, blk, h, cos, sin, L_loc, dtype, quant_out=False):
@@ -467,6 +478,14 @@ class WanModel(nn.Module):
         vt = K.v_transpose(kv[:, dim:], D, kv.stride(0), Lc, H, D, context.dtype)
         return k, vt
 
+    def _text_mlp(self, crossattn_emb):
+        """text_embedding (wan2pt1.py:678): Linear(text_dim -> dim), GELU(tanh), Linear(dim -> dim) on the [B, 512, text_dim]
+        prompt embedding — two td_gemm_bf16 launches (bias + GELU in the first one's epilogue)."""
+        te = self.text_embedding
+        x = crossattn_emb.to(self.dtype)
+        h = self._lin16(x, te[0].weight, te[0].bias, gelu=True)
+        return self._lin16(h, te[2].weight, te[2].bias).contiguous()
+
     @torch.no_grad()
     def prepare_text(self, crossattn_emb):
         """Everything on the cross-attention K side depends on the text embedding only — the text MLP, the K|V projections
@@ -478,7 +497,7 @@ class WanModel(nn.Module):
         st = self._text_states.get(key[0])
         if st is not None and st[0] == key:
             return st
-        context = self.text_embedding(crossattn_emb.to(self.dtype)).contiguous()  # [B, Lc, dim]
+        context = self._text_mlp(crossattn_emb)  # [B, Lc, dim]
         B = context.shape[0]
         per_b = []
         for b in range(B):
@@ -712,7 +731,7 @@ class WanModel(nn.Module):
         if self.cache_text_kv:
             context, kvts = self.prepare_text(crossattn_emb)[2:4]   # once per text (keyed on the tensor's identity + version)
         else:
-            context = self.text_embedding(crossattn_emb.to(dt)).contiguous()  # [B, Lc, dim]
+            context = self._text_mlp(crossattn_emb)  # [B, Lc, dim]
             if self.batch_text_kv:
                 # the cross-attention K|V projections of ALL blocks read the same 512 text tokens: one [Lc, nblk*2*dim] GEMM
                 # (2880 tiles) and one quantisation of the text instead of one 96-tile GEMM + quantisation per block
