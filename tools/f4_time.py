@@ -61,7 +61,7 @@ def main():
                 for e in evs:
                     ms = e[0].elapsed_time(e[1])
                     print(f"  conv x{e[2][0]} -> Co {e[2][1]} k{e[2][2]} up2={e[2][3]} interleave={e[2][4]} res={e[2][5]}: {ms:.2f} ms, {e[3] / ms / 1e9:.0f} TFLOP/s", flush=True)
-            print(json.dumps({"what": f"WanVaeDecoder.decode ({"hip"} backend), whole clip, bf16, latent {tuple(z.shape)} -> video {tuple(v.shape)}",
+            print(json.dumps({"what": f"WanVaeDecoder.decode (HIP kernels), whole clip, bf16, latent {tuple(z.shape)} -> video {tuple(v.shape)}",
                               "seconds": round(t, 3), "conv_launches": len(evs), "conv_seconds": round(conv_s, 3),
                               "conv_TFLOP": round(fl[0] / 1e12, 1), "conv_TFLOP_per_s": round(fl[0] / conv_s / 1e12, 1),
                               "conv_frac_of_bf16_peak_2500": round(fl[0] / conv_s / 2.5e15, 3), "peak_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
@@ -77,7 +77,7 @@ def main():
         torch.cuda.reset_peak_memory_stats()
         t = timed(lambda: enc.encode(vid), reps=2)
         lat = enc.encode(vid)
-        print(json.dumps({"what": f"WanVaeEncoder.encode ({"hip"} backend), whole clip, bf16, video {tuple(vid.shape)} -> latent {tuple(lat.shape)}",
+        print(json.dumps({"what": f"WanVaeEncoder.encode (HIP kernels), whole clip, bf16, video {tuple(vid.shape)} -> latent {tuple(lat.shape)}",
                           "seconds": round(t, 3), "peak_GiB": round(torch.cuda.max_memory_allocated() / 2**30, 1),
                           "finite": bool(torch.isfinite(lat).all())}), flush=True)
         del enc, vid, lat
