@@ -415,6 +415,14 @@ int td_sla_linear_kv_final(const float* ws_kv, const float* ws_ks, int nch, int6
 int td_sla_linear_out(const void* q, int dtype, const void* kvsum_t, const void* ksum,
                       const float* wp, const float* bp, void* o, int64_t o_stride_h,
                       int64_t o_stride_l, int64_t L, int H, int D, td_stream_t stream);
+/* The linear branch with the reference's other feature maps (SLA/core.py:57-64; ABI v3): feature_map 0 = softmax over D
+ * (== td_sla_linear_kv / td_sla_linear_out), 1 = elu(x) + 1, 2 = relu — elementwise, with torch's 16-bit rounding after
+ * every op.  Same buffers and layouts as the softmax entry points. */
+int td_sla_linear_kv_fm(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv, float* ws_ks, void* kvsum_t,
+                        void* ksum, int feature_map, int64_t L, int H, int D, td_stream_t stream);
+int td_sla_linear_out_fm(const void* q, int dtype, const void* kvsum_t, const void* ksum, const float* wp, const float* bp,
+                         void* o, int64_t o_stride_h, int64_t o_stride_l, int feature_map, int64_t L, int H, int D,
+                         td_stream_t stream);
 
 /* pass 2 without the read-modify-write: o_l = cast(proj_l(...)) is written to t_out, 16-bit, in the lane-private
  * layout [H][ceil(L/128)][4 waves][16][64 lanes][4] that td_attn_*_ex consumes through add_t (run it BEFORE the

@@ -75,7 +75,10 @@ def _attention(q, k, v, kind, sd, prefix, topk, dt):
 def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=None, mode="eager",
                 attention="original", quant=False, topk=0.1, act_dtype=torch.bfloat16, num_layers=None,
                 return_tokens=False, tap=None):
-    """``tap``: optional dict that receives the intermediates of block 0 (fixture generation only)."""
+    """``tap``: optional dict that receives the intermediates of block 0 (fixture generation only).
+    ``return_tokens``: True -> the [B, L, dim] tokens after the last block; "both" -> (tokens, velocity) from ONE pass.
+    ``sd`` may be any mapping with ``__getitem__`` / ``get`` / ``__contains__`` (make_golden_r04.LazyLayers generates a
+    14B-width model's layers one at a time)."""
     dt = act_dtype
     dim, H = cfg["dim"], cfg["num_heads"]
     D = dim // H
@@ -142,15 +145,18 @@ def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=
         h = O.modulate(ln(x), em[4], em[3])
         f = lin(p + ".ffn.2", lin(p + ".ffn.0", h, gelu=True))
         x = O.gated_residual(x, f, em[5])
+        if getattr(sd, "evict_finished_layers", False):
+            lin.cache = {k_: v_ for k_, v_ in lin.cache.items() if not k_.startswith(p + ".")}
 
-    if return_tokens:
+    if return_tokens and return_tokens != "both":
         return x
     # head (fp32 island): norm -> type_as(x) -> *(1+e1)+e0 in fp32 -> fp32 Linear
     hm = (sd["head.modulation"].float() + e_B_D.unsqueeze(1)).chunk(2, dim=1)
     hn = O.layernorm_eager(x, None, None, eps).float() * (1 + hm[1]) + hm[0]
     out = F.linear(hn, sd["head.head.weight"].float(), sd["head.head.bias"].float())
     out = out.view(B, T, Hh, Ww, kt, kh, kw, out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
-    return out.reshape(B, out_dim, T * kt, Hh * kh, Ww * kw)
+    out = out.reshape(B, out_dim, T * kt, Hh * kh, Ww * kw)
+    return (x, out) if return_tokens == "both" else out
 
 
 # --------------------------------------------------------------------------- #

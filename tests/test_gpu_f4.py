@@ -261,7 +261,13 @@ def test_gemm_bf16_vs_fp32_matmul(K, case):
     assert out.shape == ref.shape and torch.isfinite(out).all()
     step = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
     err = (out - ref).abs()
-    assert (err <= ref.abs() * step * (2 if epi != "none" else 1) + 1e-3).all(), f"max err {err.max().item()}"
+    # a one-step difference of the rounded GEMM result (fp32 accumulation order) survives the later operators: with a residual
+    # at the magnitude of the GEMM result (not of the possibly smaller sum), through the gated GELU as up to ~4 steps of the product
+    mag = ref.abs()
+    if res is not None:
+        mag = torch.maximum(mag, (ref - res.float()).abs())
+    steps = {"none": 1, "gelu_tanh": 2, "geglu": 4}[epi]
+    assert (err <= mag * step * steps + 1e-3).all(), f"max err {err.max().item()}"
     assert (out == ref).float().mean().item() > (0.8 if epi != "none" else 0.97)
 
 

@@ -202,6 +202,54 @@ def test_hip_sla_kernels_vs_the_reference_triton_kernels(K, leaves):
         o, sp = m(*(I[n].transpose(1, 2).contiguous().to(DEV) for n in "qkv"), return_sparsity=True)
     assert abs(sp - leaves["sla_sparsity128"]) < 1e-9
     assert cosine(o, leaves["sla_module128"]) > 0.9995 and rel_l2(o, leaves["sla_module128"]) < 2e-2, rel_l2(o, leaves["sla_module128"])
+    # round 4: the class DEFAULTS (SparseLinearAttention(head_dim, topk): BLKQ = 64, SLA/core.py:39) against the reference
+    # module constructed the same way and run on the same chip (fixture: sla_module64; its block map: map64)
+    pq64, _, _ = K.sage_quant_pool(q, None, 64, want_quant=False)
+    lut64 = K.sla_topk(pq64, pk, leaves["topk64"])
+    got64 = torch.zeros(H, lut64.shape[1], leaves["map64"].shape[-1], dtype=torch.bool).scatter_(-1, lut64.cpu().long(), True)
+    assert torch.equal(got64, leaves["map64"][0].bool()), "BLKQ = 64 block map differs from the reference's get_block_map"
+    m64 = SparseLinearAttention(128, I["topk"]).to(DEV)
+    assert (m64.BLKQ, m64.BLKK) == (64, 64)
+    with torch.no_grad():
+        m64.proj_l.weight.copy_(I["proj_w"])
+        m64.proj_l.bias.copy_(I["proj_b"])
+        o64, sp64 = m64(*(I[n].transpose(1, 2).contiguous().to(DEV) for n in "qkv"), return_sparsity=True)
+    assert abs(sp64 - leaves["sla_sparsity64"]) < 1e-9
+    e64 = rel_l2(o64, leaves["sla_module64"])
+    print(f"\n[SparseLinearAttention, class defaults (BLKQ 64)] rel-L2 vs the reference module on the MI355X: {e64:.4f}")
+    assert cosine(o64, leaves["sla_module64"]) > 0.9995 and e64 < 2e-2, e64
+
+
+@pytest.mark.parametrize("feature_map", ["elu", "relu"])
+@pytest.mark.parametrize("sage", [False, True])
+def test_sla_modules_with_the_other_feature_maps(K, feature_map, sage):
+    """feature_map = 'elu' / 'relu' (SLA/core.py:57-64, 139-147): the linear branch with the elementwise maps (16-bit rounding
+    after every torch op) against the reference's formula evaluated in bf16 on the CPU; the sparse branch = the module with a
+    zero proj_l.  L = 700: a 60-row tail in both block sizes."""
+    import torch.nn.functional as F
+    from turbodiffusion_amd.sla import SageSparseLinearAttention, SparseLinearAttention
+    g = torch.Generator().manual_seed(11)
+    B, L, H, D = 1, 700, 2, 128
+    q, k, v = (torch.randn(B, L, H, D, generator=g).bfloat16() for _ in range(3))
+    wp, bp = torch.randn(D, D, generator=g) * 0.05, torch.randn(D, generator=g) * 0.05
+    mk = (lambda fm: SageSparseLinearAttention(D, 0.3, feature_map=fm)) if sage else (lambda fm: SparseLinearAttention(D, 0.3, feature_map=fm, BLKQ=128))
+    m, m0 = mk(feature_map).to(DEV), mk("softmax").to(DEV)
+    with torch.no_grad():
+        m.proj_l.weight.copy_(wp)
+        m.proj_l.bias.copy_(bp)
+        o = m(q.to(DEV), k.to(DEV), v.to(DEV)).float().cpu()
+        o_s = m0(q.to(DEV), k.to(DEV), v.to(DEV)).float().cpu()            # zero proj_l: the sparse branch alone
+    fmap = (lambda x: F.elu(x) + 1) if feature_map == "elu" else F.relu
+    qh, kh, vh = (t.transpose(1, 2).contiguous() for t in (q, k, v))       # [B, H, L, D] bf16: SLA/core.py:104-113 as written
+    cq, ck = fmap(qh).contiguous().bfloat16(), fmap(kh).contiguous().bfloat16()
+    kvsum = ck.transpose(-1, -2) @ vh
+    ksum = torch.sum(ck, dim=-2, keepdim=True)
+    o_l = (cq @ kvsum) / (1e-5 + (cq * ksum).sum(dim=-1, keepdim=True))
+    o_l = F.linear(o_l.bfloat16(), wp.bfloat16(), bp.bfloat16())         # proj_l under bf16 autocast
+    ref = (o_s.transpose(1, 2).bfloat16() + o_l).float().transpose(1, 2)
+    e = rel_l2(o, ref)
+    print(f"\n[{'SageSLA' if sage else 'SLA'}, feature_map = {feature_map}] rel-L2 vs the reference formula in bf16: {e:.4f}")
+    assert e < 2e-2 and cosine(o, ref) > 0.999
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -390,18 +390,21 @@ def test_fused_weight_views_and_cache_invalidation():
 
 
 def test_sla_modules_name_what_is_supported():
-    """Constructor arguments the reference accepts but the MI355X kernels are not built for fail at construction with a
-    message that names the supported set (never a bare assert, never a silent mismatch under python -O)."""
+    """The reference's constructor surface (SLA/core.py:38-77, 122-161): the class defaults construct (BLKQ = 64, the three
+    feature maps); what the MI355X kernels are not built for fails at construction with a message naming the supported set
+    (never a bare assert, never a silent mismatch under python -O)."""
     from turbodiffusion_amd.sla import SageSparseLinearAttention, SparseLinearAttention
-    with pytest.raises(ValueError, match="BLKQ = 128"):
-        SparseLinearAttention(128, 0.1)                       # reference default BLKQ = 64 (SLA/core.py:39)
+    m = SparseLinearAttention(128, 0.1)                       # reference defaults: BLKQ = 64, BLKK = 64, softmax (SLA/core.py:39)
+    assert (m.BLKQ, m.BLKK, m.feature_map, m.dtype) == (64, 64, "softmax", torch.bfloat16)
+    for fm in ("elu", "relu", "softmax"):
+        assert SparseLinearAttention(128, 0.1, feature_map=fm, BLKQ=128, BLKK=64).feature_map == fm
+        assert SageSparseLinearAttention(128, 0.1, feature_map=fm, use_bf16=False).dtype == torch.float16
     with pytest.raises(ValueError, match="head_dim = 128"):
         SageSparseLinearAttention(64, 0.1)                    # SLA/core.py:207 allows 64
-    for fm in ("elu", "relu"):
-        with pytest.raises(NotImplementedError, match="supported"):
-            SparseLinearAttention(128, 0.1, feature_map=fm, BLKQ=128, BLKK=64)
-    with pytest.raises(NotImplementedError):
-        SageSparseLinearAttention(128, 0.1, feature_map="hedgehog")
+    with pytest.raises(ValueError, match="BLKK = 64"):
+        SparseLinearAttention(128, 0.1, BLKQ=128, BLKK=128)
+    with pytest.raises(NotImplementedError, match="Not supported feature map"):
+        SageSparseLinearAttention(128, 0.1, feature_map="hedgehog")     # the reference raises the same (SLA/core.py:75)
     m = SparseLinearAttention(128, 0.1, BLKQ=128, BLKK=64)
     assert m.proj_l.weight.dtype == torch.float32 and float(m.proj_l.weight.abs().sum()) == 0.0
 

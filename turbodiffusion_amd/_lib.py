@@ -84,6 +84,8 @@ SIGNATURES = {
     "td_sla_linear_kv_final_packed": [_vp, _vp, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp],
     "td_sla_linear_kv": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_out": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp],
+    "td_sla_linear_kv_fm": [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
+    "td_sla_linear_out_fm": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i64, _i32, _i32, _vp],
 }
 
 _lib = None

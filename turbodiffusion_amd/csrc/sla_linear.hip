@@ -48,12 +48,22 @@ template <> struct MmaT<TD_BF16> {
 
 // ---------------------------------------------------------------------------------------
 // pass 1a: partial kv / ksum over a range of K blocks
+// FM: the linear branch's feature map (SLA/core.py:57-72): 0 = softmax over D (the published checkpoints), 1 = elu(x) + 1, 2 = relu —
+// the two elementwise maps with torch's 16-bit rounding after every op (F.elu rounds, "+ 1" rounds)
+template <int DT, int FM> __device__ __forceinline__ float sla_feature(float x) {
+  if constexpr (FM == 1) {
+    const float e = round_half<DT>(x > 0.f ? x : expm1f(x));
+    return round_half<DT>(e + 1.0f);
+  } else {
+    return fmaxf(x, 0.f);
+  }
+}
 //   KDT: dtype of k (and of the rounded softmax ck);  VDT: dtype of the V^T tiles / MFMA
 // Thread (tg = tid/16, c8 = tid%16) owns tokens 4tg..4tg+3 x channels 8c8..8c8+7 of each 64-token block:
 // 4 coalesced 16-B row loads, the row softmax is a 16-lane butterfly, and the transposed image ck^T[d][tok]
 // is written as 8-byte pieces (4 consecutive tokens of one channel are 4 consecutive MFMA positions).
 // ---------------------------------------------------------------------------------------
-template <int KDT, int VDT, bool WANT_KM>
+template <int KDT, int VDT, bool WANT_KM, int FM = 0>
 __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* __restrict__ k,
                                                                 const uint16_t* __restrict__ vt,
                                                                 float* __restrict__ ws_kv,
@@ -125,6 +135,14 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
       if constexpr (WANT_KM) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) km_acc[j] += f[j];
+      }
+      if constexpr (FM != 0) {   // elementwise feature map (already a 16-bit value), zero for rows past the end
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ck[t][j] = ok ? sla_feature<KDT, FM>(f[j]) : 0.f;
+          ks_acc[j] += ck[t][j];
+        }
+        continue;
       }
       float mx = f[0];
 #pragma unroll
@@ -265,7 +283,8 @@ __global__ __launch_bounds__(256) void linear_kv_final_kernel(const float* __res
 
 static int sla_linear_kv_partial_impl(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv,
                                       float* ws_ks, float* ws_km, int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes,
-                                      int H, int D, td_stream_t stream) {
+                                      int H, int D, td_stream_t stream, int fm = 0) {
+  TD_REQUIRE(fm >= 0 && fm <= 2, TD_ERR_INVALID, "td_sla_linear_kv: feature map %d (0 softmax, 1 elu + 1, 2 relu)", fm);
   TD_REQUIRE(L_alloc >= L && hg >= 0 && gs_bytes >= 0 && gs_bytes % 16 == 0 && (hg == 0 || H % hg == 0), TD_ERR_INVALID,
              "td_sla_linear_kv_partial: packed layout L_alloc=%lld hg=%d gs=%lld", (long long)L_alloc, hg, (long long)gs_bytes);
   TD_REQUIRE(k && vt && ws_kv && ws_ks, TD_ERR_INVALID, "td_sla_linear_kv_partial: null pointer");
@@ -276,9 +295,12 @@ static int sla_linear_kv_partial_impl(const void* k, int dtype, const void* vt, 
   hipStream_t st = (hipStream_t)stream;
 #define TD_LKP(KD_, VD_)                                                                                         \
   {                                                                                                               \
-    if (ws_km) linear_kv_partial_kernel<KD_, VD_, true><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb, Kb_alloc, hg, gs_bytes / 2); \
+    if (fm == 1) linear_kv_partial_kernel<KD_, VD_, false, 1><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, nullptr, L, Kb, Kb_alloc, hg, gs_bytes / 2); \
+    else if (fm == 2) linear_kv_partial_kernel<KD_, VD_, false, 2><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, nullptr, L, Kb, Kb_alloc, hg, gs_bytes / 2); \
+    else if (ws_km) linear_kv_partial_kernel<KD_, VD_, true><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb, Kb_alloc, hg, gs_bytes / 2); \
     else linear_kv_partial_kernel<KD_, VD_, false><<<grid, 256, 0, st>>>((const uint16_t*)k, (const uint16_t*)vt, ws_kv, ws_ks, ws_km, L, Kb, Kb_alloc, hg, gs_bytes / 2);     \
   }
+  TD_REQUIRE(fm == 0 || ws_km == nullptr, TD_ERR_UNSUPPORTED, "td_sla_linear_kv: the k mean rides on the softmax feature map's pass only");
   if (dtype == TD_BF16 && vt_dtype == TD_F16) TD_LKP(TD_BF16, TD_F16)
   else if (dtype == TD_BF16 && vt_dtype == TD_BF16) TD_LKP(TD_BF16, TD_BF16)
   else if (dtype == TD_F16 && vt_dtype == TD_F16) TD_LKP(TD_F16, TD_F16)
@@ -351,7 +373,7 @@ extern "C" int td_sla_linear_kv(const void* k, int dtype, const void* vt, int vt
 // pass 2: o += proj_l( (cq @ kvsum) / (1e-5 + sum(cq*ksum)) )
 // ---------------------------------------------------------------------------------------
 #define LO_QB_PER_WG 4   // 768 workgroups at the C1 shape = 3 per CU: 67 us vs 75 (8) / 84 (6) / 104 (12), tools/lin_qb_exp.py
-template <int DT>
+template <int DT, int FM = 0>
 __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __restrict__ q,
                                                          const uint16_t* __restrict__ kvT,
                                                          const uint16_t* __restrict__ ksum,
@@ -436,18 +458,26 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
       for (int ks = 0; ks < 8; ++ks)
         qraw[ks] = *reinterpret_cast<const uint4*>(q + ((int64_t)h * L + tokn) * 128 + 16 * ks + 8 * hi);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mb = mx * TD_LOG2E;
-    float sum = 0.f;
+    float inv = 1.0f;
+    if constexpr (FM == 0) {
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mb = mx * TD_LOG2E;
+      float sum = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+      for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        qf[ks][e] = __builtin_amdgcn_exp2f(fmaf(qf[ks][e], TD_LOG2E, -mb));
-        sum += qf[ks][e];
-      }
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = __builtin_amdgcn_rcpf(sum);
+        for (int e = 0; e < 8; ++e) {
+          qf[ks][e] = __builtin_amdgcn_exp2f(fmaf(qf[ks][e], TD_LOG2E, -mb));
+          sum += qf[ks][e];
+        }
+      sum += __shfl_xor(sum, 32, 64);
+      inv = __builtin_amdgcn_rcpf(sum);
+    } else {   // elementwise feature map: already the 16-bit value, the pack below is exact
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[ks][e] = sla_feature<DT, FM>(qf[ks][e]);
+    }
     float den = 0.f;
     uint4 cqf[8];
 #pragma unroll
@@ -552,7 +582,8 @@ __global__ __launch_bounds__(256, 2) void linear_out_kernel(const uint16_t* __re
 
 static int sla_linear_out_impl(const void* q, int dtype, const void* kvsum_t, const void* ksum,
                                const float* wp, const float* bp, void* o, int64_t o_stride_h,
-                               int64_t o_stride_l, int64_t L, int H, int D, void* t_out, td_stream_t stream) {
+                               int64_t o_stride_l, int64_t L, int H, int D, void* t_out, td_stream_t stream, int fm = 0) {
+  TD_REQUIRE(fm >= 0 && fm <= 2, TD_ERR_INVALID, "td_sla_linear_out: feature map %d (0 softmax, 1 elu + 1, 2 relu)", fm);
   TD_REQUIRE(q && kvsum_t && ksum && wp && bp && (o || t_out), TD_ERR_INVALID, "td_sla_linear_out: null pointer");
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sla_linear_out: D=%d (need 128)", D);
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_sla_linear_out: dtype %d", dtype);
@@ -565,17 +596,16 @@ static int sla_linear_out_impl(const void* q, int dtype, const void* kvsum_t, co
   unsigned long long* dbg = tune_ < 0 ? td_dbg_buffer() : nullptr;
   dim3 grid((unsigned)td_cdiv(Qb, qpw), H);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == TD_BF16) {
-    static std::atomic<uint64_t> a{0};
-    td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<TD_BF16>), lds, a);
-    linear_out_kernel<TD_BF16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
-        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw, dbg);
-  } else {
-    static std::atomic<uint64_t> a{0};
-    td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<TD_F16>), lds, a);
-    linear_out_kernel<TD_F16><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,
-        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw, dbg);
+#define TD_LO(DT_, FM_)                                                                                        \
+  {                                                                                                              \
+    static std::atomic<uint64_t> a{0};                                                                           \
+    td_ensure_dyn_lds(reinterpret_cast<const void*>(linear_out_kernel<DT_, FM_>), lds, a);                       \
+    linear_out_kernel<DT_, FM_><<<grid, 256, lds, st>>>((const uint16_t*)q, (const uint16_t*)kvsum_t,            \
+        (const uint16_t*)ksum, wp, bp, (uint16_t*)o, o_stride_h, o_stride_l, L, Qb, (uint16_t*)t_out, qpw, dbg); \
   }
+  if (dtype == TD_BF16) { if (fm == 1) TD_LO(TD_BF16, 1) else if (fm == 2) TD_LO(TD_BF16, 2) else TD_LO(TD_BF16, 0) }
+  else { if (fm == 1) TD_LO(TD_F16, 1) else if (fm == 2) TD_LO(TD_F16, 2) else TD_LO(TD_F16, 0) }
+#undef TD_LO
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
@@ -592,4 +622,23 @@ extern "C" int td_sla_linear_out_t(const void* q, int dtype, const void* kvsum_t
                                    td_stream_t stream) {
   TD_REQUIRE(t_out, TD_ERR_INVALID, "td_sla_linear_out_t: null output");
   return sla_linear_out_impl(q, dtype, kvsum_t, ksum, wp, bp, nullptr, 4, 4, L, H, D, t_out, stream);
+}
+
+
+// The linear branch with another feature map (SparseLinearAttention(feature_map = "elu" | "relu"), SLA/core.py:57-64):
+// the two passes as td_sla_linear_kv / td_sla_linear_out with feature_map = 0 (softmax) | 1 (elu + 1) | 2 (relu).
+extern "C" int td_sla_linear_kv_fm(const void* k, int dtype, const void* vt, int vt_dtype, float* ws_kv, float* ws_ks,
+                                   void* kvsum_t, void* ksum, int feature_map, int64_t L, int H, int D, td_stream_t stream) {
+  TD_REQUIRE(kvsum_t && ksum, TD_ERR_INVALID, "td_sla_linear_kv_fm: null pointer");
+  int rc = sla_linear_kv_partial_impl(k, dtype, vt, vt_dtype, ws_kv, ws_ks, nullptr, L, L, 0, 0, H, D, stream, feature_map);
+  if (rc) return rc;
+  return td_sla_linear_kv_final(ws_kv, ws_ks, LK_NCH, (int64_t)LK_NCH * 128 * 128, 128 * 128, (int64_t)LK_NCH * 128, 128,
+                                kvsum_t, ksum, dtype, H, D, stream);
+}
+
+extern "C" int td_sla_linear_out_fm(const void* q, int dtype, const void* kvsum_t, const void* ksum, const float* wp,
+                                    const float* bp, void* o, int64_t o_stride_h, int64_t o_stride_l, int feature_map,
+                                    int64_t L, int H, int D, td_stream_t stream) {
+  TD_REQUIRE(o, TD_ERR_INVALID, "td_sla_linear_out_fm: null output");
+  return sla_linear_out_impl(q, dtype, kvsum_t, ksum, wp, bp, o, o_stride_h, o_stride_l, L, H, D, nullptr, stream, feature_map);
 }

@@ -620,10 +620,22 @@ def attn_16_qnorm(q_src, rstd, w, k, vt, lut, out, o_stride_h, o_stride_l, sm_sc
 SLA_NCH = 32  # TD_SLA_NCH in include/turbodiffusion_amd.h
 
 
-def sla_linear_kv(k, vt, want_kmean=False):
-    """-> (kvsum_t, ksum) of the linear branch [, km = seq_mean(k) accumulated during the same pass over K]."""
+FEATURE_MAPS = {"softmax": 0, "elu": 1, "relu": 2}
+
+
+def sla_linear_kv(k, vt, want_kmean=False, feature_map="softmax"):
+    """-> (kvsum_t, ksum) of the linear branch [, km = seq_mean(k) accumulated during the same pass over K (softmax map only)]."""
     require_gpu(k, vt)
     H, L_, D = k.shape
+    if feature_map != "softmax":
+        assert not want_kmean
+        ws_kv = torch.empty((H, SLA_NCH, D, D), dtype=torch.float32, device=k.device)
+        ws_ks = torch.empty((H, SLA_NCH, D), dtype=torch.float32, device=k.device)
+        kv_t = torch.empty((H, D, D), dtype=k.dtype, device=k.device)
+        ksum = torch.empty((H, D), dtype=k.dtype, device=k.device)
+        call("td_sla_linear_kv_fm", ptr(k), dt_code(k.dtype), ptr(vt), dt_code(vt.dtype), ptr(ws_kv), ptr(ws_ks), ptr(kv_t),
+             ptr(ksum), FEATURE_MAPS[feature_map], L_, H, D, stream_ptr())
+        return kv_t, ksum
     ws_km = torch.empty((H, SLA_NCH, D), dtype=torch.float32, device=k.device) if want_kmean else None
     km = torch.empty((H, D), dtype=k.dtype, device=k.device) if want_kmean else None
     ws_kv = torch.empty((H, SLA_NCH, D, D), dtype=torch.float32, device=k.device)
@@ -686,10 +698,15 @@ def sla_linear_out_t(q, kv_t, ksum, wp, bp):
     return t
 
 
-def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l):
+def sla_linear_out_(q, kv_t, ksum, wp, bp, out, o_stride_h, o_stride_l, feature_map="softmax"):
+    """out[h, l, :] += cast(proj_l((cq @ kvsum) / (1e-5 + cq.ksum)))  (read-modify-write of the attention output)"""
     require_gpu(q, kv_t, ksum, wp, bp, out)
     H, L_, D = q.shape
     assert wp.dtype == torch.float32 and bp.dtype == torch.float32 and wp.is_contiguous()
+    if feature_map != "softmax":
+        call("td_sla_linear_out_fm", ptr(q), dt_code(q.dtype), ptr(kv_t), ptr(ksum), ptr(wp), ptr(bp), ptr(out),
+             o_stride_h, o_stride_l, FEATURE_MAPS[feature_map], L_, H, D, stream_ptr())
+        return out
     call("td_sla_linear_out", ptr(q), dt_code(q.dtype), ptr(kv_t), ptr(ksum), ptr(wp), ptr(bp), ptr(out),
          o_stride_h, o_stride_l, L_, H, D, stream_ptr())
     return out
@@ -843,6 +860,11 @@ def vae_chan_rms(x, gamma, silu=True):
 GEMM16_EPI = {"none": 0, "gelu_tanh": 1, "geglu": 2}
 
 
+def _unit_inner(t):
+    """last dim contiguous (a size-1 dim may carry any stride)"""
+    return t.shape[-1] == 1 or t.stride(-1) == 1
+
+
 def _pad_k64(t):
     """[.., k] -> [.., ceil64(k)] zero-padded copy when k is not a multiple of 64 or the rows are not 16-byte aligned
     (toy shapes only: every production width here is a multiple of 64)."""
@@ -869,11 +891,11 @@ def gemm_bf16(a, w, bias=None, res=None, epilogue="none", out_dtype=None, out=No
     n_out = n // 2 if epilogue == "geglu" else n
     if out is None:
         out = torch.empty((m, n_out), dtype=odt, device=a.device)
-    assert tuple(out.shape) == (m, n_out) and out.dtype == odt and out.stride(1) == 1
+    assert tuple(out.shape) == (m, n_out) and out.dtype == odt and _unit_inner(out)
     if bias is not None:
         assert bias.dtype == a.dtype and bias.numel() == n and bias.is_contiguous()
     if res is not None:
-        assert res.dtype == a.dtype and tuple(res.shape) == (m, n) and res.stride(1) == 1
+        assert res.dtype == a.dtype and tuple(res.shape) == (m, n) and _unit_inner(res)
     call("td_gemm_bf16", ptr(a), ptr(w), ptr(bias), ptr(res), ptr(out), L.dt_code(a.dtype), L.dt_code(odt), GEMM16_EPI[epilogue],
          m, n, k, a.stride(0), w.stride(0), out.stride(0), 0 if res is None else res.stride(0), 1, 0, 0, 0, 0, stream_ptr())
     return out
@@ -891,7 +913,7 @@ def gemm_bf16_batched(a, b, out_dtype=None, out=None, bias=None):
     if out is None:
         npad = n if odt == torch.float32 else cdiv(n, 8) * 8
         out = torch.empty((B, m, npad), dtype=odt, device=a.device)[:, :, :n]
-    assert tuple(out.shape) == (B, m, n) and out.dtype == odt and out.stride(2) == 1
+    assert tuple(out.shape) == (B, m, n) and out.dtype == odt and _unit_inner(out)
     if bias is not None:
         assert bias.dtype == a.dtype and bias.numel() == n and bias.is_contiguous()
     call("td_gemm_bf16", ptr(a), ptr(b), ptr(bias), None, ptr(out), L.dt_code(a.dtype), L.dt_code(odt), 0, m, n, k, a.stride(1),
@@ -912,7 +934,7 @@ def softmax_rows(s, scale=1.0, bias=None, out=None, out_dtype=None, padded=False
     stride) is zero-filled behind ``cols``; bias [bias_rows, cols] 16-bit is added first (rows cycle).  padded: return the
     [rows, ceil64(cols)] storage (what a following GEMM contracts over) instead of the [rows, cols] view."""
     require_gpu(s, bias, out)
-    assert s.dim() == 2 and s.stride(1) == 1
+    assert s.dim() == 2 and _unit_inner(s)
     rows, cols = s.shape
     pdt = out_dtype or (torch.bfloat16 if s.dtype == torch.float32 else s.dtype)
     full = None
@@ -920,10 +942,10 @@ def softmax_rows(s, scale=1.0, bias=None, out=None, out_dtype=None, padded=False
         ldp = cdiv(cols, 64) * 64
         full = torch.empty((rows, ldp), dtype=pdt, device=s.device)
         out = full[:, :cols]
-    assert tuple(out.shape) == (rows, cols) and out.dtype == pdt and out.stride(1) == 1
+    assert tuple(out.shape) == (rows, cols) and out.dtype == pdt and _unit_inner(out)
     assert not padded or full is not None
     if bias is not None:
-        assert bias.dim() == 2 and bias.dtype == pdt and bias.shape[1] == cols and bias.stride(1) == 1
+        assert bias.dim() == 2 and bias.dtype == pdt and bias.shape[1] == cols and _unit_inner(bias)
     call("td_softmax_rows", ptr(s), L.dt_code(s.dtype), ptr(out), L.dt_code(pdt), ptr(bias), rows, cols, s.stride(0), out.stride(0),
          0 if bias is None else bias.shape[0], 0 if bias is None else bias.stride(0), float(scale), stream_ptr())
     return full if padded else out
@@ -932,7 +954,7 @@ def softmax_rows(s, scale=1.0, bias=None, out=None, out_dtype=None, padded=False
 def t5_norm(x, w, eps=1e-6):
     """T5LayerNorm on [rows, n] 16-bit (two roundings, umt5.py:130-142)."""
     require_gpu(x, w)
-    assert x.dim() == 2 and x.stride(1) == 1 and w.dtype == x.dtype and w.numel() == x.shape[1] and w.is_contiguous()
+    assert x.dim() == 2 and _unit_inner(x) and w.dtype == x.dtype and w.numel() == x.shape[1] and w.is_contiguous()
     y = torch.empty((x.shape[0], x.shape[1]), dtype=x.dtype, device=x.device)
     call("td_t5_norm", ptr(x), ptr(w), ptr(y), L.dt_code(x.dtype), float(eps), x.shape[0], x.shape[1], x.stride(0), y.stride(0),
          stream_ptr())

@@ -36,6 +36,14 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class EmulatedGroup:
     """Stands in for a process group when ONE rank of an N-way split is run alone on one GPU (``bench.py --emulate-rank``,
     ``tools/emulate_ranks.py``): no communication — an all-gather fills every rank's slot of its output with THIS rank's
@@ -138,6 +146,17 @@ class SeqParallel:
         self.ops = ops
         self.L = None
         self.head_groups = 4   # self-attention K/V exchange and attention pipelined over this many head groups
+        # the head groups' block map / attention / linear branch as PARALLEL branches (one HIP stream per group, fork / join
+        # by events = graph edges under capture): a rank of an 8-way split launches 3 heads x 32 Q blocks = 96 workgroups per
+        # group — a third of the chip — so queued behind each other the four groups take four under-filled waves
+        # (bench.py --emulate-rank 0/8, round 4: 33.5 ms per DiT step against 84 / 8 = 10.5)
+        self.parallel_groups = True
+        self._group_streams = {}
+        import os   # A/B switches for the measurement tools (tools/gpu/*.sh); results do not depend on them
+        if os.environ.get("TD_SP_HEAD_GROUPS"):
+            self.head_groups = int(os.environ["TD_SP_HEAD_GROUPS"])
+        if os.environ.get("TD_SP_PARALLEL_GROUPS"):
+            self.parallel_groups = os.environ["TD_SP_PARALLEL_GROUPS"] != "0"
 
     # ------------------------------------------------------------------ token sharding
     def plan(self, L: int):
@@ -256,30 +275,65 @@ class SeqParallel:
         # entry points: block j = block j % kbp of rank j // kbp): no re-layout of the gathered K / V^T / scales / pooled K.
 
         topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
-        for (h0, h1, allb, work) in inflight:
-            if h0 > 0:
-                work.wait()
-            Hg = h1 - h0
+        from . import graph as _graph
+        # parallel branches need real streams and no segmented capture in progress (a segment cannot end with forked streams)
+        par = self.parallel_groups and q.is_cuda and lay.G > 1 and _graph._ACTIVE is None
+        main = torch.cuda.current_stream() if par else None
+        joins = []
+        if par:
+            e_fork = torch.cuda.Event()
+            e_fork.record(main)
+        for gi, (h0, h1, allb, work) in enumerate(inflight):
+            st = None
+            if par and gi > 0:
+                st = self._stream(gi)
+                st.wait_event(e_fork)
+            with (torch.cuda.stream(st) if st is not None else _NullCtx()):
+                if h0 > 0:
+                    work.wait()      # (RCCL: the CURRENT stream waits for that group's gather)
+                self._group(ops, lay, q, q_q, q_s, pq, h0, h1, allb, out, o_stride_h, o_stride_l, L, topk, kb_tot, sage, dense,
+                            linear, W, D, dt, proj_w, proj_b)
+                if st is not None:
+                    e = torch.cuda.Event()
+                    e.record(st)
+                    joins.append(e)
+        for e in joins:
+            main.wait_event(e)
+        # allocation safety without record_stream: tensors made inside a branch live on that branch's stream and are reused
+        # there only; what the branches READ (q side, the gathered buffers) belongs to the main stream and is released by
+        # Python after the join above has been enqueued
+        return out
 
-            def gathered(name, allb=allb):  # [W, hg, ...] strided VIEW of one section of the group's gather (no copy)
-                return lay.section(allb, name)
+    def _stream(self, gi):
+        key = (torch.cuda.current_device(), gi)
+        st = self._group_streams.get(key)
+        if st is None:
+            st = self._group_streams[key] = torch.cuda.Stream()
+        return st
 
-            vt_g = gathered("vt")                                                   # [W, Hg, kbp, D, 64] view
-            out_g = out.view(-1)[h0 * o_stride_h:]   # same buffer, origin moved to the group's first head
-            lut = None
-            if not dense:
-                lut = ops.sla_topk_sp(pq[h0:h1], gathered("pk"), topk, kb_tot)
-            if sage:
-                ops.attn_i8_sp(q_q[h0:h1], q_s[h0:h1], gathered("k"),
-                               gathered("ks"), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
-            else:
-                ops.attn_16_sp(q[h0:h1], gathered("k"), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
-            if linear:
-                kv_parts = gathered("kv")   # [W, Hg, D, D]
-                ks_parts = gathered("kss")     # [W, Hg, D]
-                kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D,
-                                                     ks_parts.stride(0), Hg, D, dt)
-                ops.sla_linear_out_(q[h0:h1], kv_t, ksum, proj_w, proj_b, out_g, o_stride_h, o_stride_l)
+    def _group(self, ops, lay, q, q_q, q_s, pq, h0, h1, allb, out, o_stride_h, o_stride_l, L, topk, kb_tot, sage, dense, linear,
+               W, D, dt, proj_w, proj_b):
+        """Block map, attention and linear branch of the heads [h0, h1) against one head group's gathered K side."""
+        Hg = h1 - h0
+
+        def gathered(name):  # [W, hg, ...] strided VIEW of one section of the group's gather (no copy)
+            return lay.section(allb, name)
+
+        vt_g = gathered("vt")                                                   # [W, Hg, kbp, D, 64] view
+        out_g = out.view(-1)[h0 * o_stride_h:]   # same buffer, origin moved to the group's first head
+        lut = None
+        if not dense:
+            lut = ops.sla_topk_sp(pq[h0:h1], gathered("pk"), topk, kb_tot)
+        if sage:
+            ops.attn_i8_sp(q_q[h0:h1], q_s[h0:h1], gathered("k"), gathered("ks"), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
+        else:
+            ops.attn_16_sp(q[h0:h1], gathered("k"), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
+        if linear:
+            kv_parts = gathered("kv")   # [W, Hg, D, D]
+            ks_parts = gathered("kss")     # [W, Hg, D]
+            kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D,
+                                                 ks_parts.stride(0), Hg, D, dt)
+            ops.sla_linear_out_(q[h0:h1], kv_t, ksum, proj_w, proj_b, out_g, o_stride_h, o_stride_l)
         return out
 
 

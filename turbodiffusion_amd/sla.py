@@ -17,32 +17,64 @@ from . import kernels as K
 __all__ = ["SparseLinearAttention", "SageSparseLinearAttention", "sparse_linear_attention_hld"]
 
 
-SUPPORTED = "head_dim = 128, BLKQ = 128, BLKK = 64, feature_map = 'softmax'"
+SUPPORTED = "head_dim = 128, BLKQ in (64, 128), BLKK = 64, feature_map in ('softmax', 'elu', 'relu')"
 
 
 def _check_feature_map(feature_map):
-    if feature_map in ("elu", "relu"):
-        # the published TurboDiffusion checkpoints use the default softmax map; elu/relu exist in
-        # the reference (SLA/core.py:57-64) for SLA fine-tuning only
-        raise NotImplementedError(f"feature_map={feature_map!r} is not built for the MI355X kernels (supported: {SUPPORTED})")
-    if feature_map != "softmax":
+    if feature_map not in ("softmax", "elu", "relu"):
         raise NotImplementedError(f"Not supported feature map {feature_map}.")   # the reference's own error, SLA/core.py:75
 
 
 def _check_geometry(head_dim, blkq, blkk):
-    """What the HIP attention / block-map kernels are instantiated for.  The reference additionally allows head_dim 64
-    (SLA/core.py:207) and defaults SparseLinearAttention to BLKQ = 64 (:39); its inference scripts construct
-    BLKQ = 128 / BLKK = 64 (inference/modify_model.py:50), which is the configuration built here."""
+    """What the HIP attention / block-map kernels are instantiated for: the reference's class defaults (BLKQ = 64, BLKK = 64,
+    SLA/core.py:39) and what its inference scripts construct (BLKQ = 128, BLKK = 64, inference/modify_model.py:50).  The
+    reference additionally allows head_dim 64 (SLA/core.py:207); Wan's heads are 128 wide."""
     if head_dim != 128:
         raise ValueError(f"head_dim={head_dim}: the MI355X attention kernels are built for {SUPPORTED}")
-    if blkq != 128 or blkk != 64:
-        raise ValueError(f"BLKQ={blkq}, BLKK={blkk}: the MI355X attention kernels are built for {SUPPORTED} "
-                         f"(pass BLKQ=128, BLKK=64 as inference/modify_model.py:50 does)")
+    if blkq not in (64, 128) or blkk != 64:
+        raise ValueError(f"BLKQ={blkq}, BLKK={blkk}: the MI355X attention kernels are built for {SUPPORTED}")
+
+
+def _general_sla_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, out, o_stride_h, o_stride_l, v_strides, blkq, feature_map):
+    """``SparseLinearAttention`` (16-bit QK) outside the inference scripts' configuration: the class default BLKQ = 64
+    and / or the elementwise feature maps of the linear branch (SLA/core.py:39,57-64).  Same kernels as the fast path, the
+    fusions undone: the linear branch's second pass adds into the attention output (read-modify-write) instead of riding in
+    the attention epilogue, and for BLKQ = 64 every 64-row Q block is run as the first half of its own 128-row slot of the
+    attention kernel (one LUT row per slot; the other 64 rows are zero queries whose outputs are dropped) — twice the
+    attention work, which only the reference's training-side default pays; the block map pools Q over 64 rows."""
+    H, L_, D = k.shape
+    kb = K.cdiv(L_, 64)
+    topk = min(kb, int(topk_ratio * kb))
+    if topk < 1:
+        raise ValueError(f"block-sparse attention with topk ratio {topk_ratio} selects no block of {kb} (L = {L_} tokens)")
+    vt = K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, q.dtype)
+    km = K.seq_mean(k)
+    pq, _, _ = K.sage_quant_pool(q, None, blkq, want_quant=False)
+    pk, _, _ = K.sage_quant_pool(k, km, 64, want_quant=False)
+    lut = K.sla_topk(pq, pk, topk)
+    if blkq == 128:
+        K.attn_16(q, k, vt, lut, out, o_stride_h, o_stride_l)
+    else:
+        qb = K.cdiv(L_, 64)
+        full, tail = L_ // 64, L_ % 64
+        qpad = torch.zeros((H, qb, 128, D), dtype=q.dtype, device=q.device)
+        qpad[:, :full, :64] = q[:, :full * 64].view(H, full, 64, D)
+        if tail:
+            qpad[:, full, :tail] = q[:, full * 64:]
+        opad = torch.empty((qb * 128, H, D), dtype=q.dtype, device=q.device)
+        K.attn_16(qpad.view(H, qb * 128, D), k, vt, lut, opad, D, H * D, lk=L_)
+        rows = opad.view(qb, 128, H, D)[:, :64].reshape(qb * 64, H, D)[:L_]                  # [L, H, D]
+        dst = torch.as_strided(out, (L_, H, D), (o_stride_l, o_stride_h, 1))
+        dst.copy_(rows)
+    if proj_w is not None:
+        kv_t, ksum = K.sla_linear_kv(k, vt, feature_map=feature_map)
+        K.sla_linear_out_(q, kv_t, ksum, proj_w, proj_b, out, o_stride_h, o_stride_l, feature_map=feature_map)
+    return out, topk, kb
 
 
 def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
                                 v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None, pv="fp16", vt=None,
-                                side=None, q_fn=None):
+                                side=None, q_fn=None, feature_map="softmax"):
     """Core of both modules on head-major tensors.
 
     q, k: [H, L, D] 16-bit (after RoPE); vt_src: tensor holding V with element (h,l,d) at
@@ -66,6 +98,15 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     """
     H, L_, D = k.shape
     _check_geometry(D, blkq, blkk)
+    if blkq != 128 or feature_map != "softmax":
+        if sage and blkq != 128:
+            raise ValueError("SageAttention quantises Q per 128 rows (SLA/core.py:202): BLKQ = 128")
+        if not sage and not dense and not quant_out and vt is None:
+            return _general_sla_hld(q if q is not None else q_fn(), k, vt_src, proj_w, proj_b, topk_ratio, out, o_stride_h,
+                                    o_stride_l, v_strides, blkq, feature_map)
+        if feature_map != "softmax":
+            return _sage_other_feature_map(q if q is not None else q_fn(), k, vt_src, proj_w, proj_b, topk_ratio, out, o_stride_h,
+                                           o_stride_l, v_strides, dense, quant_out, km, pv, vt, feature_map)
     kb = K.cdiv(L_, blkk)
     topk = min(kb, int(topk_ratio * kb))
     if not dense and topk < 1:
@@ -115,6 +156,22 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     return res, topk, kb
 
 
+def _sage_other_feature_map(q, k, vt_src, proj_w, proj_b, topk_ratio, out, o_stride_h, o_stride_l, v_strides, dense, quant_out,
+                            km, pv, vt, feature_map):
+    """SageSLA with the elu / relu feature map (SLA/core.py:139-147): the sparse branch as always, the linear branch's two
+    passes with the other map, added into the output afterwards (no epilogue fusion, no fused quantiser)."""
+    if quant_out:
+        raise ValueError("the attention epilogue's fused INT8 output needs the softmax feature map's fused linear branch")
+    res, topk, kb = sparse_linear_attention_hld(q, k, vt_src, None, None, topk_ratio, True, out, o_stride_h, o_stride_l,
+                                                v_strides, dense=dense, km=km, pv=pv, vt=vt)
+    if proj_w is not None and not dense:
+        H, L_, D = k.shape
+        vtl = vt if (vt is not None and vt.dtype == q.dtype) else K.v_transpose(vt_src, v_strides[0], v_strides[1], L_, H, D, q.dtype)
+        kv_t, ksum = K.sla_linear_kv(k, vtl, feature_map=feature_map)
+        K.sla_linear_out_(q, kv_t, ksum, proj_w, proj_b, out, o_stride_h, o_stride_l, feature_map=feature_map)
+    return res, topk, kb
+
+
 def _sagesla_two_streams(q_fn, k, vt, proj_w, proj_b, topk, kb, out, o_stride_h, o_stride_l, blkq, blkk, quant_out, side):
     """The SageSLA kernel sequence of ``sparse_linear_attention_hld`` with the Q-side chain on ``side`` (see there).
     Allocation safety without record_stream: tensors made on ``side`` are consumed on the current stream before this
@@ -150,6 +207,7 @@ class _SLABase(nn.Module):
         super().__init__()
         _check_feature_map(feature_map)
         _check_geometry(head_dim, 128, 64)
+        self.feature_map = feature_map      # (tie_feature_map_qk: q and k share the map either way, SLA/core.py:77-78)
         self.dtype = torch.bfloat16 if use_bf16 else torch.float16
         self.topk = topk
         self.head_dim = head_dim
@@ -175,7 +233,8 @@ class _SLABase(nn.Module):
             out = torch.empty((L_, H, D), dtype=self.dtype, device=q.device)
             _, real, kb_n = sparse_linear_attention_hld(
                 qb, kb_, vb, self.proj_l.weight.float().contiguous(), self.proj_l.bias.float().contiguous(),
-                self.topk, sage, out, D, H * D, (D, H * D), blkq, blkk, pv=self.pv_dtype if sage else "fp16")
+                self.topk, sage, out, D, H * D, (D, H * D), blkq, blkk, pv=self.pv_dtype if sage else "fp16",
+                feature_map=self.feature_map)
             outs.append(out)
         o = torch.stack(outs, dim=0).to(dtype)  # [B, L, H, D]
         if return_sparsity:
@@ -189,7 +248,7 @@ class SparseLinearAttention(_SLABase):
     def __init__(self, head_dim, topk, feature_map="softmax", BLKQ=64, BLKK=64, use_bf16=True,
                  tie_feature_map_qk=True):
         super().__init__(head_dim, topk, feature_map, use_bf16, tie_feature_map_qk)
-        _check_geometry(head_dim, BLKQ, BLKK)   # incl. the reference's default BLKQ = 64: refused at construction
+        _check_geometry(head_dim, BLKQ, BLKK)
         self.BLKQ = BLKQ
         self.BLKK = BLKK
 
