@@ -694,7 +694,7 @@ def main():
             from turbodiffusion_amd.seqpar import PackLayout
             spo = net.seq_parallel.sp
             at = wl["attention_type"]
-            lay = PackLayout(cfg["num_heads"], spo.per, 128, spo.head_groups, at in ("sage", "sagesla"), at in ("original", "sage"),
+            lay = PackLayout(cfg["num_heads"], spo.per, 128, spo.groups_for(cfg["num_heads"], spo.per), at in ("sage", "sagesla"), at in ("original", "sage"),
                              torch.bfloat16)
             pack = lay.gb * lay.G                       # bytes a rank sends to EVERY peer per self-attention layer
             link = 120e9                                # effective B/s of one xGMI link (153 GB/s peak; full mesh: one link per peer)

@@ -194,7 +194,9 @@ def test_umt5_encoder_on_the_gpu_matches_the_reference_fixture():
     e16, e32 = rel_l2(out16, fx["out_bf16"]), rel_l2(out16, fx["out_f32"])
     print(f"\n[umT5, HIP kernels, bf16] rel-L2 vs the reference's bf16 run {e16:.4f}, vs its fp32 run {e32:.4f} "
           f"(the reference's own bf16 vs fp32: {rel_l2(fx['out_bf16'], fx['out_f32']):.4f})")
-    assert e16 < 2e-2 and e32 < 2e-2
+    # the kernels stand where the reference's own bf16 run stands against fp32 (it is a 3-layer toy with unit-variance weights:
+    # bf16 rounding alone moves it by 4 %), and within 2 % of that bf16 run
+    assert e16 < 2e-2 and e32 < 1.15 * rel_l2(fx["out_bf16"], fx["out_f32"])
     with pytest.raises(ValueError, match="HIP kernels only"):
         Umt5Encoder(fx["state_dict"], dtype=torch.float32, device=DEV)
 
@@ -267,7 +269,15 @@ def test_gemm_bf16_vs_fp32_matmul(K, case):
     if res is not None:
         mag = torch.maximum(mag, (ref - res.float()).abs())
     steps = {"none": 1, "gelu_tanh": 2, "geglu": 4}[epi]
-    assert (err <= mag * step * steps + 1e-3).all(), f"max err {err.max().item()}"
+    bad = err > mag * step * steps + 1e-3
+    if bad.any():
+        i, j = (int(v) for v in bad.nonzero()[0])
+        extra = ""
+        if case == "geglu":
+            y = (a.float() @ wi.float().cpu().t()).to(dt).float().view(m, n // 64, 2, 32)
+            extra = f" gate {y[i, j // 32, 0, j % 32].item()} fc1 {y[i, j // 32, 1, j % 32].item()}"
+        raise AssertionError(f"{int(bad.sum())} of {bad.numel()} outside the bound; first at ({i}, {j}): got {out[i, j].item()} "
+                             f"want {ref[i, j].item()}{extra}; max err {err.max().item()}")
     assert (out == ref).float().mean().item() > (0.8 if epi != "none" else 0.97)
 
 

@@ -25,6 +25,7 @@ def _free_port():
 def _worker(rank, world, port, attention, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["TD_SP_HEAD_GROUPS"] = "4"     # toy shards: keep the head-group pipeline + parallel branches exercised
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -64,6 +65,7 @@ def test_seqpar_world2_on_gpu_matches_single_rank(attention):
 def _graph_worker(rank, world, port, attention, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["TD_SP_HEAD_GROUPS"] = "4"     # toy shards: keep the head-group pipeline + parallel branches exercised
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -114,6 +116,7 @@ def _nccl_worker(rank, world, port, attention, ret):
     (seqpar._Gather.issue / _wait, graph.SegmentRecorder)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["TD_SP_HEAD_GROUPS"] = "4"     # toy shards: keep the head-group pipeline + parallel branches exercised
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))

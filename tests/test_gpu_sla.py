@@ -545,6 +545,32 @@ def test_attn_i8_two_per_cu_build_is_bit_identical(K):
         assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("H,L,ratio", [(2, 1000, 0.3), (3, 777, 0.2), (1, 130, 1.0), (2, 2080, 0.1)])
+def test_attn_i8_rowsum_on_the_matrix_pipe_build_vs_oracle(K, H, L, ratio):
+    """TD_TUNE_ATTN_OCC = 4 (round-4 experiment): the two-workgroup build with the softmax denominator accumulated by four
+    extra MFMAs per tile against an all-ones operand (the sum of the fp16-ROUNDED probabilities) instead of 32 v_add per lane:
+    same bar against the oracle as the production build, and rounding-level distance to it."""
+    q, k, v, q_i8, q_s, k_i8, k_s = _sage_inputs(H, L, 7)
+    _, lut, topk = S.get_block_map(q, k, ratio, 128, 64)
+    ref = S.sage_sparse_attn(q_i8, q_s, k_i8, k_s, v, lut, out_dtype=torch.bfloat16)[0]
+    vt = K.v_transpose(v[0].contiguous().to(DEV), L * 128, 128, L, H, 128, torch.float16)
+    dense = ratio >= 1.0
+    args = (q_i8[0].to(DEV), q_s[0].to(DEV), k_i8[0].to(DEV), k_s[0].to(DEV), vt, None if dense else lut[0].int().to(DEV))
+    outs = []
+    try:
+        for occ in (0, 4):
+            K.set_tuning(K.TUNE_ATTN_OCC, occ)
+            o = torch.full((H, L, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+            K.attn_i8(*args, o, L * 128, 128)
+            outs.append(o)
+    finally:
+        K.set_tuning(K.TUNE_ATTN_OCC, 0)
+    base, out = outs
+    assert torch.isfinite(out).all()
+    assert cosine(out, ref) > 0.9999 and rel_l2(out, ref) < 5e-3
+    assert rel_l2(out, base.float().cpu()) < 3e-3
+
+
 @pytest.mark.parametrize("H,L,ratio", [(2, 256, 1.0), (2, 1000, 0.3), (3, 777, 0.2), (1, 130, 1.0), (2, 2080, 0.1), (1, 97, 1.0)])
 def test_attn_i8_q64_build_vs_oracle(K, H, L, ratio):
     """TD_TUNE_ATTN_OCC = 3: the waves of a workgroup as 2 (Q halves of 64 rows) x 2 (key halves) — every wave a split-K

@@ -52,6 +52,7 @@ def _worker(rank, world, port, at, L, ratio, ret, H=2):
         g = torch.Generator().manual_seed(3)
         wp, bp = torch.randn(D, D, generator=g) * 0.05, torch.randn(D, generator=g) * 0.05
         sp = SeqParallel(ops=oracle_ops)
+        sp._groups_forced = True          # toy shards: keep the head-group pipeline (production picks 1 group for them)
         s, e = sp.plan(L)
         L_loc = e - s
         out = torch.zeros(L_loc, H, D, dtype=q.dtype)
@@ -263,6 +264,7 @@ def test_emulated_rank_runs_one_ranks_work_without_communication():
         sp = SeqParallel(EmulatedGroup(r, W), ops=oracle_ops)
         s, e = sp.plan(L)
         assert (s, e) == (r * 256, min(L, (r + 1) * 256)) and sp.capturable
+        assert sp.groups_for(12, 4096) == 2 and sp.groups_for(12, 8192) == 4 and sp.groups_for(40, 9472) == 4 and sp.groups_for(2, 256) == 1
         L_loc = e - s
         out = torch.zeros(L_loc, H, D, dtype=q.dtype)
         sp.self_attention(q[:, s:e].contiguous(), k[:, s:e].contiguous(), v[:, s:e].contiguous(), (L_loc * D, D), out, D, H * D,

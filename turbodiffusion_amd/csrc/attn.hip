@@ -112,7 +112,12 @@ template <> struct Mma16<TD_BF16> {
 // room for THREE tile buffers and for explicit fragment prefetch: all 8 K fragments of a tile are requested before the
 // first QK MFMA (the 168-register build reuses one fragment register: ds_read -> wait -> MFMA, eight times), and the V
 // fragments of d-block c+1 are requested before the MFMAs of d-block c.
-template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false>
+// ROWSUM (experiment TD_TUNE_ATTN_OCC = 4, on the OCC2 build: it needs 20 more registers than three workgroups per CU leave):
+// the softmax denominator on the MATRIX pipe — P is already rounded to 16 bits for O^T += V^T . P^T; four more MFMAs per
+// tile against an all-ones A operand accumulate sum_k P[k][q] into one more accumulator block (every row of it is the row
+// sum, complete over both half-waves), and the 32 v_add per lane and tile of `psum` leave the VALU stream.  The denominator
+// is then the sum of the ROUNDED probabilities (what the numerator uses); results equal to rounding, not bit-identical.
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false, bool ROWSUM = false>
 // lut_all / ks_all / qs_all repeat p.lut / p.k_s / p.q_s as __restrict__ kernel arguments: only then are the per-iteration
 // LUT entry and K scale SCALAR loads (s_load, lgkmcnt).  As vector loads they drag an s_waitcnt vmcnt(0) into the loop,
 // which waits for every K/V tile in flight and undoes the fetch-ahead.
@@ -236,6 +241,15 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[c][r] = 0.f;
   float m_run = -INFINITY, l_part = 0.f;
+  v16f lacc;
+  frag16 ones16;
+  if constexpr (ROWSUM) {
+    static_assert(!ROWSUM || (OCC2 && !PV8), "the row-sum-by-MFMA experiment lives on the two-workgroup build");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones16[e] = 1.0f;
+  }
 
   // the Q fragments (plain loads) are older than every DMA piece, so the vmcnt waits below cover them too
   TISSUE(has_lut ? lut[0] : 0, 0)
@@ -356,9 +370,10 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s[g][r] = __builtin_amdgcn_exp2f(fmaf(s[g][r], mult, cc));
-        psum += s[g][r];
+        if constexpr (!ROWSUM) psum += s[g][r];
       }
-    l_part = l_part * alpha + psum;
+    if constexpr (ROWSUM) lacc[0] *= alpha;     // (only row 0 of the ones-product is ever read: every row holds the same sum)
+    else l_part = l_part * alpha + psum;
     if (!__all(alpha == 1.0f)) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
@@ -409,6 +424,10 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
           frag16 pv = *reinterpret_cast<const frag16*>(&pf[ks]);
           oacc[c] = Mma16<PDT>::mma(vfr[c & 1][ks], pv, oacc[c]);
         }
+        if constexpr (ROWSUM) {   // one of the four row-sum MFMAs behind each d block's four
+          frag16 pv = *reinterpret_cast<const frag16*>(&pf[c]);
+          lacc = Mma16<PDT>::mma(ones16, pv, lacc);
+        }
       }
     } else {
 #pragma unroll
@@ -438,7 +457,7 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
   // instruction), the linear branch's o_l is added from its lane-private layout (a coalesced read instead of a
   // strided read-modify-write pass), and — optionally — the tile, which is exactly one 128x128 quantisation block of
   // the [L, H*128] attention output, is block-quantised for the o projection right here.
-  const float l_tot = l_part + __shfl_xor(l_part, 32, 64);
+  const float l_tot = ROWSUM ? lacc[0] : l_part + __shfl_xor(l_part, 32, 64);
   const float inv = 1.0f / l_tot;
   uint2 addv[16];
   if (p.add_t) {
@@ -866,20 +885,21 @@ static int launch_attn_q64(const AttnParams& p_in, hipStream_t st) {
   return TD_OK;
 }
 
-template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false>
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false, bool ROWSUM = false>
 static int launch_attn(const AttnParams& p_in, hipStream_t st) {
   AttnParams p = p_in;
   p.dbg = nullptr;
   if constexpr (QK_I8 && !PV8 && !OCC2 && !STAMP) {
     if (td_tuning(TD_TUNE_ATTN_OCC) == 2) return launch_attn<QK_I8, PDT, ODT, PV8, true>(p, st);
     if (td_tuning(TD_TUNE_ATTN_OCC) == 3) return launch_attn_q64<ODT>(p, st);
+    if (td_tuning(TD_TUNE_ATTN_OCC) == 4) return launch_attn<QK_I8, PDT, ODT, PV8, true, false, true>(p, st);
   }
   if constexpr (!PV8 && !OCC2 && !STAMP && ODT == TD_BF16 && (QK_I8 || PDT == TD_BF16)) {
     // profiling instantiations of the two kernels the model runs (bf16 outputs)
     if (td_tuning(TD_TUNE_ATTN_OCC) == 9) return launch_attn<QK_I8, PDT, ODT, PV8, false, true>(p, st);
   }
   if constexpr (STAMP) p.dbg = td_dbg_buffer();
-  auto kern = attn_kernel<QK_I8, PDT, ODT, PV8, OCC2, STAMP>;
+  auto kern = attn_kernel<QK_I8, PDT, ODT, PV8, OCC2, STAMP, ROWSUM>;
   // two (three: OCC2) tile buffers, and at least the 128 x 272-byte staging area of the epilogue's transpose
   constexpr int lds_tiles = (OCC2 ? 3 : 2) * (KTile<QK_I8>::BYTES + (PV8 ? VT8_BYTES : VT_BYTES));
   constexpr int lds = lds_tiles > 128 * 272 ? lds_tiles : 128 * 272;

@@ -592,7 +592,11 @@ static int sla_linear_out_impl(const void* q, int dtype, const void* kvsum_t, co
   const int Qb = (int)td_cdiv(L, 128);
   const int lds = 2 * 128 * 256 + 128 * 4;
   const int tune_ = td_tuning(TD_TUNE_LIN_QB);
-  const int qpw = tune_ > 0 ? tune_ : (tune_ < 0 ? -tune_ : LO_QB_PER_WG);
+  // small problems (a sequence-parallel rank's heads of one group: 32 Q blocks x 3 heads): fewer Q blocks per workgroup so
+  // that the grid still covers the chip (24 workgroups took 34 us for 1/32 of the single-GPU work, round 4)
+  int qpw_auto = LO_QB_PER_WG;
+  while (qpw_auto > 1 && td_cdiv(Qb, qpw_auto) * H < 512) --qpw_auto;
+  const int qpw = tune_ > 0 ? tune_ : (tune_ < 0 ? -tune_ : qpw_auto);
   unsigned long long* dbg = tune_ < 0 ? td_dbg_buffer() : nullptr;
   dim3 grid((unsigned)td_cdiv(Qb, qpw), H);
   hipStream_t st = (hipStream_t)stream;

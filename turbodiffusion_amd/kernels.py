@@ -67,9 +67,10 @@ def _timed(name, meta, fn):
 
 TUNE_GEMM_VARIANT = 0
 TUNE_GEMM_ABLATE = 1
+TUNE_GEMM_GROUP_M = 3  # m-tiles per raster group of the 256x256 GEMM kernels (0 = default 4)
 TUNE_GEMM_FAST = 6   # 0 = library default, 1 = exact dequant, G in {2, 4, 8} = one-VALU dequant re-centred every G K blocks
 TUNE_LIN_QB = 7      # linear branch pass 2: Q blocks per workgroup (0 = library default)
-TUNE_ATTN_OCC = 8    # 2 = INT8/FP16-PV attention built for two workgroups per CU with explicit fragment prefetch, 3 = the Q64 build
+TUNE_ATTN_OCC = 8    # 2 = INT8/FP16-PV attention built for two workgroups per CU with explicit fragment prefetch, 3 = the Q64 build, 4 = 2 + row sum on the matrix pipe
 TUNE_VAE_CONV = 9    # 1 = the first td_vae_conv kernel (cross-check of the default)
 
 

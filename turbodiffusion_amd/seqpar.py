@@ -153,10 +153,21 @@ class SeqParallel:
         self.parallel_groups = True
         self._group_streams = {}
         import os   # A/B switches for the measurement tools (tools/gpu/*.sh); results do not depend on them
-        if os.environ.get("TD_SP_HEAD_GROUPS"):
+        self._groups_forced = bool(os.environ.get("TD_SP_HEAD_GROUPS"))
+        if self._groups_forced:
             self.head_groups = int(os.environ["TD_SP_HEAD_GROUPS"])
         if os.environ.get("TD_SP_PARALLEL_GROUPS"):
             self.parallel_groups = os.environ["TD_SP_PARALLEL_GROUPS"] != "0"
+
+    def groups_for(self, H, per):
+        """Head groups of the K-side exchange for a rank with ``per`` tokens: every group's attention launch is H/G heads x
+        per/128 Q blocks workgroups, and a launch under ~200 workgroups leaves most of the 256 CUs idle for the length of
+        one workgroup's serial walk over its keys (measured by rank emulation, round 4: 1.3B / 480p over 8 ranks = 384
+        workgroups in total — 22.3 / 23.2 / 26.7 ms per DiT step with 1 / 2 / 4 groups; the exchange that the groups hide is
+        5.0 ms).  TD_SP_HEAD_GROUPS overrides (``head_groups`` set explicitly)."""
+        if self._groups_forced:
+            return self.head_groups
+        return max(1, min(self.head_groups, (H * (per // 128)) // 192))
 
     # ------------------------------------------------------------------ token sharding
     def plan(self, L: int):
@@ -254,7 +265,7 @@ class SeqParallel:
 
         # ---- (2) local K-side state, written by the producer kernels straight into the send buffer: ONE buffer
         # [groups][k | vt | ks | pk | kv | kss][heads of the group][...] (PackLayout), one all-gather per head group ----
-        lay = PackLayout(H, per, D, self.head_groups, sage, dense, dt)
+        lay = PackLayout(H, per, D, self.groups_for(H, per), sage, dense, dt)
         pack = ops.sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay)          # uint8 [G, group_bytes]
 
         # ---- (2) + (3), pipelined over head groups: the groups' all-gathers are issued back to back (asynchronously,

@@ -168,7 +168,6 @@ class WanModel(nn.Module):
         self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
         self.fuse_embed_head = True  # patchify+patch_embedding, time MLPs, AdaLN vectors, head+unpatchify in HIP (embed_head.hip)
         self.split_tokens = True    # everything after self-attention is token-local: two token halves on two streams (_block)
-        self.hip_gemm16 = True      # plain 16-bit Linears (text MLP, C3's bf16 linears) on td_gemm_bf16; False: the library GEMM (A/B only)
         self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
         self.cache_text_kv = True  # cross-attention K / V^T of the text are a function of the text only: once per video
@@ -280,12 +279,12 @@ class WanModel(nn.Module):
     def _lin16(self, x, w, b, gelu=False):
         """A plain 16-bit Linear (BASELINE config 3's "bf16 linears", the text MLP, C1's arithmetic on the GPU) on
         ``td_gemm_bf16`` — bias and GELU-tanh in the GEMM's epilogue with the operator sequence's rounding points."""
-        if (self.hip_gemm16 and x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and x.shape[-1] % 64 == 0
+        if (x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and x.shape[-1] % 64 == 0
                 and w.shape[0] % 8 == 0 and (b is None or b.dtype == x.dtype)):
             x2 = x.reshape(-1, x.shape[-1])
             y = K.gemm_bf16(x2, w.detach(), None if b is None else b.detach(), epilogue="gelu_tanh" if gelu else "none")
             return y.view(*x.shape[:-1], w.shape[0])
-        y = F.linear(x, w, b)
+        y = F.linear(x, w, b)          # widths the kernel does not take (k % 64 != 0: toy models in tests) and fp32 models
         return F.gelu(y, approximate="tanh") if gelu else y
 
     def _lin_q(self, mod, xq, xs, dtype, gelu=False):
