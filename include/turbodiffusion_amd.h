@@ -132,6 +132,12 @@ int td_vae_chan_rms(const void* x, const void* gamma, void* y, int64_t rows, int
 int td_gemm_bf16(const void* a, const void* b, const void* bias, const void* res, void* d, int dtype, int out_dtype, int epilogue,
                  int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int64_t ldd, int64_t ldr, int64_t batch,
                  int64_t stride_a, int64_t stride_b, int64_t stride_d, int64_t stride_r, td_stream_t stream);
+/* split-K companion of td_gemm_bf16 for small m (a few dozen 256x256 tiles cannot pull the weights through the chip): run the
+ * GEMM as a batch of `splits` K-slices with fp32 outputs ws [splits, m, n] (td_gemm_bf16 with out_dtype TD_F32, batch strides =
+ * k / splits columns), then this pass adds the slices in fp32 and applies bias / epilogue / residual with td_gemm_bf16's
+ * rounding points. */
+int td_gemm_bf16_splitk_reduce(const float* ws, int splits, const void* bias, const void* res, void* d, int dtype, int epilogue,
+                               int64_t m, int64_t n, int64_t ldd, int64_t ldr, td_stream_t stream);
 int td_softmax_rows(const void* s, int s_dtype, void* p, int p_dtype, const void* bias, int64_t rows, int64_t cols, int64_t lds,
                     int64_t ldp, int64_t bias_rows, int64_t ldb, float scale, td_stream_t stream);
 int td_t5_norm(const void* x, const void* w, void* y, int dtype, float eps, int64_t rows, int64_t n, int64_t ldx, int64_t ldy,

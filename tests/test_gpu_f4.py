@@ -221,7 +221,8 @@ def _gemm_ref(a, w, bias=None, res=None, epilogue="none"):
     return y
 
 
-@pytest.mark.parametrize("case", ["plain", "bias", "bias+gelu", "res", "geglu", "f32 out", "ragged", "k pad", "strided", "f16"])
+@pytest.mark.parametrize("case", ["plain", "bias", "bias+gelu", "res", "geglu", "f32 out", "ragged", "k pad", "strided", "f16",
+                                  "splitk bias+gelu", "splitk res", "splitk geglu"])
 def test_gemm_bf16_vs_fp32_matmul(K, case):
     """td_gemm_bf16 (256x256-tile 16-bit GEMM on v_mfma_f32_16x16x32) against an fp32 matmul of the same 16-bit operands
     with the operator sequence's rounding points: within one 16-bit step, most outputs equal."""
@@ -234,12 +235,15 @@ def test_gemm_bf16_vs_fp32_matmul(K, case):
         m, n, k = 130, 96, 160          # k not a multiple of 64: the wrapper zero-pads both operands
     elif case == "geglu":
         m, n, k = 300, 2 * 288, 256     # 288 output columns = 9 blocks of 32: the last 256-row tile of B is partial
+    elif case.startswith("splitk"):     # few tiles, deep K: the wrapper runs K-slices + the reduce / epilogue pass
+        m, n, k = 100, 2 * 288 if "geglu" in case else 520, 2048
+        assert K._splitk(m, n, k) == 4
     a = torch.randn(m, k, generator=g).to(dt)
     w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dt)
-    bias = (0.3 * torch.randn(n, generator=g)).to(dt) if case in ("bias", "bias+gelu", "f32 out", "ragged", "f16") else None
-    res = torch.randn(m, n, generator=g).to(dt) if case == "res" else None
-    epi = {"bias+gelu": "gelu_tanh", "geglu": "geglu"}.get(case, "none")
-    if case == "geglu":
+    bias = (0.3 * torch.randn(n, generator=g)).to(dt) if case in ("bias", "bias+gelu", "f32 out", "ragged", "f16", "splitk bias+gelu", "splitk res") else None
+    res = torch.randn(m, n, generator=g).to(dt) if case in ("res", "splitk res") else None
+    epi = {"bias+gelu": "gelu_tanh", "geglu": "geglu", "splitk bias+gelu": "gelu_tanh", "splitk geglu": "geglu"}.get(case, "none")
+    if epi == "geglu":
         gate, fc1 = w[: n // 2], w[n // 2:]
         wi = K.geglu_interleave(gate.to(DEV), fc1.to(DEV))
         out = K.gemm_bf16(a.to(DEV), wi, epilogue="geglu").float().cpu()
@@ -273,7 +277,7 @@ def test_gemm_bf16_vs_fp32_matmul(K, case):
     if bad.any():
         i, j = (int(v) for v in bad.nonzero()[0])
         extra = ""
-        if case == "geglu":
+        if epi == "geglu":
             y = (a.float() @ wi.float().cpu().t()).to(dt).float().view(m, n // 64, 2, 32)
             extra = f" gate {y[i, j // 32, 0, j % 32].item()} fc1 {y[i, j // 32, 1, j % 32].item()}"
         raise AssertionError(f"{int(bad.sum())} of {bad.numel()} outside the bound; first at ({i}, {j}): got {out[i, j].item()} "

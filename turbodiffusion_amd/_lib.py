@@ -34,6 +34,7 @@ SIGNATURES = {
     "td_vae_conv_ex": [_vp, _i64, _vp, _vp, _vp, _vp, _i64] + [_i32] * 19 + [_vp],
     "td_vae_chan_rms": [_vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_gemm_bf16": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32] + [_i64] * 12 + [_vp],
+    "td_gemm_bf16_splitk_reduce": [_vp, _i32, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i64, _vp],
     "td_softmax_rows": [_vp, _i32, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp],
     "td_t5_norm": [_vp, _vp, _vp, _i32, _f32, _i64, _i64, _i64, _i64, _vp],
     "td_gemv_f32": [_vp, _vp, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp],

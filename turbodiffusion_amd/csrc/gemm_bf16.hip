@@ -19,6 +19,7 @@
 // reference's operator sequence with its rounding points: + bias (rounded), GELU-tanh (rounded) | gated-GELU, + residual
 // (rounded).  Parity is stated against an fp32 matmul of the same 16-bit operands (tests/test_gpu_f4.py).
 #include "td_common.h"
+#include <algorithm>
 
 #define G_BM 256
 #define G_BN 256
@@ -63,7 +64,10 @@ struct Gemm16P {
 // umt5.py:125-127 on a value already rounded to the 16-bit dtype, every torch op rounding its result to that dtype:
 // 0.5 * x * (1.0 + tanh(sqrt(2/pi) * (x + 0.044715 * pow(x, 3))))
 template <int DT> __device__ __forceinline__ float g_t5_gelu(float x) {
-  const float p3 = round_half<DT>(x * x * x);                       // torch.pow(x, 3.0): computed in fp32, one rounding
+  // torch.pow(x, 3.0) on a 16-bit tensor is `base * base * base` on the 16-bit scalar type (ATen's pow kernels, CPU and
+  // GPU alike): the square is rounded before the third factor — two roundings (an fp32 cube rounded once differs in the last
+  // place often enough to flip tanh's rounding further down: found by the GPU parity test, round 4)
+  const float p3 = round_half<DT>(round_half<DT>(x * x) * x);
   const float a = round_half<DT>(0.044715f * p3);
   const float s = round_half<DT>(x + a);
   const float u = round_half<DT>(0.7978845608028654f * s);
@@ -398,6 +402,62 @@ extern "C" int td_gemm_bf16(const void* a, const void* b, const void* bias, cons
   hipStream_t st = (hipStream_t)stream;
   return dtype == TD_BF16 ? dispatch_gemm16<TD_BF16>(p, out_dtype, epilogue, (int)batch, st)
                           : dispatch_gemm16<TD_F16>(p, out_dtype, epilogue, (int)batch, st);
+}
+
+// ---- split-K (small M: umT5's linears at 64 ... 512 tokens, the text MLP).  A 256x256-tile GEMM with M <= 512 has a few dozen
+// tiles for 256 CUs and every one walks the whole K: the weights stream through too few workgroups (86 us for the 100 MB of
+// umT5's q|k|v at 64 tokens: 1.2 TB/s).  The host wrapper runs such a problem as a BATCH of S K-slices through the kernel
+// above (batch strides = K/S columns of A and B, fp32 partial outputs [S, M, N]: no kernel change) and this pass adds the
+// slices in fp32 and applies the epilogue with the same rounding points: cast -> + bias, cast -> GELU | gated GELU, cast ->
+// + res, cast. ----
+template <int DT, int EPI, bool HAS_BIAS, bool RES>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, int64_t M, int64_t N,
+                                                            const uint16_t* __restrict__ bias, const uint16_t* __restrict__ R,
+                                                            uint16_t* __restrict__ D, int64_t ldd, int64_t ldr) {
+  const int64_t No = EPI == G_EPI_GEGLU ? N / 2 : N;
+  const int64_t total = M * No;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / No, n = i % No;
+    if constexpr (EPI == G_EPI_GEGLU) {
+      const int64_t ng = (n >> 5) * 64 + (n & 31), nf = ng + 32;   // interleaved gate / fc1 rows of B = columns of the partials
+      float g = 0.f, f = 0.f;
+      for (int z = 0; z < S; ++z) { g += ws[((int64_t)z * M + m) * N + ng]; f += ws[((int64_t)z * M + m) * N + nf]; }
+      g = round_half<DT>(g); f = round_half<DT>(f);
+      D[m * ldd + n] = (uint16_t)f32_to_half_bits<DT>(f * g_t5_gelu<DT>(g));
+    } else {
+      float a = 0.f;
+      for (int z = 0; z < S; ++z) a += ws[((int64_t)z * M + m) * N + n];
+      a = round_half<DT>(a);
+      if constexpr (HAS_BIAS) a = round_half<DT>(a + half_bits_to_f32<DT>(bias[n]));
+      if constexpr (EPI == G_EPI_GELU) a = round_half<DT>(td_gelu_tanh(a));
+      if constexpr (RES) a = a + half_bits_to_f32<DT>(R[m * ldr + n]);
+      D[m * ldd + n] = (uint16_t)f32_to_half_bits<DT>(a);
+    }
+  }
+}
+
+extern "C" int td_gemm_bf16_splitk_reduce(const float* ws, int splits, const void* bias, const void* res, void* d, int dtype,
+                                          int epilogue, int64_t m, int64_t n, int64_t ldd, int64_t ldr, td_stream_t stream) {
+  TD_REQUIRE(ws && d && splits >= 1 && splits <= 64, TD_ERR_INVALID, "td_gemm_bf16_splitk_reduce: null pointer or splits = %d", splits);
+  TD_REQUIRE(dtype == TD_BF16 || dtype == TD_F16, TD_ERR_UNSUPPORTED, "td_gemm_bf16_splitk_reduce: dtype %d", dtype);
+  TD_REQUIRE(m > 0 && n > 0 && epilogue >= G_EPI_NONE && epilogue <= G_EPI_GEGLU, TD_ERR_INVALID, "td_gemm_bf16_splitk_reduce: shape / epilogue");
+  TD_REQUIRE(epilogue != G_EPI_GEGLU || (n % 64 == 0 && !bias && !res), TD_ERR_UNSUPPORTED, "td_gemm_bf16_splitk_reduce: gated GELU takes no bias / residual");
+  TD_REQUIRE(!res || epilogue == G_EPI_NONE, TD_ERR_UNSUPPORTED, "td_gemm_bf16_splitk_reduce: residual with the plain epilogue only");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = m * (epilogue == G_EPI_GEGLU ? n / 2 : n);
+  const unsigned grid = (unsigned)std::min<int64_t>(td_cdiv(total, 256), 4096);
+#define TD_SKR(DT_, EPI_, HB_, RS_) \
+  splitk_reduce_kernel<DT_, EPI_, HB_, RS_><<<grid, 256, 0, st>>>(ws, splits, m, n, (const uint16_t*)bias, (const uint16_t*)res, (uint16_t*)d, ldd, ldr)
+#define TD_SKR_DT(DT_)                                                                             \
+  if (epilogue == G_EPI_GEGLU) TD_SKR(DT_, G_EPI_GEGLU, false, false);                             \
+  else if (epilogue == G_EPI_GELU) { if (bias) TD_SKR(DT_, G_EPI_GELU, true, false); else TD_SKR(DT_, G_EPI_GELU, false, false); } \
+  else if (res) { if (bias) TD_SKR(DT_, G_EPI_NONE, true, true); else TD_SKR(DT_, G_EPI_NONE, false, true); }                      \
+  else { if (bias) TD_SKR(DT_, G_EPI_NONE, true, false); else TD_SKR(DT_, G_EPI_NONE, false, false); }
+  if (dtype == TD_BF16) { TD_SKR_DT(TD_BF16) } else { TD_SKR_DT(TD_F16) }
+#undef TD_SKR_DT
+#undef TD_SKR
+  TD_CHECK_LAUNCH();
+  return TD_OK;
 }
 
 // ---- row softmax (VAE middle-block attention: F.scaled_dot_product_attention's softmax(q k^T / sqrt(C)); umT5:

@@ -360,7 +360,15 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // lane owns m = ..+l16; accumulator (i,j) holds n_local = 16j + r + 8(lq&1) + 4(lq>>1).
   // After the swap lanes with lq<2 store 8 consecutive n of sub-tile ja, lanes with lq>=2 of jb.
   const int hi = lq >> 1;
+  // TD_PHASE_MARKS (analysis builds only, tools/epilogue_valu_count.py): assembler comments at the phase boundaries of the
+  // QOUT epilogue so that its instructions can be counted per phase in the .s file
+#ifdef TD_PHASE_MARKS
+#define F_MARK(name_) asm volatile("; TD_PHASE " name_ ::: "memory");
+#else
+#define F_MARK(name_)
+#endif
   if constexpr (QOUT) {
+    F_MARK("qout_begin")
     // (1) the 16-bit results exactly as the plain epilogue would store them, kept in 64 VGPRs
     uint32_t pk[8][4][2];
     const bool tail = (m0 + F_BM > M) || (n0 + F_BN > N);
@@ -383,6 +391,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         if (tail && !ok) { pk[i][j][0] = 0u; pk[i][j][1] = 0u; }  // rows/cols outside the matrix: zero-filled (load.hpp:24-47)
       }
     }
+    F_MARK("qout_amax")
     // (2) amax of this wave's 128x64 half of the 128x128 quant block: max over |x| as 15-bit magnitudes (both 16-bit
     //     formats are monotone in their magnitude bits), two per v_pk_max_u16
     uint32_t mx = 0u;
@@ -398,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     uint32_t m16 = max(mx & 0xffffu, mx >> 16);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m16 = max(m16, (uint32_t)__shfl_xor((int)m16, o, 64));
+    F_MARK("qout_exchange")
     // (3) the other half belongs to wave ^ 1: exchange through LDS (free: every wave is past the last barrier
     //     of the main loop, nothing reads or lands in the stages any more)
     uint32_t* red = reinterpret_cast<uint32_t*>(smem);
@@ -415,6 +425,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     //     rintf of the rounded product); its low byte IS the two's-complement code.  |x*mult| <= 128(1+eps), so only
     //     +128 needs the clamp.  (5) two lane swaps gather 16 consecutive n per lane -> one 16-byte store per row.
     int8_t* Dq = reinterpret_cast<int8_t*>(D);
+    F_MARK("qout_quantise_store")
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int64_t m = m0 + wm * 128 + i * 16 + l16;
@@ -448,6 +459,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       const int64_t n = n0 + wn * 64 + jt * 16;
       if (m < M && n < N) *reinterpret_cast<uint4*>(Dq + m * ldd + n) = v;
     }
+    F_MARK("qout_end")
     return;
   }
   // RES: the residual tile is fetched up front — 16 independent 16-byte loads per lane in flight, at the addresses

@@ -897,9 +897,31 @@ def gemm_bf16(a, w, bias=None, res=None, epilogue="none", out_dtype=None, out=No
         assert bias.dtype == a.dtype and bias.numel() == n and bias.is_contiguous()
     if res is not None:
         assert res.dtype == a.dtype and tuple(res.shape) == (m, n) and _unit_inner(res)
+    splits = _splitk(m, n, k) if odt != torch.float32 else 1
+    if splits > 1:
+        # small m: a batch of K-slices with fp32 partials, then the reduce + epilogue pass (csrc/gemm_bf16.hip "split-K")
+        ws = torch.empty((splits, m, n), dtype=torch.float32, device=a.device)
+        ks = k // splits
+        call("td_gemm_bf16", ptr(a), ptr(w), None, None, ptr(ws), L.dt_code(a.dtype), L.TD_F32, 0, m, n, ks, a.stride(0),
+             w.stride(0), n, 0, splits, ks, ks, m * n, 0, stream_ptr())
+        call("td_gemm_bf16_splitk_reduce", ptr(ws), splits, ptr(bias), ptr(res), ptr(out), L.dt_code(a.dtype), GEMM16_EPI[epilogue],
+             m, n, out.stride(0), 0 if res is None else res.stride(0), stream_ptr())
+        return out
     call("td_gemm_bf16", ptr(a), ptr(w), ptr(bias), ptr(res), ptr(out), L.dt_code(a.dtype), L.dt_code(odt), GEMM16_EPI[epilogue],
          m, n, k, a.stride(0), w.stride(0), out.stride(0), 0 if res is None else res.stride(0), 1, 0, 0, 0, 0, stream_ptr())
     return out
+
+
+def _splitk(m, n, k):
+    """K-slices for a problem whose 256x256 tiles cannot fill the chip: enough slices for >= ~256 workgroups, each slice at
+    least 512 deep and a multiple of 64; 1 = no split."""
+    tiles = cdiv(m, 256) * cdiv(n, 256)
+    if tiles >= 128 or k < 1024:
+        return 1
+    s = min(16, max(1, 256 // tiles), k // 512)
+    while s > 1 and k % (64 * s):
+        s -= 1
+    return s
 
 
 def gemm_bf16_batched(a, b, out_dtype=None, out=None, bias=None):
