@@ -700,11 +700,28 @@ def main():
             link = 120e9                                # effective B/s of one xGMI link (153 GB/s peak; full mesh: one link per peer)
             nl = cfg["num_layers"]
             wire_layer = pack / link                    # every peer's pack arrives over its own link, all in parallel
+            # what the emulation ADDS to a real rank's kernels: the device copies that fill the peers' slots of the gathered
+            # buffers (in a real run those bytes arrive over xGMI, written by the fabric, not by this GPU's CUs) — timed
+            # alone here, the same shapes back to back, so that the table can state the compute term with and without them
+            src_ = torch.empty(lay.gb, dtype=torch.uint8, device=dev)
+            dst_ = torch.empty((emu[1], lay.gb), dtype=torch.uint8, device=dev)
+            for _ in range(3):
+                dst_.copy_(src_.view(1, -1).expand(emu[1], -1))
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            ev0.record()
+            for _ in range(nl * lay.G):
+                dst_.copy_(src_.view(1, -1).expand(emu[1], -1))
+            ev1.record()
+            torch.cuda.synchronize()
+            copy_ms = ev0.elapsed_time(ev1)
             res["metric"] = "EMULATED rank: " + res["metric"]
             res["vs_baseline"] = None
             res["emulated_rank"] = {
                 "rank": emu[0], "of": emu[1], "tokens_of_rank": spo.stop - spo.start, "tokens_per_rank_padded": spo.per,
                 "measured_compute_ms_per_dit_step": per_video * 1e3 / args.num_steps,
+                "of_which_emulation_gather_copies_ms": copy_ms,
+                "branches_in_parallel": bool(spo.branches_in_parallel(cfg["num_heads"], spo.per, lay.G)),
                 "pack_bytes_per_layer": pack, "head_groups": lay.G,
                 "modelled_wire_ms_per_dit_step": {"link_GBps": link / 1e9, "fully_exposed": nl * wire_layer * 1e3,
                                                   "first_head_group_exposed": nl * wire_layer / lay.G * 1e3},

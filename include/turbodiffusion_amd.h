@@ -124,7 +124,8 @@ int td_vae_chan_rms(const void* x, const void* gamma, void* y, int64_t rows, int
  *   epilogue: 0 none; 1 GELU-tanh (nn.GELU(approximate="tanh"), wan2pt1.py:375,678); 2 gated GELU of umT5's T5FeedForward
  *   (umt5.py:125-127,210: d [m, n/2] = fc1(x) * GELU(gate(x)) with B's rows = gate / fc1 interleaved in blocks of 32 rows
  *   — rows [64p, 64p+32) gate columns [32p, 32p+32), rows [64p+32, 64p+64) fc1 columns of the same range — and the 16-bit
- *   rounding of every elementwise step of the reference's explicit tanh formula); res (16-bit, plain epilogue only): x + Linear.
+ *   rounding of every elementwise step of the reference's explicit tanh formula); 3 exact (erf) GELU, nn.GELU() of Wan2.1 I2V's
+ *   MLPProj (wan2pt1.py:462-466); res (16-bit, plain epilogue only): x + Linear.
  * td_softmax_rows: p[r, c] = softmax_c(scale * (s[r, c] (+ bias[r % bias_rows, c]))) in fp32, rounded once; columns
  *   [cols, ldp) of p are zero-filled (the next GEMM's k runs over the padded width).  s f32 or p's dtype (16-bit s: the
  *   bias add is rounded to that dtype first — `einsum(q, k) + attn_bias`, umt5.py:183); in place when s == p and lds == ldp.

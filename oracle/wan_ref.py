@@ -74,7 +74,7 @@ def _attention(q, k, v, kind, sd, prefix, topk, dt):
 
 def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=None, mode="eager",
                 attention="original", quant=False, topk=0.1, act_dtype=torch.bfloat16, num_layers=None,
-                return_tokens=False, tap=None):
+                return_tokens=False, tap=None, clip_emb=None):
     """``tap``: optional dict that receives the intermediates of block 0 (fixture generation only).
     ``return_tokens``: True -> the [B, L, dim] tokens after the last block; "both" -> (tokens, velocity) from ONE pass.
     ``sd`` may be any mapping with ``__getitem__`` / ``get`` / ``__contains__`` (make_golden_r04.LazyLayers generates a
@@ -114,6 +114,20 @@ def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=
     ctx = _lin(crossattn_emb, sd["text_embedding.0.weight"], sd["text_embedding.0.bias"], dt)
     ctx = _lin(F.gelu(ctx, approximate="tanh"), sd["text_embedding.2.weight"], sd["text_embedding.2.bias"], dt)
     freqs = O.rope_freqs(T, Hh, Ww, D)
+    ctx_img = None
+    if clip_emb is not None:
+        # Wan2.1 I2V: CLIP image tokens [B, 257, 1280] -> MLPProj (wan2pt1.py:457-486: LayerNorm, Linear, exact GELU, Linear,
+        # LayerNorm, all in the model dtype) -> context_clip, attended by every block's image branch (:303-352)
+        h_ = F.layer_norm(clip_emb.to(dt), (clip_emb.shape[-1],), sd["img_emb.proj.0.weight"].to(dt), sd["img_emb.proj.0.bias"].to(dt), 1e-5)
+        h_ = F.gelu(_lin(h_, sd["img_emb.proj.1.weight"], sd["img_emb.proj.1.bias"], dt))
+        h_ = _lin(h_, sd["img_emb.proj.3.weight"], sd["img_emb.proj.3.bias"], dt)
+        ctx_img = F.layer_norm(h_, (dim,), sd["img_emb.proj.4.weight"].to(dt), sd["img_emb.proj.4.bias"].to(dt), 1e-5)
+        # the reference concatenates [clip tokens, text tokens] and every block slices the two parts back out (:332-334, :682);
+        # the slices are VIEWS with the concatenation's batch stride, and the CPU library GEMM's summation order depends on
+        # that layout — kept, so that the bit-for-bit pin against the live module holds
+        n_img = ctx_img.shape[1]
+        ctx_all = torch.cat([ctx_img, ctx], dim=1)
+        ctx_img, ctx = ctx_all[:, :n_img], ctx_all[:, n_img:]
 
     for i in range(nl):
         p = f"blocks.{i}"
@@ -138,6 +152,10 @@ def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=
         k = rms(lin(ca + ".k", ctx), sd[ca + ".norm_k.weight"]).view(B, -1, H, D)
         v = lin(ca + ".v", ctx).view(B, -1, H, D)
         a = _attention(q, k, v, "original", sd, ca, topk, dt)
+        if ctx_img is not None:   # WanI2VCrossAttention.forward (wan2pt1.py:340-352): the same q against the image keys, summed
+            k_i = rms(lin(ca + ".k_img", ctx_img), sd[ca + ".norm_k_img.weight"]).view(B, -1, H, D)
+            v_i = lin(ca + ".v_img", ctx_img).view(B, -1, H, D)
+            a = a + _attention(q, k_i, v_i, "original", sd, ca, topk, dt)
         x = x + lin(ca + ".o", a)
         if tap is not None and i == 0:
             tap["x_after_ca"] = x
@@ -206,7 +224,15 @@ def make_state_dict(cfg, seed=0, with_proj_l=True):
         sd[name + ".weight"] = (torch.randn(o, i, generator=g) * std).bfloat16().float()
         sd[name + ".bias"] = (torch.randn(o, generator=g) * 0.02).bfloat16().float()
 
+    clip_dim = cfg.get("clip_dim")
     lin("patch_embedding", dim, in_dim)
+    if clip_dim:
+        sd["img_emb.proj.0.weight"] = (1 + 0.1 * torch.randn(clip_dim, generator=g)).bfloat16().float()
+        sd["img_emb.proj.0.bias"] = (0.02 * torch.randn(clip_dim, generator=g)).bfloat16().float()
+        lin("img_emb.proj.1", clip_dim, clip_dim, 1.0 / math.sqrt(clip_dim))
+        lin("img_emb.proj.3", dim, clip_dim, 1.0 / math.sqrt(clip_dim))
+        sd["img_emb.proj.4.weight"] = (1 + 0.1 * torch.randn(dim, generator=g)).bfloat16().float()
+        sd["img_emb.proj.4.bias"] = (0.02 * torch.randn(dim, generator=g)).bfloat16().float()
     lin("text_embedding.0", dim, text_dim, 0.02)
     lin("text_embedding.2", dim, dim, 0.02)
     lin("time_embedding.0", dim, freq, 0.02)
@@ -219,6 +245,10 @@ def make_state_dict(cfg, seed=0, with_proj_l=True):
                 lin(f"{p}.{a}.{n}", dim, dim, 1.0 / math.sqrt(dim))
             for n in ("norm_q", "norm_k"):
                 sd[f"{p}.{a}.{n}.weight"] = (1 + 0.1 * torch.randn(dim, generator=g)).bfloat16().float()
+        if clip_dim:
+            for n in ("k_img", "v_img"):
+                lin(f"{p}.cross_attn.{n}", dim, dim, 1.0 / math.sqrt(dim))
+            sd[f"{p}.cross_attn.norm_k_img.weight"] = (1 + 0.1 * torch.randn(dim, generator=g)).bfloat16().float()
         if with_proj_l:
             sd[f"{p}.self_attn.attn_op.local_attn.proj_l.weight"] = (torch.randn(128, 128, generator=g) * 0.02).bfloat16().float()
             sd[f"{p}.self_attn.attn_op.local_attn.proj_l.bias"] = (torch.randn(128, generator=g) * 0.02).bfloat16().float()

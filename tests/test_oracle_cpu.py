@@ -96,6 +96,31 @@ def test_oracle_dit_matches_live_reference_wan2pt2(model_type, in_dim):
 
 
 @pytest.mark.skipif(not rh.available(), reason="/root/reference not present (GPU box)")
+def test_oracle_dit_matches_live_reference_wan2pt1_i2v_clip_branch():
+    """Wan2.1 I2V (rcm/networks/wan2pt1.py: ``model_type="i2v"`` -> ``WanI2VCrossAttention`` :303-352 with k_img / v_img /
+    norm_k_img and ``MLPProj`` :457-486 on the 257 CLIP tokens, ``frame_cond_crossattn_emb_B_L_D`` + ``y`` both required :642):
+    the oracle's forward with ``clip_emb`` against the LIVE reference module, bit for bit."""
+    warnings.filterwarnings("ignore")
+    cfg = dict(dim=256, eps=1e-6, ffn_dim=384, freq_dim=256, in_dim=36, model_type="i2v", num_heads=2, num_layers=2,
+               out_dim=16, text_len=512, text_dim=64, clip_dim=1280)
+    sd = W.make_state_dict(cfg, seed=11)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 16, 2, 8, 10, generator=g)
+    y = torch.cat([torch.zeros(2, 4, 2, 8, 10), torch.randn(2, 16, 2, 8, 10, generator=g)], 1)
+    y[:, :4, 0] = 1.0
+    t = torch.tensor([[995.025], [852.895]])
+    ctx = torch.randn(2, 512, 64, generator=g)
+    clip = torch.randn(2, 257, 1280, generator=g)
+    net = rh.reference_wan_from_sd(cfg, sd, torch.bfloat16)
+    with torch.no_grad():
+        ref = net(x.bfloat16(), t.bfloat16(), ctx.bfloat16(), frame_cond_crossattn_emb_B_L_D=clip.bfloat16(), y_B_C_T_H_W=y.bfloat16())
+    out = W.wan_forward(sd, cfg, x, t.bfloat16(), ctx.bfloat16(), y_B_C_T_H_W=y.bfloat16(), mode="eager", clip_emb=clip.bfloat16())
+    assert torch.equal(out, ref)
+    out0 = W.wan_forward(sd, cfg, x, t.bfloat16(), ctx.bfloat16(), y_B_C_T_H_W=y.bfloat16(), mode="eager", clip_emb=(0.5 * clip).bfloat16())
+    assert not torch.equal(out0, out)      # the image tokens are really read
+
+
+@pytest.mark.skipif(not rh.available(), reason="/root/reference not present (GPU box)")
 def test_oracle_rope_and_freqs_match_reference():
     mod = rh.load("wan2pt1")
     emb = mod.VideoRopePosition3DEmb(head_dim=128, len_h=128, len_w=128, len_t=32)

@@ -264,7 +264,8 @@ def test_emulated_rank_runs_one_ranks_work_without_communication():
         sp = SeqParallel(EmulatedGroup(r, W), ops=oracle_ops)
         s, e = sp.plan(L)
         assert (s, e) == (r * 256, min(L, (r + 1) * 256)) and sp.capturable
-        assert sp.groups_for(12, 4096) == 2 and sp.groups_for(12, 8192) == 4 and sp.groups_for(40, 9472) == 4 and sp.groups_for(2, 256) == 1
+        assert [sp.groups_for(12, p_) for p_ in (16384, 8192, 4096)] == [4, 2, 2] and sp.groups_for(40, 9472) == 4 and sp.groups_for(2, 256) == 2
+        assert sp.branches_in_parallel(12, 4096, 2) and sp.branches_in_parallel(12, 16384, 4) and not sp.branches_in_parallel(40, 9472, 4)
         L_loc = e - s
         out = torch.zeros(L_loc, H, D, dtype=q.dtype)
         sp.self_attention(q[:, s:e].contiguous(), k[:, s:e].contiguous(), v[:, s:e].contiguous(), (L_loc * D, D), out, D, H * D,

@@ -56,6 +56,7 @@ struct Gemm16P {
 
 #define G_EPI_NONE 0
 #define G_EPI_GELU 1     // GELU-tanh of the (bias-added, rounded) result, as the W8A8 kernels (td_gelu_tanh)
+#define G_EPI_GELU_ERF 3 // exact GELU, nn.GELU() (Wan2.1 I2V's MLPProj on the CLIP tokens, wan2pt1.py:462-466): 0.5 x (1 + erf(x / sqrt 2))
 #define G_EPI_GEGLU 2    // umT5 T5FeedForward (umt5.py:197-214): B's rows are gate / fc1 interleaved in blocks of 32
                          // (rows [64 p, 64 p + 32) = gate columns [32 p, 32 p + 32), rows [64 p + 32, 64 p + 64) = fc1
                          // columns of the same range); D [M, N / 2] = fc1(x) * GELU(gate(x)) with the reference's 16-bit
@@ -75,6 +76,13 @@ template <int DT> __device__ __forceinline__ float g_t5_gelu(float x) {
   const float o = round_half<DT>(1.0f + t);
   const float h = round_half<DT>(0.5f * x);
   return round_half<DT>(h * o);
+}
+
+// one more operator on a value already rounded to the output dtype (after bias): the exact GELU, rounded
+template <int DT> __device__ __forceinline__ uint32_t g_gelu_erf2(uint32_t w) {
+  float x0, x1;
+  unpack2<DT>(w, x0, x1);
+  return pack2<DT>(0.5f * x0 * (1.0f + erff(x0 * 0.7071067811865476f)), 0.5f * x1 * (1.0f + erff(x1 * 0.7071067811865476f)));
 }
 
 template <int IDT> struct g_mma;
@@ -298,6 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const Gemm16P p) {
         }
         pk[j][0] = td_gemm_epilogue2<ODT, EP, HAS_BIAS>(acc[i][j][0], acc[i][j][1], bf[0], bf[1]);
         pk[j][1] = td_gemm_epilogue2<ODT, EP, HAS_BIAS>(acc[i][j][2], acc[i][j][3], bf[2], bf[3]);
+        if constexpr (EPI == G_EPI_GELU_ERF) { pk[j][0] = g_gelu_erf2<ODT>(pk[j][0]); pk[j][1] = g_gelu_erf2<ODT>(pk[j][1]); }
       }
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
@@ -364,6 +373,10 @@ static int dispatch_gemm16(const Gemm16P& p, int out_dtype, int epilogue, int ba
     return hb ? launch_gemm16<IDT, IDT, G_EPI_GELU, true, false>(p, batch, st)
               : launch_gemm16<IDT, IDT, G_EPI_GELU, false, false>(p, batch, st);
   }
+  if (epilogue == G_EPI_GELU_ERF) {
+    return hb ? launch_gemm16<IDT, IDT, G_EPI_GELU_ERF, true, false>(p, batch, st)
+              : launch_gemm16<IDT, IDT, G_EPI_GELU_ERF, false, false>(p, batch, st);
+  }
   if (res) {
     return hb ? launch_gemm16<IDT, IDT, G_EPI_NONE, true, true>(p, batch, st)
               : launch_gemm16<IDT, IDT, G_EPI_NONE, false, true>(p, batch, st);
@@ -382,7 +395,7 @@ extern "C" int td_gemm_bf16(const void* a, const void* b, const void* bias, cons
   TD_REQUIRE(m > 0 && n > 0 && k > 0 && batch > 0 && batch < 65536, TD_ERR_INVALID, "td_gemm_bf16: empty problem or batch >= 65536");
   TD_REQUIRE(k % 64 == 0, TD_ERR_UNSUPPORTED, "td_gemm_bf16: k = %lld must be a multiple of 64 (pad the operands' rows with zeros)", (long long)k);
   TD_REQUIRE(lda >= k && ldb >= k && lda % 8 == 0 && ldb % 8 == 0, TD_ERR_INVALID, "td_gemm_bf16: lda / ldb must be >= k and multiples of 8");
-  TD_REQUIRE(epilogue >= G_EPI_NONE && epilogue <= G_EPI_GEGLU, TD_ERR_INVALID, "td_gemm_bf16: epilogue %d", epilogue);
+  TD_REQUIRE(epilogue >= G_EPI_NONE && epilogue <= G_EPI_GELU_ERF, TD_ERR_INVALID, "td_gemm_bf16: epilogue %d", epilogue);
   const int64_t n_out = epilogue == G_EPI_GEGLU ? n / 2 : n;
   TD_REQUIRE(ldd >= n_out, TD_ERR_INVALID, "td_gemm_bf16: ldd < n");
   TD_REQUIRE(out_dtype == TD_F32 || ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_bf16: 16-bit output rows must start 16-byte aligned (ldd %% 8 == 0)");
@@ -430,6 +443,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       a = round_half<DT>(a);
       if constexpr (HAS_BIAS) a = round_half<DT>(a + half_bits_to_f32<DT>(bias[n]));
       if constexpr (EPI == G_EPI_GELU) a = round_half<DT>(td_gelu_tanh(a));
+      if constexpr (EPI == G_EPI_GELU_ERF) a = round_half<DT>(0.5f * a * (1.0f + erff(a * 0.7071067811865476f)));
       if constexpr (RES) a = a + half_bits_to_f32<DT>(R[m * ldr + n]);
       D[m * ldd + n] = (uint16_t)f32_to_half_bits<DT>(a);
     }
@@ -440,7 +454,7 @@ extern "C" int td_gemm_bf16_splitk_reduce(const float* ws, int splits, const voi
                                           int epilogue, int64_t m, int64_t n, int64_t ldd, int64_t ldr, td_stream_t stream) {
   TD_REQUIRE(ws && d && splits >= 1 && splits <= 64, TD_ERR_INVALID, "td_gemm_bf16_splitk_reduce: null pointer or splits = %d", splits);
   TD_REQUIRE(dtype == TD_BF16 || dtype == TD_F16, TD_ERR_UNSUPPORTED, "td_gemm_bf16_splitk_reduce: dtype %d", dtype);
-  TD_REQUIRE(m > 0 && n > 0 && epilogue >= G_EPI_NONE && epilogue <= G_EPI_GEGLU, TD_ERR_INVALID, "td_gemm_bf16_splitk_reduce: shape / epilogue");
+  TD_REQUIRE(m > 0 && n > 0 && epilogue >= G_EPI_NONE && epilogue <= G_EPI_GELU_ERF, TD_ERR_INVALID, "td_gemm_bf16_splitk_reduce: shape / epilogue");
   TD_REQUIRE(epilogue != G_EPI_GEGLU || (n % 64 == 0 && !bias && !res), TD_ERR_UNSUPPORTED, "td_gemm_bf16_splitk_reduce: gated GELU takes no bias / residual");
   TD_REQUIRE(!res || epilogue == G_EPI_NONE, TD_ERR_UNSUPPORTED, "td_gemm_bf16_splitk_reduce: residual with the plain epilogue only");
   hipStream_t st = (hipStream_t)stream;
@@ -451,6 +465,7 @@ extern "C" int td_gemm_bf16_splitk_reduce(const float* ws, int splits, const voi
 #define TD_SKR_DT(DT_)                                                                             \
   if (epilogue == G_EPI_GEGLU) TD_SKR(DT_, G_EPI_GEGLU, false, false);                             \
   else if (epilogue == G_EPI_GELU) { if (bias) TD_SKR(DT_, G_EPI_GELU, true, false); else TD_SKR(DT_, G_EPI_GELU, false, false); } \
+  else if (epilogue == G_EPI_GELU_ERF) { if (bias) TD_SKR(DT_, G_EPI_GELU_ERF, true, false); else TD_SKR(DT_, G_EPI_GELU_ERF, false, false); } \
   else if (res) { if (bias) TD_SKR(DT_, G_EPI_NONE, true, true); else TD_SKR(DT_, G_EPI_NONE, false, true); }                      \
   else { if (bias) TD_SKR(DT_, G_EPI_NONE, true, false); else TD_SKR(DT_, G_EPI_NONE, false, false); }
   if (dtype == TD_BF16) { TD_SKR_DT(TD_BF16) } else { TD_SKR_DT(TD_F16) }

@@ -858,7 +858,7 @@ def vae_chan_rms(x, gamma, silu=True):
 
 
 # ----------------------------------------------------------------------------- 16-bit GEMM / softmax / T5 norm (gemm_bf16.hip)
-GEMM16_EPI = {"none": 0, "gelu_tanh": 1, "geglu": 2}
+GEMM16_EPI = {"none": 0, "gelu_tanh": 1, "geglu": 2, "gelu_erf": 3}
 
 
 def _unit_inner(t):

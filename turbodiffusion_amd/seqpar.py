@@ -160,14 +160,22 @@ class SeqParallel:
             self.parallel_groups = os.environ["TD_SP_PARALLEL_GROUPS"] != "0"
 
     def groups_for(self, H, per):
-        """Head groups of the K-side exchange for a rank with ``per`` tokens: every group's attention launch is H/G heads x
-        per/128 Q blocks workgroups, and a launch under ~200 workgroups leaves most of the 256 CUs idle for the length of
-        one workgroup's serial walk over its keys (measured by rank emulation, round 4: 1.3B / 480p over 8 ranks = 384
-        workgroups in total — 22.3 / 23.2 / 26.7 ms per DiT step with 1 / 2 / 4 groups; the exchange that the groups hide is
-        5.0 ms).  TD_SP_HEAD_GROUPS overrides (``head_groups`` set explicitly)."""
+        """Head groups of the K-side exchange for a rank with ``per`` tokens.  More groups hide more of the exchange behind
+        attention (only the first group's transfer is exposed) but cut the attention / block-map / linear-branch launches into
+        H/G heads x per/128 Q blocks workgroups each, and a launch far below the chip's ~768 resident workgroups takes as long
+        as one workgroup's serial walk over its keys whatever its size.  Read off the rank-emulation sweep of round 4
+        (profiles/r04_emu_group_sweep.txt; compute + exposed wire per DiT step): 1.3B / 480p over 2 / 4 / 8 ranks is best with
+        4 / 2 / 2 groups (60.7 / 37.1 / 25.3 ms), A14B / 720p over 8 with 4 (240.7 ms) — at least two groups (half of the
+        exchange hidden always pays), about one group per 384 workgroups of attention.  TD_SP_HEAD_GROUPS overrides."""
         if self._groups_forced:
             return self.head_groups
-        return max(1, min(self.head_groups, (H * (per // 128)) // 192))
+        return max(1, min(self.head_groups, max(2, (H * (per // 128)) // 384)))
+
+    def branches_in_parallel(self, H, per, G):
+        """The groups' kernels as parallel graph branches only while one group's launch under-fills the chip (< 512 workgroups):
+        1.3B over 8 ranks 28.5 vs 31.1 ms with 4 groups; A14B over 8 ranks (740 workgroups per group) 243 vs 228 ms — full-size
+        launches beside each other only thrash the caches (same sweep)."""
+        return self.parallel_groups and G > 1 and (H // G) * (per // 128) < 512
 
     # ------------------------------------------------------------------ token sharding
     def plan(self, L: int):
@@ -288,7 +296,7 @@ class SeqParallel:
         topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
         from . import graph as _graph
         # parallel branches need real streams and no segmented capture in progress (a segment cannot end with forked streams)
-        par = self.parallel_groups and q.is_cuda and lay.G > 1 and _graph._ACTIVE is None
+        par = q.is_cuda and _graph._ACTIVE is None and self.branches_in_parallel(H, per, lay.G)
         main = torch.cuda.current_stream() if par else None
         joins = []
         if par:

@@ -61,7 +61,7 @@ def _linear(in_f, out_f, quant, dtype):
 
 
 class WanSelfAttention(nn.Module):
-    def __init__(self, dim, num_heads, eps, quant, dtype, attention_type=None, sla_topk=0.1):
+    def __init__(self, dim, num_heads, eps, quant, dtype, attention_type=None, sla_topk=0.1, image_branch=False):
         super().__init__()
         self.dim, self.num_heads, self.head_dim, self.eps = dim, num_heads, dim // num_heads, eps
         self.q = _linear(dim, dim, quant, dtype)
@@ -76,15 +76,30 @@ class WanSelfAttention(nn.Module):
         elif attention_type == "sagesla":
             local = SageSparseLinearAttention(self.head_dim, sla_topk)
         self.attn_op = AttnOp(local)
+        if image_branch:   # WanI2VCrossAttention (wan2pt1.py:303-313): a second K / V pair for the CLIP image tokens
+            self.k_img = _linear(dim, dim, quant, dtype)
+            self.v_img = _linear(dim, dim, quant, dtype)
+            self.norm_k_img = FastRMSNorm(dim, eps=eps)
+            self.attn_op_image = AttnOp(None)
+
+
+class MLPProj(nn.Module):
+    """wan2pt1.py:457-486 (without the first-last-frame position table): LayerNorm, Linear, exact GELU, Linear, LayerNorm on the
+    CLIP image tokens; state-dict keys ``img_emb.proj.{0,1,3,4}.*``."""
+
+    def __init__(self, in_dim, out_dim, dtype):
+        super().__init__()
+        self.proj = nn.Sequential(nn.LayerNorm(in_dim, dtype=dtype), nn.Linear(in_dim, in_dim, dtype=dtype), nn.GELU(),
+                                  nn.Linear(in_dim, out_dim, dtype=dtype), nn.LayerNorm(out_dim, dtype=dtype))
 
 
 class WanAttentionBlock(nn.Module):
-    def __init__(self, dim, ffn_dim, num_heads, cross_attn_norm, eps, quant, dtype, attention_type, sla_topk):
+    def __init__(self, dim, ffn_dim, num_heads, cross_attn_norm, eps, quant, dtype, attention_type, sla_topk, image_branch=False):
         super().__init__()
         self.norm1 = FastLayerNorm(dim, eps)
         self.self_attn = WanSelfAttention(dim, num_heads, eps, quant, dtype, attention_type, sla_topk)
         self.norm3 = FastLayerNorm(dim, eps, elementwise_affine=True) if cross_attn_norm else nn.Identity()
-        self.cross_attn = WanSelfAttention(dim, num_heads, eps, quant, dtype)
+        self.cross_attn = WanSelfAttention(dim, num_heads, eps, quant, dtype, image_branch=image_branch)
         self.norm2 = FastLayerNorm(dim, eps)
         self.ffn = nn.Sequential(_linear(dim, ffn_dim, quant, dtype), nn.GELU(approximate="tanh"),
                                  _linear(ffn_dim, dim, quant, dtype))
@@ -128,7 +143,7 @@ class WanModel(nn.Module):
     def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
                  freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, qk_norm=True,
                  cross_attn_norm=True, eps=1e-6, attention_type="sagesla", sla_topk=0.1, quant_linear=True,
-                 dtype=torch.bfloat16, default_norm=None, **_unused):
+                 dtype=torch.bfloat16, default_norm=None, clip_dim=None, **_unused):
         super().__init__()
         assert model_type in ("t2v", "i2v") and qk_norm
         assert attention_type in ATTENTION_TYPES
@@ -154,8 +169,14 @@ class WanModel(nn.Module):
         self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6, dtype=dtype))
         self.blocks = nn.ModuleList([
             WanAttentionBlock(dim, ffn_dim, num_heads, cross_attn_norm, eps, quant_linear, dtype, attention_type,
-                              sla_topk) for _ in range(num_layers)])
+                              sla_topk, image_branch=bool(clip_dim)) for _ in range(num_layers)])
         self.head = Head(dim, out_dim, patch_size, eps, dtype)
+        # Wan2.1 I2V (rcm/networks/wan2pt1.py with model_type "i2v": :575, :590-591): CLIP image tokens [B, 257, clip_dim = 1280]
+        # arrive as ``frame_cond_crossattn_emb_B_L_D``, go through ``img_emb`` and are attended by a second K / V pair of
+        # every block's cross-attention.  Wan2.2-A14B I2V (wan2pt2.py) has no such branch: clip_dim = None.
+        self.clip_dim = clip_dim
+        if clip_dim:
+            self.img_emb = MLPProj(clip_dim, dim, dtype)
         self._fused = {}
         self._rope_cache = {}
         self.seq_parallel = None  # set by turbodiffusion_amd.seqpar.enable(...)
@@ -521,8 +542,33 @@ class WanModel(nn.Module):
         self._text_states[key[0]] = (key, crossattn_emb, context, per_b, gen)
         return self._text_states[key[0]]
 
-    def _cross_attention(self, i, blk, xn, context, quant_out=False, text_kv=None, kvt=None):
-        """xn [L, dim] (norm3 output), context [Lc, dim] -> [L, dim] (before the o projection)."""
+    def _img_mlp(self, clip_tokens):
+        """``img_emb`` (MLPProj, wan2pt1.py:457-486) on the CLIP tokens [B, 257, clip_dim]: the two LayerNorms on td_layernorm
+        (fp32 statistics, one rounding, eps 1e-5 — nn.LayerNorm's), the Linears on td_gemm_bf16 with the exact GELU in the
+        first one's epilogue."""
+        pj = self.img_emb.proj
+        B, n, c = clip_tokens.shape
+        x = clip_tokens.to(self.dtype).reshape(B * n, c).contiguous()
+        x = K.layernorm(x, pj[0].weight.float().contiguous(), pj[0].bias.float().contiguous(), pj[0].eps)
+        x = K.gemm_bf16(x, pj[1].weight.detach(), pj[1].bias.detach(), epilogue="gelu_erf")
+        x = K.gemm_bf16(x, pj[3].weight.detach(), pj[3].bias.detach())
+        x = K.layernorm(x, pj[4].weight.float().contiguous(), pj[4].bias.float().contiguous(), pj[4].eps)
+        return x.view(B, n, self.dim)
+
+    def _img_kvt(self, blk, img_ctx):
+        """K (RMSNorm'ed, head-major) and V^T tiles of a block's image branch for one batch entry's CLIP context [257, dim]
+        (wan2pt1.py:343-344)."""
+        ca = blk.cross_attn
+        H, D, dim = self.num_heads, 128, self.dim
+        kk = self._lin(ca.k_img, img_ctx)
+        vv = self._lin(ca.v_img, img_ctx)
+        k = K.qk_norm_rope(kk, 0, H, D, ca.norm_k_img.weight, None, None, self.eps)
+        vt = K.v_transpose(vv, D, vv.stride(0), img_ctx.shape[0], H, D, img_ctx.dtype)
+        return k, vt
+
+    def _cross_attention(self, i, blk, xn, context, quant_out=False, text_kv=None, kvt=None, img_ctx=None):
+        """xn [L, dim] (norm3 output), context [Lc, dim] -> [L, dim] (before the o projection).  img_ctx [257, dim]: Wan2.1
+        I2V's image branch — the same queries against the CLIP tokens' K / V, the two results added (wan2pt1.py:345-351)."""
         ca = blk.cross_attn
         H, D, dim = self.num_heads, 128, self.dim
         L_ = xn[0].shape[0] if isinstance(xn, tuple) else xn.shape[0]
@@ -540,9 +586,21 @@ class WanModel(nn.Module):
             # (one statistics pass over q instead of td_qk_norm_rope's read + write; bit-identical)
             if rstd is None:
                 rstd = K.rms_stats(qc, dim, self.eps)
-            return K.attn_16_qnorm(qc, rstd, ca.norm_q.weight, k, vt, None, out, D, dim, quant_out=quant_out)
+            res = K.attn_16_qnorm(qc, rstd, ca.norm_q.weight, k, vt, None, out, D, dim, quant_out=quant_out)
+            if img_ctx is not None:
+                ki, vti = self._img_kvt(blk, img_ctx)
+                oi = torch.empty_like(res)
+                K.attn_16_qnorm(qc, rstd, ca.norm_q.weight, ki, vti, None, oi, D, dim)
+                K.gated_residual_(res, oi, None)          # x = x + img_x in the activation dtype (wan2pt1.py:350)
+            return res
         q = K.qk_norm_rope(qc, 0, H, D, ca.norm_q.weight, None, None, self.eps)
-        return K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
+        res = K.attn_16(q, k, vt, None, out, D, dim, quant_out=quant_out)
+        if img_ctx is not None:
+            ki, vti = self._img_kvt(blk, img_ctx)
+            oi = torch.empty_like(res)
+            K.attn_16(q, ki, vti, None, oi, D, dim)
+            K.gated_residual_(res, oi, None)
+        return res
 
     @property
     def _ln_pad(self):
@@ -601,7 +659,7 @@ class WanModel(nn.Module):
         main.wait_event(e_join)
         return K.row_stats_finalize(ws, dim, self.eps, pad_cols=self._ln_pad)
 
-    def _block(self, i, blk, x, e_B_6_D, cos, sin, context, tkv=None, kvts=None):
+    def _block(self, i, blk, x, e_B_6_D, cos, sin, context, tkv=None, kvts=None, img_ctx=None):
         """x: [B, L_loc, dim] (updated in place); e fp32 [B, 6, dim] = this block's modulation + e0 (wan2pt1.py:400,
         formed for all blocks at once in forward); context [B, Lc, dim]."""
         B, L_loc, dim = x.shape
@@ -628,7 +686,7 @@ class WanModel(nn.Module):
         ys = [self._self_attention(i, blk, hb, cos, sin, L_loc, dt, quant_out=qo) for hb in hs_]
         y = ys[0] if B == 1 else torch.cat(ys, 0)
         ms = self._split_rows(L_loc) if (fstats and qo and isinstance(blk.norm3, FastLayerNorm) and isinstance(y, tuple)
-                                         and isinstance(blk.ffn[0], Int8Linear)) else 0
+                                         and isinstance(blk.ffn[0], Int8Linear) and img_ctx is None) else 0
         if ms:
             self._carry_stats = self._tail_two_halves(i, blk, x2, y, ec, context[0], None if kvts is None else kvts[0][i], ms,
                                                       None if tkv is None else tkv[0])
@@ -644,9 +702,10 @@ class WanModel(nn.Module):
                 xns = [xn[r] for r in rows]
         else:
             xns = [x2[r] for r in rows]
-        cs = [self._cross_attention(i, blk, xns[b], context[b], quant_out=self.quant_linear and B == 1,
+        cs = [self._cross_attention(i, blk, xns[b], context[b], quant_out=self.quant_linear and B == 1 and img_ctx is None,
                                     text_kv=None if tkv is None else tkv[b],
-                                    kvt=None if kvts is None else kvts[b][i]) for b in range(B)]
+                                    kvt=None if kvts is None else kvts[b][i],
+                                    img_ctx=None if img_ctx is None else img_ctx[b]) for b in range(B)]
         c = cs[0] if B == 1 else torch.cat(cs, 0)
         st2 = self._residual_lin_(x2, blk.cross_attn.o, c, None, stats=fstats)
         # ---- FFN ----
@@ -672,9 +731,9 @@ class WanModel(nn.Module):
         return_tokens = bool(kwargs.pop("_return_tokens", False))   # parity tests: the [B, L, dim] tokens after the blocks
         del kwargs
         K.require_gpu(x_B_C_T_H_W)
-        if frame_cond_crossattn_emb_B_L_D is not None:
-            raise NotImplementedError("CLIP image-context branch (Wan2.1 I2V) is outside the hot path; "
-                                      "Wan2.2-A14B I2V conditions through y_B_C_T_H_W only")
+        if (frame_cond_crossattn_emb_B_L_D is not None) != bool(self.clip_dim):
+            raise ValueError("frame_cond_crossattn_emb_B_L_D (CLIP image tokens) goes with a model built with clip_dim (Wan2.1 I2V, "
+                             "wan2pt1.py:642); Wan2.2-A14B I2V conditions through y_B_C_T_H_W only")
         assert timesteps_B_T.shape[1] == 1
         if self.seq_parallel is not None and getattr(self.seq_parallel, "broadcast_inputs", False):
             x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W = self.seq_parallel.broadcast(
@@ -745,9 +804,15 @@ class WanModel(nn.Module):
         else:
             e_all = mods[0] + e0.unsqueeze(0)                    # fp32 [nblk, B, 6, dim]
         self._carry_stats = None
+        img_ctx = None
+        if frame_cond_crossattn_emb_B_L_D is not None:
+            if sp is not None:
+                frame_cond_crossattn_emb_B_L_D = sp.broadcast(frame_cond_crossattn_emb_B_L_D)[0] if getattr(sp, "broadcast_inputs", False) \
+                    else frame_cond_crossattn_emb_B_L_D
+            img_ctx = self._img_mlp(frame_cond_crossattn_emb_B_L_D)      # [B, 257, dim]
         tap = getattr(self, "_tap_tokens", None)   # tools/drift.py: list that receives the tokens after every block
         for i, blk in enumerate(self.blocks):
-            x = self._block(i, blk, x, e_all[i], cos, sin, context, tkv, kvts)
+            x = self._block(i, blk, x, e_all[i], cos, sin, context, tkv, kvts, img_ctx)
             if tap is not None:
                 tap.append(x.clone())
         if return_tokens:
