@@ -216,13 +216,15 @@ def _gemm_ref(a, w, bias=None, res=None, epilogue="none"):
         y = (y + bias.float().cpu()).to(dt).float()
     if epilogue == "gelu_tanh":
         y = F.gelu(y, approximate="tanh").to(dt).float()
+    if epilogue == "gelu_erf":
+        y = F.gelu(y).to(dt).float()
     if res is not None:
         y = (y + res.float().cpu()).to(dt).float()
     return y
 
 
 @pytest.mark.parametrize("case", ["plain", "bias", "bias+gelu", "res", "geglu", "f32 out", "ragged", "k pad", "strided", "f16",
-                                  "splitk bias+gelu", "splitk res", "splitk geglu"])
+                                  "splitk bias+gelu", "splitk res", "splitk geglu", "bias+gelu_erf", "splitk bias+gelu_erf"])
 def test_gemm_bf16_vs_fp32_matmul(K, case):
     """td_gemm_bf16 (256x256-tile 16-bit GEMM on v_mfma_f32_16x16x32) against an fp32 matmul of the same 16-bit operands
     with the operator sequence's rounding points: within one 16-bit step, most outputs equal."""
@@ -240,9 +242,10 @@ def test_gemm_bf16_vs_fp32_matmul(K, case):
         assert K._splitk(m, n, k) == 4
     a = torch.randn(m, k, generator=g).to(dt)
     w = (torch.randn(n, k, generator=g) / k ** 0.5).to(dt)
-    bias = (0.3 * torch.randn(n, generator=g)).to(dt) if case in ("bias", "bias+gelu", "f32 out", "ragged", "f16", "splitk bias+gelu", "splitk res") else None
+    bias = (0.3 * torch.randn(n, generator=g)).to(dt) if ("bias" in case or case in ("f32 out", "ragged", "f16", "splitk res")) else None
     res = torch.randn(m, n, generator=g).to(dt) if case in ("res", "splitk res") else None
-    epi = {"bias+gelu": "gelu_tanh", "geglu": "geglu", "splitk bias+gelu": "gelu_tanh", "splitk geglu": "geglu"}.get(case, "none")
+    epi = {"bias+gelu": "gelu_tanh", "geglu": "geglu", "splitk bias+gelu": "gelu_tanh", "splitk geglu": "geglu",
+           "bias+gelu_erf": "gelu_erf", "splitk bias+gelu_erf": "gelu_erf"}.get(case, "none")
     if epi == "geglu":
         gate, fc1 = w[: n // 2], w[n // 2:]
         wi = K.geglu_interleave(gate.to(DEV), fc1.to(DEV))
@@ -272,7 +275,7 @@ def test_gemm_bf16_vs_fp32_matmul(K, case):
     mag = ref.abs()
     if res is not None:
         mag = torch.maximum(mag, (ref - res.float()).abs())
-    steps = {"none": 1, "gelu_tanh": 2, "geglu": 4}[epi]
+    steps = {"none": 1, "gelu_tanh": 2, "gelu_erf": 2, "geglu": 4}[epi]
     bad = err > mag * step * steps + 1e-3
     if bad.any():
         i, j = (int(v) for v in bad.nonzero()[0])
