@@ -154,6 +154,49 @@ def pmc_meta():
             "traffic_stale": (dig != kernel_source_digest()) if dig else None}
 
 
+def collect_traffic(argv_model):
+    """--collect-traffic: the HBM-side bytes per launch of the GEMM / attention kernels, collected IN THIS RUN (after the timed
+    region): two child processes under ``rocprofv3 --pmc`` (FETCH_SIZE and WRITE_SIZE need separate passes: TCC counter slots,
+    MI355X_MICROARCH.md) run ONE eager DiT forward of the same model (full-size launches: token split off), and the
+    counter_collection.csv files are reduced exactly as tools/pmc_traffic.py reduces them.  ~40 s per pass.  Opt-in: the
+    default line reads the committed summary and says whether it is stale (``traffic_stale``)."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_traffic as PT
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    out = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as td:
+        for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            d = os.path.join(td, name)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "b", "--output-format", "csv", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--num-steps", "1", "--no-graph", "--no-cpu-baseline",
+                   "--no-box-calibration"] + argv_model
+            env = dict(os.environ, TD_BENCH_MODEL_FLAGS="split_tokens=0", TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            csvs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not csvs:
+                return None, f"rocprofv3 pass {name} failed (exit {r.returncode}): {r.stderr[-300:]}"
+            out[name] = PT.load(csvs[0], ctr)
+    res = {}
+    for k in set(out["fetch"]) | set(out["write"]):
+        f, w = out["fetch"].get(k, []), out["write"].get(k, [])
+        res[k] = {"launches": max(len(f), len(w)), "fetch_bytes_per_launch": 2.0 * 1024.0 * sum(f) / max(1, len(f)),
+                  "write_bytes_per_launch": 1024.0 * sum(w) / max(1, len(w))}
+    return res, None
+
+
+def traffic_of(kernels, prefixes):
+    n = b = 0.0
+    for name, v in kernels.items():
+        if any(name.startswith(p) for p in prefixes):
+            n += v["launches"]
+            b += v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+    return (b / n) if n else None
+
+
 def cpu_baseline(cfg, lat_shape, topk, reps=3):
     """The reference's ORIGINAL eager path (config C1: SDPA, plain Linear, eager norms) timed on the host cores on a bounded
     sample of the same workload: the embeddings once (a forward with 0 blocks) and ONE block of ONE DiT step at the full
@@ -266,6 +309,9 @@ def main():
                     "split (its token shard, its launches, gathered buffers of the real size filled with copies of its own shard, "
                     "no communication) and report the measured per-rank time beside a modelled wire term (`emulated_rank`); "
                     "a measurement tool for DESIGN.md §6 — the line is marked and carries no vs_baseline")
+    ap.add_argument("--collect-traffic", action="store_true", help="N = 1: collect `roofline.traffic` / `roofline_attention.traffic` in "
+                    "THIS run (two rocprofv3 --pmc child passes over one eager DiT forward after the timed region, ~40 s each) "
+                    "instead of reading the committed counter summary")
     ap.add_argument("--no-replica-leg", action="store_true", help="N > 1: skip the throughput-mode measurement (N "
                     "independent videos) that follows the timed region")
     ap.add_argument("--prompt-to-pixels", action="store_true", help="N = 1: after the timed region also time the user-visible "
@@ -602,6 +648,19 @@ def main():
         replicas = {"videos_per_s": world * args.steps / tt3.item(), "ms_per_video_per_gpu": tt3.item() / args.steps * 1e3,
                     "mode": f"{world} independent videos, one per GPU, hipGraph replay, no data-path collective"}
 
+    live_traffic, live_err = None, None
+    if rank == 0 and world == 1 and args.collect_traffic and emu is None:
+        argv_model = ["--workload", args.workload, "--model", args.model, "--res", args.res, "--topk", str(args.topk), "--sage-pv", args.sage_pv]
+        if args.two_experts:
+            argv_model.append("--two-experts")
+        if args.layers:
+            argv_model += ["--layers", str(args.layers)]
+        phase("collecting HBM traffic counters (two rocprofv3 --pmc passes over one eager forward)")
+        try:
+            live_traffic, live_err = collect_traffic(argv_model)
+        except Exception as e:   # an extra: never fatal
+            live_err = repr(e)
+        phase("traffic counters " + ("collected" if live_traffic else f"NOT collected: {live_err}"))
     if rank == 0:
         per_video = elapsed / args.steps   # per sequence-parallel group
         value = dp / per_video             # whole job: dp groups generate dp videos per step
@@ -656,6 +715,20 @@ def main():
                 roof_attn["hbm_GBps"] = roof_attn["traffic"] / t_l / 1e9
                 roof_attn["hbm_frac"] = roof_attn["traffic"] / t_l / HBM_PEAK
                 roof_attn.update(pmc_meta())
+        if live_traffic is not None:     # counters of THIS run replace the committed summary's
+            for r_, pre in ((roof, ("gemm_w8a8_",)), (roof_attn, ("attn_kernel<true",))):
+                tv = traffic_of(live_traffic, pre) if r_ is not None else None
+                if tv is not None:
+                    r_["traffic"] = tv
+                    r_["traffic_source"] = "collected in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over one eager DiT forward after the timed region"
+                    for k_ in ("traffic_file", "traffic_commit"):
+                        r_.pop(k_, None)
+                    r_["traffic_stale"] = False
+                    if r_ is roof_attn:
+                        r_["hbm_GBps"] = tv / (r_["avg_launch_ms"] * 1e-3) / 1e9
+                        r_["hbm_frac"] = tv / (r_["avg_launch_ms"] * 1e-3) / HBM_PEAK
+        elif live_err is not None and roof is not None:
+            roof["traffic_collect_error"] = live_err
         if roof is None:
             roof = roof_attn
         res = {

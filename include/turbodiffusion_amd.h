@@ -156,6 +156,13 @@ int td_gemv_f32(const float* x, const void* w, const void* bias, int dtype, int 
 int td_bcast_add(const float* m, const float* e, float* out, int64_t A, int64_t B, int64_t R, int64_t RE, int64_t D,
                  td_stream_t stream);
 
+/* a18: one update of the few-step rCM sampler on the fp64 state (inference/wan2.1_t2v_infer.py:134-139; the ODE form
+ * wan2.2_i2v_infer.py:202-203 when eps == NULL), the reference's fp64 operator sequence operation for operation, fused with
+ * the cast of the next step's network input: x f64 [n] in place; v f32 [n] (the network's velocity); eps f32 [n] N(0,1) or
+ * NULL; x16 (optional) 16-bit [n] = x.to(dtype16) as torch casts a double (through float). */
+int td_rcm_step(double* x, const float* v, const float* eps, void* x16, int dtype16, double t_cur, double t_next, int64_t n,
+                td_stream_t stream);
+
 /* measurement support (csrc/calib.hip; bench.py's "box" calibration — no reference counterpart: the reference ships no
  * benchmark code).  td_calib_mfma_i8: blocks x 256 threads, every wave issues iters x 4 v_mfma_i32_32x32x32_i8 (2*32^3 ops
  * each); td_calib_hbm_read: one streaming pass of 16-byte non-temporal loads over src[0, bytes); td_calib_clock_probe: one

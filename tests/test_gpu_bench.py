@@ -87,3 +87,19 @@ def test_bench_emulated_rank_reports_compute_and_wire_terms():
     assert e["rank"] == 7 and e["of"] == 8 and e["tokens_per_rank_padded"] == 4096 and e["tokens_of_rank"] == 32760 - 7 * 4096
     assert e["measured_compute_ms_per_dit_step"] > 0 and e["pack_bytes_per_layer"] > 4096 * 1536 * 3
     assert "one hipGraph" in r["launch_mode"], r["launch_mode"]
+
+
+def test_bench_collects_its_traffic_counters_in_the_run():
+    """--collect-traffic: `roofline.traffic` from two rocprofv3 --pmc child passes of THIS run instead of the committed summary."""
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        pytest.skip("rocprofv3 not on PATH")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--layers", "2",
+                          "--no-cpu-baseline", "--no-box-calibration", "--collect-traffic"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    roof, ra = r["roofline"], r["roofline_attention"]
+    assert "collected in this run" in roof.get("traffic_source", ""), (roof.get("traffic_collect_error"), out.stderr[-1500:])
+    assert roof["traffic_stale"] is False and roof["traffic"] > roof["algorithmic_bytes"] * 0.5
+    assert ra["traffic"] > 0 and 0 < ra["hbm_frac"] < 1

@@ -39,6 +39,7 @@ SIGNATURES = {
     "td_t5_norm": [_vp, _vp, _vp, _i32, _f32, _i64, _i64, _i64, _i64, _vp],
     "td_gemv_f32": [_vp, _vp, _vp, _i32, _i32, _vp, _i64, _i64, _i64, _vp],
     "td_bcast_add": [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _vp],
+    "td_rcm_step": [_vp, _vp, _vp, _vp, _i32, ctypes.c_double, ctypes.c_double, _i64, _vp],
     "td_calib_mfma_i8": [_i32, _i32, _vp, _vp],
     "td_calib_hbm_read": [_vp, _i64, _vp, _vp],
     "td_calib_clock_probe": [_i64, _vp, _vp],

@@ -9,6 +9,7 @@
 // Both are small next to the blocks (< 0.3 % of a step); they exist so that a captured forward contains no library kernel.
 // Patch size (1, 2, 2) only (every Wan model, modify_model.py:86-127).
 #include "td_common.h"
+#include <algorithm>
 
 // ------------------------------------------------------------------------------------------------------------------
 // patch embedding: Y[l, n] = cast(sum_f X[l, f] W[n, f] + bias[n]), fp32 accumulate on v_mfma_f32_32x32x16_{bf16,f16},
@@ -424,6 +425,48 @@ extern "C" int td_bcast_add(const float* m, const float* e, float* out, int64_t 
   TD_REQUIRE(m && e && out && A > 0 && B > 0 && R > 0 && D > 0 && (RE == R || RE == 1), TD_ERR_INVALID, "td_bcast_add: bad argument");
   const int64_t total = A * B * R * D;
   bcast_add_kernel<<<(unsigned)td_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(m, e, out, (int)A, (int)B, (int)R, (int)RE, (int)D);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// a18: one sampler update of the few-step rCM loop (inference/wan2.1_t2v_infer.py:134-139; ODE form wan2.2_i2v_infer.py:202-203)
+// on the fp64 state, fused with the cast of the next step's network input:
+//   SDE: x <- (1 - t_next) * (x - t_cur * double(v)) + double(float(t_next) * eps)   ODE (eps == NULL): x <- x - (t_cur - t_next) * double(v)
+// the reference's operator sequence in fp64, operation for operation (no contraction: -ffp-contract=off), so the state is
+// the bits torch's elementwise chain produces; x16 (optional) = x cast to the model's 16-bit dtype the way torch's
+// `.to(dtype)` casts a double: through float (c10's BFloat16 / Half construct from float), i.e. two roundings.
+// ---------------------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(256) void rcm_step_kernel(double* __restrict__ x, const float* __restrict__ v, const float* __restrict__ eps,
+                                                       uint16_t* __restrict__ x16, double t_cur, double t_next, int64_t n) {
+  const double one_m = 1.0 - t_next, dt = t_cur - t_next;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double vv = (double)v[i];
+    double xn;
+    if (eps != nullptr) {
+      const double a = x[i] - t_cur * vv;
+      // `t_next * randn(dtype=float32)` is an fp32 product in the reference (a 0-dim fp64 tensor / Python float does not
+      // promote an fp32 tensor): rounded to fp32 first, then added in fp64
+      xn = one_m * a + (double)((float)t_next * eps[i]);
+    } else {
+      xn = x[i] - dt * vv;
+    }
+    x[i] = xn;
+    if (x16 != nullptr) {
+      x16[i] = (uint16_t)f32_to_half_bits<DT>((float)xn);
+    }
+  }
+}
+
+extern "C" int td_rcm_step(double* x, const float* v, const float* eps, void* x16, int dtype16, double t_cur, double t_next,
+                           int64_t n, td_stream_t stream) {
+  TD_REQUIRE(x && v && n > 0, TD_ERR_INVALID, "td_rcm_step: null pointer or empty state");
+  TD_REQUIRE(!x16 || dtype16 == TD_BF16 || dtype16 == TD_F16, TD_ERR_UNSUPPORTED, "td_rcm_step: 16-bit dtype %d", dtype16);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)std::min<int64_t>(td_cdiv(n, 256), 2048);
+  if (dtype16 == TD_F16) rcm_step_kernel<TD_F16><<<grid, 256, 0, st>>>(x, v, eps, (uint16_t*)x16, t_cur, t_next, n);
+  else rcm_step_kernel<TD_BF16><<<grid, 256, 0, st>>>(x, v, eps, (uint16_t*)x16, t_cur, t_next, n);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }

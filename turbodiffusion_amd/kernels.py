@@ -153,6 +153,19 @@ def bcast_add(m, e):
     return out
 
 
+def rcm_step_(x, v, eps, t_cur, t_next, dtype16=None):
+    """In place on the fp64 state x: the SDE update (1 - t_next) (x - t_cur v) + t_next eps, or the ODE update x - (t_cur -
+    t_next) v when eps is None; returns x cast to ``dtype16`` (the next step's network input) when asked, from the same pass."""
+    require_gpu(x, v, eps)
+    assert x.dtype == torch.float64 and v.dtype == torch.float32 and x.is_contiguous() and v.is_contiguous() and v.numel() == x.numel()
+    if eps is not None:
+        assert eps.dtype == torch.float32 and eps.is_contiguous() and eps.numel() == x.numel()
+    x16 = torch.empty(x.shape, dtype=dtype16, device=x.device) if dtype16 is not None else None
+    call("td_rcm_step", ptr(x), ptr(v), ptr(eps), ptr(x16), 0 if dtype16 is None else L.dt_code(dtype16), float(t_cur), float(t_next),
+         x.numel(), stream_ptr())
+    return x16
+
+
 # ----------------------------------------------------------------------------- measurement support (csrc/calib.hip)
 def box_calibration(gemm_fn=None, device=None):
     """What this box sustains right now (bench.py's "box" record): the dense INT8 matrix-pipe rate, the streaming HBM read

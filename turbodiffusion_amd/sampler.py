@@ -35,12 +35,16 @@ def rcm_sample_iter(net: Callable, init_noise: torch.Tensor, crossattn_emb: torc
                     net_low: Optional[Callable] = None, boundary: float = 0.9, ode: bool = False,
                     dtype=torch.bfloat16):
     """The loop of ``rcm_sample`` as a generator: yields (step index, fp64 latent) after every sampler step, so that a
-    caller can interleave several videos from ONE host thread (each resumed under its own stream).  Arguments as there."""
+    caller can interleave several videos from ONE host thread (each resumed under its own stream).  Arguments as there.
+    The yielded tensor is the sampler's STATE buffer, updated in place by the next step: clone it to keep it."""
+    from . import kernels as K
+    K.require_gpu(init_noise)                                 # (the CPU statement of this loop is oracle/wan_ref.rcm_sample)
     dev = init_noise.device
     t_host = rcm_timesteps(num_steps, sigma_max)             # fp64, host: no device sync anywhere in the loop
     t_steps = t_host.tolist()
     with torch.no_grad():
-        x = init_noise.to(torch.float64) * t_steps[0]
+        x = (init_noise.to(torch.float64) * t_steps[0]).contiguous()
+        x16 = x.to(dtype)
     kw = {} if y is None else {"y_B_C_T_H_W": y.to(dtype)}
     switched = False
     for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
@@ -49,15 +53,14 @@ def rcm_sample_iter(net: Callable, init_noise: torch.Tensor, crossattn_emb: torc
             model = net_low if switched else net
             # (t_cur.float() * ones * 1000).to(dtype): the fp32 rounding of t_cur, times 1000 in fp64, cast  (:199)
             t_in = torch.full((x.size(0), 1), float(t_host[i].float()) * 1000.0, dtype=torch.float64, device=dev).to(dtype)
-            v = model(x_B_C_T_H_W=x.to(dtype), timesteps_B_T=t_in, crossattn_emb=crossattn_emb, **kw).to(torch.float64)
-            if ode:
-                x = x - (t_cur - t_next) * v
-            else:
-                if noises is not None:
-                    eps = noises[i].to(dev)
-                else:
-                    eps = torch.randn(*x.shape, dtype=torch.float32, device=dev, generator=generator)
-                x = (1 - t_next) * (x - t_cur * v) + t_next * eps
+            v = model(x_B_C_T_H_W=x16, timesteps_B_T=t_in, crossattn_emb=crossattn_emb, **kw).float().contiguous()
+            eps = None
+            if not ode:
+                eps = noises[i].to(dev).float().contiguous() if noises is not None else \
+                    torch.randn(*x.shape, dtype=torch.float32, device=dev, generator=generator)
+            # the update AND the next step's 16-bit network input in one pass over the state (td_rcm_step): the reference's
+            # fp64 operator sequence operation for operation, its fp32 `t_next * randn` product included
+            x16 = K.rcm_step_(x, v, eps, t_cur, t_next, dtype16=dtype)
         yield i, x
 
 
