@@ -353,6 +353,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        # a multi-rank run that stops making progress (a collective whose peer died, a graph replay that never returns) must
+        # END with a message and a non-zero status, not sit until someone's outer timeout: every rank arms a hard limit
+        import threading
+        limit = float(os.environ.get("TD_BENCH_HARD_TIMEOUT_S", "900"))
+
+        def _hard_stop():
+            print(f"[bench] rank {rank}: no result after {limit:.0f} s (TD_BENCH_HARD_TIMEOUT_S) — a collective or a graph replay "
+                  f"is stuck; Python stacks follow", file=sys.stderr, flush=True)
+            import faulthandler
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            os._exit(3)
+        _t = threading.Timer(limit, _hard_stop)
+        _t.daemon = True
+        _t.start()
     emu = None
     if args.emulate_rank:
         er, en = (int(v) for v in args.emulate_rank.split("/"))

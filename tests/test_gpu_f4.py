@@ -225,9 +225,39 @@ def _gemm_ref(a, w, bias=None, res=None, epilogue="none"):
 
 @pytest.mark.parametrize("case", ["plain", "bias", "bias+gelu", "res", "geglu", "f32 out", "ragged", "k pad", "strided", "f16",
                                   "splitk bias+gelu", "splitk res", "splitk geglu", "bias+gelu_erf", "splitk bias+gelu_erf"])
-def test_gemm_bf16_vs_fp32_matmul(K, case):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_bf16_vs_fp32_matmul(K, case, variant):
     """td_gemm_bf16 (256x256-tile 16-bit GEMM on v_mfma_f32_16x16x32) against an fp32 matmul of the same 16-bit operands
-    with the operator sequence's rounding points: within one 16-bit step, most outputs equal."""
+    with the operator sequence's rounding points: within one 16-bit step, most outputs equal.  variant: the eight-wave (128x64
+    wave tiles) and the four-wave (128x128, accumulators in AGPRs) kernel, each forced (TD_TUNE_GEMM16); the four-wave kernel
+    serves the plain / bias / GELU / residual epilogues with 16-bit output, everything else stays on the eight-wave one."""
+    K.set_tuning(K.TUNE_GEMM16, variant)
+    try:
+        _gemm_case(K, case)
+    finally:
+        K.set_tuning(K.TUNE_GEMM16, 0)
+
+
+def test_gemm_bf16_kernels_agree_bit_for_bit(K):
+    """Both kernels add the same MFMA steps in the same order (k ascending, 32 per step): identical bits, also with the residual
+    epilogue and a ragged tile in both directions."""
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(1000, 640, generator=g).bfloat16().to(DEV)
+    w = (torch.randn(777 + 7, 640, generator=g) / 25).bfloat16().to(DEV)[:776]
+    b = (0.3 * torch.randn(776, generator=g)).bfloat16().to(DEV)
+    r = torch.randn(1000, 776, generator=g).bfloat16().to(DEV)
+    outs = []
+    for variant in (1, 2):
+        K.set_tuning(K.TUNE_GEMM16, variant)
+        try:
+            outs.append((K.gemm_bf16(a, w, b), K.gemm_bf16(a, w, b, res=r), K.gemm_bf16(a, w, b, epilogue="gelu_tanh")))
+        finally:
+            K.set_tuning(K.TUNE_GEMM16, 0)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+
+
+def _gemm_case(K, case):
     g = torch.Generator().manual_seed(len(case))
     dt = torch.float16 if case == "f16" else torch.bfloat16
     m, n, k = 700, 520, 384

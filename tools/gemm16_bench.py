@@ -37,6 +37,11 @@ def main():
         a = torch.randn(m, k, device=DEV, generator=g).bfloat16()
         w = (torch.randn(n, k, device=DEV, generator=g) / k ** 0.5).bfloat16()
         b = (0.1 * torch.randn(n, device=DEV, generator=g)).bfloat16()
+        ts = {}
+        for variant in (1, 2):      # eight waves of 128x64 | four waves of 128x128 (forced; production picks by problem size)
+            K.set_tuning(K.TUNE_GEMM16, variant)
+            ts[variant] = timed(lambda: K.gemm_bf16(a, w, b, epilogue=epi))
+        K.set_tuning(K.TUNE_GEMM16, 0)
         t_h = timed(lambda: K.gemm_bf16(a, w, b, epilogue=epi))
         if epi == "gelu_tanh":
             t_l = timed(lambda: F.gelu(F.linear(a, w, b), approximate="tanh"))
@@ -45,6 +50,7 @@ def main():
         fl = 2.0 * m * n * k
         y, yl = K.gemm_bf16(a, w, b, epilogue=epi).float(), (F.gelu(F.linear(a, w, b), approximate="tanh") if epi == "gelu_tanh" else F.linear(a, w, b)).float()
         print(json.dumps({"shape": name, "m": m, "n": n, "k": k, "epilogue": epi, "td_gemm_bf16_us": round(t_h, 1),
+                          "eight_wave_us": round(ts[1], 1), "four_wave_us": round(ts[2], 1),
                           "library_us": round(t_l, 1), "td_TFLOPs": round(fl / t_h / 1e6, 1), "td_frac_of_2500": round(fl / t_h / 1e6 / 2500, 3),
                           "library_TFLOPs": round(fl / t_l / 1e6, 1), "rel_l2_vs_library": float(((y - yl).norm() / yl.norm()).item())}), flush=True)
         del a, w, y, yl

@@ -346,6 +346,231 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const Gemm16P p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// v2 for LARGE problems (round 4): the same 256x256 workgroup tile and LDS image, walked by FOUR waves of 128 x 128 instead
+// of eight of 128 x 64.  Why: per K step a 128 x 64 wave tile reads 24 KB of fragments for 64 MFMAs — 8 waves x 24 KB + 64 KB of
+// DMA writes = 256 KB through a 128 B/clk LDS per 2048 matrix-pipe cycles: the kernel above is co-limited by LDS and the
+// matrix pipe (counter: 0.52 busy, waves parked 45 %).  A 128 x 128 wave tile reads 32 KB for 128 MFMAs (4 waves x 32 KB + 64 KB
+// = 192 KB per 2048 cycles: 73 % of the matrix time), at the price of 256 accumulator registers: they live in AGPRs (the MFMA's
+// own C / D file; bf16 needs no VALU on them, which is what closes this road for the W8A8 kernel), one wave per SIMD with the
+// whole 512-register file, latency hidden by the wave's own software pipeline (the next fragment is read while eight MFMAs
+// of the current one issue).  Plain / bias / GELU / residual epilogues, 16-bit output; everything else stays on the kernel above.
+// ------------------------------------------------------------------------------------------------------------------
+template <int IDT> struct g_mma_b;
+template <> struct g_mma_b<TD_BF16> {
+  __device__ static __forceinline__ v4f run(const v4i& a, const v4i& b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b), c, 0, 0, 0);
+  }
+};
+template <> struct g_mma_b<TD_F16> {
+  __device__ static __forceinline__ v4f run(const v4i& a, const v4i& b, v4f c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a), __builtin_bit_cast(v8h, b), c, 0, 0, 0);
+  }
+};
+
+template <int IDT, int EPI, bool HAS_BIAS, bool RES>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const Gemm16P p) {
+  constexpr int ODT = IDT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t M = p.M, N = p.N;
+  const uint16_t* A = p.A + (int64_t)blockIdx.y * p.sA;
+  const uint16_t* B = p.B + (int64_t)blockIdx.y * p.sB;
+
+  const uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_group = p.group_m * p.tiles_n;
+  const int gid = vid / per_group;
+  const int first_m = gid * p.group_m;
+  const int gsz = min(p.group_m, p.tiles_m - first_m);
+  const int in_g = vid % per_group;
+  const int tm = first_m + in_g % gsz;
+  const int tn = in_g / gsz;
+  const int64_t m0 = (int64_t)tm * G_BM, n0 = (int64_t)tn * G_BN;
+  const int nk = (int)(p.K / 64);
+  const int64_t ldab = p.lda * 2, ldbb = p.ldb * 2;
+
+  // ---- LDS-DMA pieces: wave w moves chunks c = w + 4t, t = 0..7 (8 rows x 128 B each) of both operand tiles ----
+  uint32_t ga[8], gb[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int c = wave + 4 * t;
+    const int row = 8 * c + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    int64_t am = m0 + row; if (am > M - 1) am = M - 1;
+    int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
+    ga[t] = (uint32_t)(am * ldab + chunk * 16);
+    gb[t] = (uint32_t)(bn * ldbb + chunk * 16);
+  }
+  const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(uint32_t)((M - 1) * ldab + p.K * 2), 0x00020000);
+  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(uint32_t)((N - 1) * ldbb + p.K * 2), 0x00020000);
+  // piece q of stage kb_ into buffer (kb_ & 1): q = 0..7 activation chunks, 8..15 weight chunks
+#define W4_PIECE(kb_, q_)                                                                          \
+  {                                                                                                \
+    char* sb_ = smem + ((kb_) & 1) * G_STAGE + wave * 1024;                                        \
+    if ((q_) < 8)                                                                                  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (g_lptr_t)(sb_ + ((q_) & 7) * 4096), 16,    \
+                                               ga[(q_) & 7], (kb_) * 128, 0, 0);                   \
+    else                                                                                           \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (g_lptr_t)(sb_ + G_TILE + ((q_) & 7) * 4096), \
+                                               16, gb[(q_) & 7], (kb_) * 128, 0, 0);               \
+  }
+
+  const int pr = (l16 & 3) | ((l16 & 4) << 1) | ((l16 & 8) >> 1);
+  uint32_t xoff[2], woff[2];
+#pragma unroll
+  for (int kc = 0; kc < 2; ++kc) {
+    xoff[kc] = g_swz(wm * 128 + l16, 4 * kc + lq);
+    woff[kc] = G_TILE + g_swz(wn * 128 + pr, 4 * kc + lq);
+  }
+
+  v4f acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+  v4i wf[2][8], xf[2];   // weight fragments of BOTH halves of a K step (the other half is read while this one multiplies)
+
+#define W4_LOAD_W(st_, kc_)                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                    \
+    wf[kc_][j] = *reinterpret_cast<const v4i*>((st_) + woff[kc_] + j * 2048);
+#define W4_LOAD_X(st_, kc_, i_, slot_) xf[slot_] = *reinterpret_cast<const v4i*>((st_) + xoff[kc_] + (i_) * 2048);
+
+  // ---- prologue: stages 0 and 1 in flight; wait for stage 0 ----
+#pragma unroll
+  for (int q = 0; q < 16; ++q) W4_PIECE(0, q)
+  if (nk > 1) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) W4_PIECE(1, q)
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  G_BARRIER()
+  W4_LOAD_W(smem, 0)
+  W4_LOAD_X(smem, 0, 0, 0)
+
+  // One K step = 16 groups g = (kc, i): 8 MFMAs each against the 8 weight fragments of half kc.  The activation fragment of
+  // group g + 1 is read at the top of group g; the weight fragments of the next half are re-read behind the last group that
+  // uses the current ones.  ONE barrier per K step, before the last group: by then every LDS read of this stage has been
+  // issued and returned and this wave's DMA pieces of the next-but-one stage... (see below) have landed.
+  for (int kb = 0; kb < nk; ++kb) {
+    const char* st = smem + (kb & 1) * G_STAGE;
+    const char* stn = smem + ((kb + 1) & 1) * G_STAGE;
+    const bool more = kb + 1 < nk;
+    const bool dma = (kb >= 1) && more;          // stage kb + 1's pieces go out during THIS step (stage 1: the prologue)
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int kc = g >> 3, i = g & 7;
+      const int cur = g & 1, nxt = cur ^ 1;
+      // next group's activation fragment
+      if (g < 15) { W4_LOAD_X(st, (g + 1) >> 3, (g + 1) & 7, nxt) }
+      else if (more) { W4_LOAD_X(stn, 0, 0, nxt) }
+      // DMA of stage kb + 1 into the OTHER buffer: its last readers passed the barrier of step kb - 1.  All 16 pieces in the
+      // first half of the step, so that the latest has ~1000 cycles before the wait below.
+      if (dma && g < 8) { W4_PIECE(kb + 1, 2 * g) W4_PIECE(kb + 1, 2 * g + 1) }
+      if (g == 1) { W4_LOAD_W(st, 1) }           // the second half's weight fragments: six groups before their first use
+      if (g == 15 && more) { W4_LOAD_W(stn, 0) } // the next step's first half (behind the barrier of group 14), under this group's MFMAs
+      G_FENCE()
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = g_mma_b<IDT>::run(wf[kc][j], xf[cur], acc[i][j]);
+      G_FENCE()
+      if (g == 14) {
+        // every read of stage kb has been issued (group 15's fragment was read at the top of this group); wait for them and
+        // for this wave's pieces of stage kb + 1, then meet the others: after the barrier stage kb + 1 is complete for
+        // everyone and buffer kb & 1 may be overwritten by stage kb + 2 during the next step
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        G_BARRIER()
+      }
+    }
+  }
+  asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+
+  // ---- epilogue: lane owns m = .. + l16; accumulator (i, j) holds n_local = 16 j + 8 (lq & 1) + 4 (lq >> 1) + r ----
+  const int hi = lq >> 1;
+  uint16_t* D = reinterpret_cast<uint16_t*>(p.D) + (int64_t)blockIdx.y * p.sD;
+  const uint16_t* R = RES ? p.R + (int64_t)blockIdx.y * p.sR : nullptr;
+  __syncthreads();                    // every wave has read its last fragments: the stages may be overwritten
+  constexpr int WS = 136;             // staging row: 128 columns + 8 pad (16-bit)
+  float* ep_bias = reinterpret_cast<float*>(smem + 4 * (64 * WS) * 2);
+  if (tid < 256) {
+    const int64_t n = n0 + tid;
+    float bv = 0.f;
+    if constexpr (HAS_BIAS) { if (n < N) bv = half_bits_to_f32<ODT>(p.bias[n]); }
+    ep_bias[tid] = bv;
+  }
+  __syncthreads();
+  uint16_t* stg = reinterpret_cast<uint16_t*>(smem) + wave * (64 * WS);
+  constexpr int EP = EPI == G_EPI_GELU ? TD_EPI_GELU_TANH : TD_EPI_NONE;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t pk[8][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float bf[4] = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (HAS_BIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(ep_bias + wn * 128 + j * 16 + 8 * (lq & 1) + 4 * hi);
+        bf[0] = bb.x; bf[1] = bb.y; bf[2] = bb.z; bf[3] = bb.w;
+      }
+      pk[j][0] = td_gemm_epilogue2<ODT, EP, HAS_BIAS>(acc[i][j][0], acc[i][j][1], bf[0], bf[1]);
+      pk[j][1] = td_gemm_epilogue2<ODT, EP, HAS_BIAS>(acc[i][j][2], acc[i][j][3], bf[2], bf[3]);
+      if constexpr (EPI == G_EPI_GELU_ERF) { pk[j][0] = g_gelu_erf2<ODT>(pk[j][0]); pk[j][1] = g_gelu_erf2<ODT>(pk[j][1]); }
+    }
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp) {
+      const int ja = 2 * jp, jb = 2 * jp + 1;
+      auto s0 = __builtin_amdgcn_permlane32_swap(pk[ja][0], pk[jb][0], false, false);
+      auto s1 = __builtin_amdgcn_permlane32_swap(pk[ja][1], pk[jb][1], false, false);
+      const uint4 v = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+      const int jt = hi ? jb : ja;
+      *reinterpret_cast<uint4*>(stg + ((i & 3) * 16 + l16) * WS + jt * 16 + 8 * (lq & 1)) = v;
+    }
+    if ((i & 3) == 3) {   // a 64-row half is complete in LDS: 4 rows x two full 128-byte lines per store instruction
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + (lane >> 4), chunk = lane & 15;
+        const int64_t mm = m0 + wm * 128 + (i >> 2) * 64 + row, nn = n0 + wn * 128 + chunk * 8;
+        uint4 r = *reinterpret_cast<const uint4*>(stg + row * WS + chunk * 8);
+        if (mm < M && nn < N) {
+          if constexpr (RES) {
+            float xf8[8], yf8[8];
+            unpack8<ODT>(*reinterpret_cast<const uint4*>(R + mm * p.ldr + nn), xf8);
+            unpack8<ODT>(r, yf8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xf8[e] += yf8[e];
+            r = pack8<ODT>(xf8);
+          }
+          if (nn + 8 <= N) *reinterpret_cast<uint4*>(D + mm * p.ldd + nn) = r;
+          else {
+            const uint32_t w4[4] = {r.x, r.y, r.z, r.w};
+            for (int e = 0; e < 8 && nn + e < N; ++e) D[mm * p.ldd + nn + e] = (uint16_t)(w4[e >> 1] >> ((e & 1) * 16));
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+template <int IDT, int EPI, bool HAS_BIAS, bool RES>
+static int launch_gemm16_w4(const Gemm16P& p0, int batch, hipStream_t st) {
+  auto kern = gemm_bf16_w4_kernel<IDT, EPI, HAS_BIAS, RES>;
+  static std::atomic<uint64_t> attr_mask{0};
+  td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), G_LDS, attr_mask);
+  Gemm16P p = p0;
+  p.tiles_m = (int)td_cdiv(p.M, G_BM);
+  p.tiles_n = (int)td_cdiv(p.N, G_BN);
+  p.group_m = td_tuning(TD_TUNE_GEMM_GROUP_M) > 0 ? td_tuning(TD_TUNE_GEMM_GROUP_M) : 4;
+  const dim3 grid((unsigned)p.tiles_m * (unsigned)p.tiles_n, (unsigned)batch, 1);
+  kern<<<grid, 256, G_LDS, st>>>(p);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
 template <int IDT, int ODT, int EPI, bool HAS_BIAS, bool RES>
 static int launch_gemm16(const Gemm16P& p0, int batch, hipStream_t st) {
   auto kern = gemm_bf16_kernel<IDT, ODT, EPI, HAS_BIAS, RES>;
@@ -367,6 +592,21 @@ static int dispatch_gemm16(const Gemm16P& p, int out_dtype, int epilogue, int ba
   if (out_dtype == TD_F32) {
     return hb ? launch_gemm16<IDT, TD_F32, G_EPI_NONE, true, false>(p, batch, st)
               : launch_gemm16<IDT, TD_F32, G_EPI_NONE, false, false>(p, batch, st);
+  }
+  // large problems (>= 256 tiles: every CU busy for at least one round) on the four-wave kernel; TD_TUNE_GEMM16 = 1 forces the
+  // eight-wave kernel, 2 the four-wave one (A/B and tests)
+  const int64_t tiles = td_cdiv(p.M, G_BM) * td_cdiv(p.N, G_BN) * batch;
+  const int force = td_tuning(TD_TUNE_GEMM16);
+  if (epilogue != G_EPI_GEGLU && (force == 2 || (force == 0 && tiles >= 256))) {
+#define TD_W4(EPI_)                                                                                  \
+    {                                                                                                \
+      if (res) return hb ? launch_gemm16_w4<IDT, EPI_, true, true>(p, batch, st) : launch_gemm16_w4<IDT, EPI_, false, true>(p, batch, st); \
+      return hb ? launch_gemm16_w4<IDT, EPI_, true, false>(p, batch, st) : launch_gemm16_w4<IDT, EPI_, false, false>(p, batch, st);      \
+    }
+    if (epilogue == G_EPI_NONE) TD_W4(G_EPI_NONE)
+    if (!res && epilogue == G_EPI_GELU) TD_W4(G_EPI_GELU)
+    if (!res && epilogue == G_EPI_GELU_ERF) TD_W4(G_EPI_GELU_ERF)
+#undef TD_W4
   }
   if (epilogue == G_EPI_GEGLU) return launch_gemm16<IDT, IDT, G_EPI_GEGLU, false, false>(p, batch, st);
   if (epilogue == G_EPI_GELU) {
