@@ -505,10 +505,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w4_kernel(const Gemm16P p) {
   __syncthreads();
   uint16_t* stg = reinterpret_cast<uint16_t*>(smem) + wave * (64 * WS);
   constexpr int EP = EPI == G_EPI_GELU ? TD_EPI_GELU_TANH : TD_EPI_NONE;
-#pragma unroll
+  // (unroll(full), not the `unroll` hint: with a bias / GELU / residual body the hint is dropped, `acc[i]` becomes a dynamically
+  // indexed array and all 256 accumulators move to scratch — the main loop then spills around every MFMA: 10 x slower, measured)
+#pragma clang loop unroll(full)
   for (int i = 0; i < 8; ++i) {
     uint32_t pk[8][2];
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int j = 0; j < 8; ++j) {
       float bf[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (HAS_BIAS) {
