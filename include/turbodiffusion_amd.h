@@ -72,7 +72,7 @@ const char* td_last_error(void);
 #define TD_TUNE_LIN_QB 7       /* linear branch, pass 2: Q blocks one workgroup walks (0 = default) */
 #define TD_TUNE_ATTN_OCC 8     /* INT8/FP16-PV attention builds kept for comparison: 2 = two workgroups per CU with explicit fragment prefetch, 3 = Q64 (waves as 2 Q halves x 2 key halves; equal to rounding, not bit-identical), 4 = build 2 with the softmax denominator accumulated on the matrix pipe (round-4 experiment; equal to rounding) */
 #define TD_TUNE_VAE_CONV 9     /* td_vae_conv: 1 = the first kernel (one gather per tap, flat position tiles), kept as the cross-check of the default; 3 = the row-tile kernel with 512-column tiles and one workgroup per CU (experiment, slower), 4 = with 32-channel chunks in two LDS stages and one barrier per chunk, 5 = frames-first tile order, 6 = 4 with the chunk multiply unrolled into one basic block (experiments: equal within 1 %) */
-#define TD_TUNE_GEMM16 10      /* td_gemm_bf16, 16-bit outputs: 0 = automatic (four waves of 128x128 for >= 256 tiles, else eight of 128x64), 1 = eight-wave kernel, 2 = four-wave kernel; equal results up to fp32 summation order (identical: both walk k ascending in the same MFMA steps) */
+#define TD_TUNE_GEMM16 10      /* td_gemm_bf16, 16-bit outputs: 2 = the four-wave kernel (128x128 wave tiles, accumulators in AGPRs: round-4 experiment, measured equal to the default eight-wave kernel; bit-identical results) */
 #define TD_TUNE_COUNT 12
 int td_set_tuning(int key, int value);
 /* profiling: copy the n (<= 256) 64-bit s_memtime stamps of the last TD_TUNE_GEMM_ABLATE == 9 launch to host */

@@ -347,8 +347,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const Gemm16P p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// v2 for LARGE problems (round 4): the same 256x256 workgroup tile and LDS image, walked by FOUR waves of 128 x 128 instead
-// of eight of 128 x 64.  Why: per K step a 128 x 64 wave tile reads 24 KB of fragments for 64 MFMAs — 8 waves x 24 KB + 64 KB of
+// EXPERIMENT (round 4, TD_TUNE_GEMM16 = 2; measured EQUAL, not the default): the same 256x256 workgroup tile and LDS image,
+// walked by FOUR waves of 128 x 128 instead of eight of 128 x 64.  Result (profiles/r04_gemm16_bench.jsonl, C3 shapes at L = 32 760,
+// two runs): q|k|v 418-431 µs vs 464-473, o 164-166 vs 150-157, ffn.0 + GELU 861 vs 858, ffn.2 713-722 vs 755-819; C3 end to end 110.7
+// vs 111.1 ms per DiT step — inside the spread: fewer LDS bytes per MFMA buy nothing once each SIMD holds ONE wave whose
+// barrier and DMA waits nothing else covers.  (A trap on the way: with a bias / GELU / residual epilogue the `#pragma unroll`
+// hint on the row-group loop was dropped, `acc[i]` became a dynamically indexed array and all 256 accumulators went to scratch
+// — 10 x slower; `unroll(full)` fixed it.)  The idea was: per K step a 128 x 64 wave tile reads 24 KB of fragments for 64 MFMAs — 8 waves x 24 KB + 64 KB of
 // DMA writes = 256 KB through a 128 B/clk LDS per 2048 matrix-pipe cycles: the kernel above is co-limited by LDS and the
 // matrix pipe (counter: 0.52 busy, waves parked 45 %).  A 128 x 128 wave tile reads 32 KB for 128 MFMAs (4 waves x 32 KB + 64 KB
 // = 192 KB per 2048 cycles: 73 % of the matrix time), at the price of 256 accumulator registers: they live in AGPRs (the MFMA's
@@ -595,11 +600,10 @@ static int dispatch_gemm16(const Gemm16P& p, int out_dtype, int epilogue, int ba
     return hb ? launch_gemm16<IDT, TD_F32, G_EPI_NONE, true, false>(p, batch, st)
               : launch_gemm16<IDT, TD_F32, G_EPI_NONE, false, false>(p, batch, st);
   }
-  // large problems (>= 256 tiles: every CU busy for at least one round) on the four-wave kernel; TD_TUNE_GEMM16 = 1 forces the
-  // eight-wave kernel, 2 the four-wave one (A/B and tests)
-  const int64_t tiles = td_cdiv(p.M, G_BM) * td_cdiv(p.N, G_BN) * batch;
+  // TD_TUNE_GEMM16 = 2: the four-wave kernel (experiment, kept selectable and tested: equal to the eight-wave kernel within
+  // the run-to-run spread on every shape measured — see its header); default: the eight-wave kernel
   const int force = td_tuning(TD_TUNE_GEMM16);
-  if (epilogue != G_EPI_GEGLU && (force == 2 || (force == 0 && tiles >= 256))) {
+  if (epilogue != G_EPI_GEGLU && force == 2) {
 #define TD_W4(EPI_)                                                                                  \
     {                                                                                                \
       if (res) return hb ? launch_gemm16_w4<IDT, EPI_, true, true>(p, batch, st) : launch_gemm16_w4<IDT, EPI_, false, true>(p, batch, st); \
