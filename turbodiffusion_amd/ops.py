@@ -57,110 +57,108 @@ def layernorm(x, w, b, eps, elementwise_affine=True, triton_variance=True):
     return K.layernorm(x.contiguous(), None, None, eps, pad_cols=pad)
 
 
-def cdiv(a: int, b: int):
-    return (a + b - 1) // b
+def _blocks(n: int) -> int:
+    return -(-n // 128)
 
 
-class Int8Linear(nn.Module):
-    """ops/core.py:391-432 — buffers ``int8_weight [out,in] int8``, ``scale [ceil(out/128),
-    ceil(in/128)] f32``, ``bias [out]`` are the published-checkpoint contract."""
+def _on_meta(t) -> bool:
+    return t is not None and t.device.type == "meta"
+
+
+class _ContractModule(nn.Module):
+    """The three operator modules share one shape: a few BUFFERS whose names / shapes / dtypes are the published-checkpoint
+    contract (``modify_model.replace_*`` + ``load_state_dict(assign=True)``, inference/modify_model.py:56-81,137-138) and a
+    ``from_<original>`` constructor that adopts an eager module's tensors.  ``_slots`` declares the buffers; absent ones are
+    plain ``None`` attributes (the reference's ``self.bias = None`` / ``register_parameter(name, None)``)."""
+
+    def _declare(self, **slots):
+        for name, spec in slots.items():
+            if spec is None:
+                setattr(self, name, None)
+            else:
+                shape, dtype, fill = spec
+                t = torch.ones(shape, dtype=dtype) if fill == "ones" else torch.empty(shape, dtype=dtype)
+                self.register_buffer(name, t)
+
+    def _adopt(self, name, tensor, dtype=None, device=None):
+        """Take ``tensor``'s values as buffer ``name`` (a clone; skipped for meta tensors: the checkpoint fills them later)."""
+        if tensor is None or _on_meta(tensor):
+            return
+        t = tensor.detach()
+        if device is not None:
+            t = t.to(device)
+        setattr(self, name, (t.to(dtype) if dtype is not None else t).clone())
+
+
+class Int8Linear(_ContractModule):
+    """``turbodiffusion.ops.Int8Linear`` (ops/core.py:391-432): ``int8_weight [out, in] int8``, ``scale [ceil(out/128),
+    ceil(in/128)] f32``, ``bias [out]`` in the model dtype.  forward = dynamic per-128x128-block activation quantisation +
+    W8A8 GEMM; the bias rides in the GEMM's epilogue, added after the result has been rounded to ``x.dtype`` — the bits of
+    the reference's separate ``out + self.bias`` (ops/core.py:408-412)."""
 
     def __init__(self, in_features, out_features, bias=True, dtype=torch.bfloat16):
         super().__init__()
-        self.in_features = in_features
-        self.out_features = out_features
-        row_blocks = cdiv(out_features, b=128)
-        col_blocks = cdiv(in_features, b=128)
-        self.register_buffer("int8_weight", torch.empty((out_features, in_features), dtype=torch.int8))
-        self.register_buffer("scale", torch.empty((row_blocks, col_blocks), dtype=torch.float32))
-        if bias:
-            self.register_buffer("bias", torch.empty(out_features, dtype=dtype))
-        else:
-            self.bias = None
+        self.in_features, self.out_features = in_features, out_features
+        self._declare(int8_weight=((out_features, in_features), torch.int8, None),
+                      scale=((_blocks(out_features), _blocks(in_features)), torch.float32, None),
+                      bias=((out_features,), dtype, None) if bias else None)
 
     def forward(self, x):
-        # bias is added inside the GEMM epilogue, after the GEMM result has been rounded to
-        # x.dtype — bit-identical to the reference's separate ``out + self.bias``
         b = self.bias
-        if b is not None and b.dtype != x.dtype:
-            b = b.to(x.dtype)
-        return int8_linear(x, self.int8_weight, self.scale, bias=b)
+        return int8_linear(x, self.int8_weight, self.scale, bias=None if b is None else (b if b.dtype == x.dtype else b.to(x.dtype)))
 
     @classmethod
     def from_linear(cls, original_linear: nn.Linear, quantize: bool = True):
-        int8_layer = cls(
-            original_linear.in_features,
-            original_linear.out_features,
-            bias=original_linear.bias is not None,
-            dtype=original_linear.weight.dtype,
-        )
+        """``quantize=False``: shapes only (the quantised checkpoint is loaded afterwards, modify_model.py:137); True: the
+        offline quantiser's job (:156-183) on the GPU — fp32 weights go through bf16 first, as there."""
+        lin = original_linear
+        layer = cls(lin.in_features, lin.out_features, bias=lin.bias is not None, dtype=lin.weight.dtype)
         if quantize:
-            w_data = original_linear.weight.data.cuda()
-            if w_data.dtype == torch.float32:
-                w_data = w_data.to(torch.bfloat16)
-            int8_w, scale = int8_quant(w_data)
-            int8_layer.int8_weight = int8_w
-            int8_layer.scale = scale
-            if original_linear.bias is not None:
-                int8_layer.bias = original_linear.bias.data.cuda().clone()
-        return int8_layer
+            w = lin.weight.data.cuda()
+            layer.int8_weight, layer.scale = int8_quant(w.to(torch.bfloat16) if w.dtype == torch.float32 else w)
+            layer._adopt("bias", lin.bias, device="cuda")
+        return layer
 
 
-class FastRMSNorm(nn.Module):
-    """ops/core.py:434-452 (buffer ``weight`` fp32)."""
+class FastRMSNorm(_ContractModule):
+    """``turbodiffusion.ops.FastRMSNorm`` (ops/core.py:434-452): buffer ``weight`` fp32 [dim].  The reference up-casts
+    (``rmsnorm(x.float(), w, eps).to(x.dtype)``); the kernel reads x's dtype, computes in fp32 and rounds once — the same value
+    without the fp32 round trip through HBM."""
 
     def __init__(self, dim: int, eps: float = 1e-5):
         super().__init__()
-        self.dim = dim
-        self.eps = eps
-        self.register_buffer("weight", torch.ones(dim))
+        self.dim, self.eps = dim, eps
+        self._declare(weight=((dim,), torch.float32, "ones"))
 
     def forward(self, x):
-        # reference: rmsnorm(x.float(), w, eps).to(x.dtype); the fused kernel reads x's dtype
-        # directly and rounds once at the end — the same value, without the fp32 round trip
         return K.rmsnorm(x.contiguous(), self.weight, self.eps)
 
     @classmethod
     def from_rmsnorm(cls, original_rmsnorm):
         layer = cls(dim=original_rmsnorm.dim, eps=original_rmsnorm.eps)
-        if original_rmsnorm.weight.device != torch.device("meta"):
-            layer.weight = original_rmsnorm.weight.float().data.clone()
+        layer._adopt("weight", original_rmsnorm.weight, dtype=torch.float32)
         return layer
 
 
-class FastLayerNorm(nn.Module):
-    """ops/core.py:454-492."""
+class FastLayerNorm(_ContractModule):
+    """``turbodiffusion.ops.FastLayerNorm`` (ops/core.py:454-492): optional ``weight`` / ``bias`` buffers [dim].
+    ``triton_variance`` (class default True) selects the reference Triton kernel's variance, see ``layernorm``."""
+
+    triton_variance = True
 
     def __init__(self, dim: int, eps: float = 1e-5, elementwise_affine: bool = False, bias: bool = True):
         super().__init__()
-        self.dim = dim
-        self.eps = eps
-        self.elementwise_affine = elementwise_affine
-        if self.elementwise_affine:
-            self.register_buffer("weight", torch.empty(self.dim))
-            if bias:
-                self.register_buffer("bias", torch.empty(self.dim))
-            else:
-                self.bias = None
-        else:
-            self.register_parameter("weight", None)
-            self.register_parameter("bias", None)
-
-    triton_variance = True   # False: the textbook variance (see ``layernorm``)
+        self.dim, self.eps, self.elementwise_affine = dim, eps, elementwise_affine
+        self._declare(weight=((dim,), torch.get_default_dtype(), None) if elementwise_affine else None,
+                      bias=((dim,), torch.get_default_dtype(), None) if (elementwise_affine and bias) else None)
 
     def forward(self, x):
         return layernorm(x, self.weight, self.bias, self.eps, self.elementwise_affine, self.triton_variance)
 
     @classmethod
     def from_layernorm(cls, original_layernorm):
-        layer = cls(
-            dim=original_layernorm.normalized_shape[0],
-            eps=original_layernorm.eps,
-            elementwise_affine=False if original_layernorm.weight is None else True,
-            bias=original_layernorm.bias is not None,
-        )
-        if original_layernorm.weight is not None and original_layernorm.weight.device != torch.device("meta"):
-            layer.weight = original_layernorm.weight.data.clone()
-        if original_layernorm.bias is not None and original_layernorm.bias.device != torch.device("meta"):
-            layer.bias = original_layernorm.bias.data.clone()
+        ln = original_layernorm
+        layer = cls(dim=ln.normalized_shape[0], eps=ln.eps, elementwise_affine=ln.weight is not None, bias=ln.bias is not None)
+        layer._adopt("weight", ln.weight)
+        layer._adopt("bias", ln.bias)
         return layer

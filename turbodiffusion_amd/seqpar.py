@@ -45,8 +45,8 @@ class _NullCtx:
 
 
 class EmulatedGroup:
-    """Stands in for a process group when ONE rank of an N-way split is run alone on one GPU (``bench.py --emulate-rank``,
-    ``tools/emulate_ranks.py``): no communication — an all-gather fills every rank's slot of its output with THIS rank's
+    """Stands in for a process group when ONE rank of an N-way split is run alone on one GPU (``bench.py --emulate-rank``):
+    no communication — an all-gather fills every rank's slot of its output with THIS rank's
     shard (a device copy on the compute stream: the HBM writes a real gather's incoming xGMI traffic would cause, not
     overlapped with anything, so the compute term it measures is on the pessimistic side).  Results are meaningless as
     attention outputs (every rank's K side is a copy of this rank's); shapes, launches, LUT sizes and kernel work are those of
