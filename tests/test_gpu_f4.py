@@ -424,6 +424,37 @@ def test_prompt_ids_to_video_runs_the_three_stages():
     assert torch.equal(v1, v2)
 
 
+def test_prompt_text_to_embedding_through_the_reference_entry_points(tmp_path):
+    """text -> ids -> embedding through the reference's entry points of the same names (umt5.py:479-545): a T5-layout
+    vocabulary trained here, a toy encoder; padding rows zero, valid rows == the encoder on the tokenizer's ids; one
+    process-wide encoder until ``clear_umt5_memory``."""
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors, trainers
+    from turbodiffusion_amd import text_encoder as TE
+    from turbodiffusion_amd.tokenizer import HuggingfaceTokenizer
+    corpus = ["a stylish woman walks down a tokyo street", "a cat surfing a wave at sunset", "an astronaut riding a horse on mars"] * 6
+    tok = Tokenizer(models.Unigram())
+    tok.pre_tokenizer = pre_tokenizers.Metaspace()
+    tok.train_from_iterator(corpus, trainers.UnigramTrainer(vocab_size=80, special_tokens=["<pad>", "</s>", "<unk>"],
+                                                           unk_token="<unk>", show_progress=False))
+    tok.post_processor = processors.TemplateProcessing(single="$A </s>", special_tokens=[("</s>", 1)])
+    tok.save(str(tmp_path / "tokenizer.json"))
+    sd = TE.synthetic_state_dict(layers=2, dim=256, dim_ffn=512, heads=4, vocab=tok.get_vocab_size(), seed=2)
+    prompts = ["a cat   riding a horse &amp; a wave", "a woman walks on mars " * 20, ""]
+    TE.clear_umt5_memory()
+    emb = TE.get_umt5_embedding(sd, prompts, device="cuda", max_length=32, tokenizer_path=str(tmp_path))
+    assert emb.shape == (3, 32, 256) and emb.dtype == torch.bfloat16 and emb.is_cuda and torch.isfinite(emb).all()
+    assert TE.t5_encoder is not None and TE.get_umt5_embedding(None, prompts[:1], max_length=32).shape == (1, 32, 256)   # cached
+    ids, mask = HuggingfaceTokenizer(str(tmp_path), seq_len=32, clean="whitespace")(prompts, return_mask=True)
+    lens = mask.sum(1).tolist()
+    assert lens[1] == 32 and lens[2] == 1 and 1 < lens[0] < 32
+    direct = TE.Umt5Encoder(sd)(ids, mask)
+    assert torch.equal(emb, direct)
+    for b, n in enumerate(lens):
+        assert not emb[b, n:].any() and emb[b, :n].abs().sum() > 0
+    TE.clear_umt5_memory()
+    assert TE.t5_encoder is None
+
+
 def test_image_and_prompt_to_video_runs_the_i2v_data_path():
     """wan2.2_i2v_infer.py's data path on toy models: umT5 -> VAE-encoded conditioning -> 4 steps with the expert switch at the
     boundary (two DiTs resident) -> VAE decode."""

@@ -23,8 +23,9 @@ weight rows are interleaved once at load time), the per-head score and value pro
 strided views of the fused q|k|v output, ``td_softmax_rows`` adds the position bias (rounded, as the reference's 16-bit
 add) and normalises in fp32, ``td_t5_norm`` is T5LayerNorm with its two roundings.  torch is left with the token-embedding
 and position-table gathers (index plumbing).  HIP only: 16-bit on a GPU; the library-operator restatement the CPU pins run
-is ``oracle/f4_ref.py``.  Tokenisation (a HuggingFace tokenizer the reference downloads, umt5.py:58-89) is not part of
-this module: it takes ids and mask."""
+is ``oracle/f4_ref.py``.  Tokenisation (umt5.py:58-98) is ``tokenizer.HuggingfaceTokenizer``; ``UMT5EncoderModel`` /
+``get_umt5_embedding`` / ``clear_umt5_memory`` at the end of this file are the reference's entry points of the same names
+(umt5.py:479-545) on top of both."""
 from __future__ import annotations
 
 import math
@@ -164,3 +165,50 @@ class Umt5Encoder:
             if n > 0:
                 out[b, :n] = self._rows(ids[b, :n])
         return out
+
+
+class UMT5EncoderModel:
+    """The reference's ``UMT5EncoderModel`` (umt5.py:479-521): checkpoint + tokenizer -> ``model(texts)`` = [B, text_len, 4096]
+    with the rows past each prompt's length zero.  ``checkpoint_path``: the reference's ``models_t5_umt5-xxl-enc-bf16.pth`` (a
+    plain state dict) or a state dict already in memory; ``tokenizer_path``: a local ``tokenizer.json`` / directory
+    (``tokenizer.HuggingfaceTokenizer``; the reference's default is the hub id, there is no network here)."""
+
+    def __init__(self, text_len=512, dtype=torch.bfloat16, device="cuda", checkpoint_path="models_t5_umt5-xxl-enc-bf16.pth",
+                 tokenizer_path="google/umt5-xxl"):
+        from .tokenizer import HuggingfaceTokenizer
+        self.text_len, self.dtype, self.device = text_len, dtype, device
+        if isinstance(checkpoint_path, dict):
+            sd = checkpoint_path
+        else:
+            assert str(checkpoint_path).endswith(".pth")                       # umt5.py:496
+            sd = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        self.model = Umt5Encoder(sd, dtype=dtype, device=device)
+        self.tokenizer = HuggingfaceTokenizer(name=tokenizer_path, seq_len=text_len, clean="whitespace")
+
+    def __call__(self, texts, device=None):
+        ids, mask = self.tokenizer(texts, return_mask=True, add_special_tokens=True)
+        out = self.model(ids, mask)              # valid rows computed, padding rows written as zeros (umt5.py:510-521)
+        return out if device is None else out.to(device)
+
+
+t5_encoder = None
+
+
+def get_umt5_embedding(checkpoint_path, prompts, device="cuda", max_length=512, tokenizer_path="google/umt5-xxl"):
+    """umt5.py:524-533: one process-wide encoder, built on first use"""
+    global t5_encoder
+    if t5_encoder is None:
+        t5_encoder = UMT5EncoderModel(text_len=max_length, device=device, checkpoint_path=checkpoint_path,
+                                      tokenizer_path=tokenizer_path)
+    return t5_encoder(prompts, device=device)
+
+
+def clear_umt5_memory():
+    """umt5.py:536-545"""
+    global t5_encoder
+    if t5_encoder is not None:
+        t5_encoder = None
+    import gc
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
