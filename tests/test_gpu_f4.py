@@ -46,8 +46,11 @@ def _conv_ref(x, w, b, kt, kh, kw, res=None, up2=False, interleave=False):
     return y
 
 
-@pytest.mark.parametrize("kernel", [0, 1, 3, 4, 6])   # default (row tiles) | first kernel | 512-column tiles | two LDS stages | two stages + unrolled multiply
-@pytest.mark.parametrize("case", ["3x3x3", "residual+tail", "up2", "time-interleave", "head", "1x3x3 Ci96", "wide rows", "time-interleave 192"])
+# default (2-D tiles by LDS-DMA where eligible) | first kernel | row tiles (the former default) | 512-column row tiles | two LDS stages |
+# two stages + unrolled multiply | 2-D tiles, frame-by-frame order
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 6, 7])
+@pytest.mark.parametrize("case", ["3x3x3", "residual+tail", "up2", "time-interleave", "head", "1x3x3 Ci96", "wide rows", "time-interleave 192",
+                                  "up2 Co96", "tall", "two tiles each way"])
 def test_vae_conv_kernel_vs_torch(K, case, kernel):
     """td_vae_conv (implicit GEMM on the bf16 matrix pipe, csrc/vae_conv.hip) against an fp32 torch convolution of the same
     bf16 inputs: within one bf16 step of the correctly rounded result."""
@@ -68,13 +71,19 @@ def test_vae_conv_kernel_vs_torch(K, case, kernel):
         B, T, H, W, Ci, Co, res = 1, 2, 3, 300, 96, 192, True
     elif case == "time-interleave 192":                            # both halves of the channel pairs are whole 96-channel tiles
         B, T, H, W, Ci, Co, k, inter = 1, 3, 4, 9, 96, 192, (3, 1, 1), True
+    elif case == "up2 Co96":                                       # the up-sampler's convolution with whole 96-channel tiles
+        B, T, H, W, Ci, Co, k, up2 = 2, 2, 9, 21, 192, 96, (1, 3, 3), True
+    elif case == "tall":                                           # more rows than a 2-D tile is high, narrower than one is wide
+        B, T, H, W, Ci, Co, res = 1, 4, 70, 11, 32, 96, True
+    elif case == "two tiles each way":                             # 2-D tiles: 3 x 2 tiles of 32 x 16 with ragged right / bottom edges
+        B, T, H, W, Ci, Co = 1, 3, 37, 70, 64, 192
     x = torch.randn(B, T, H, W, Ci, generator=g).bfloat16()
     w = (torch.randn(Co, k[0] * k[1] * k[2] * Ci, generator=g) / (k[0] * k[1] * k[2] * Ci) ** 0.5).bfloat16()
     b = (0.1 * torch.randn(Co, generator=g)).bfloat16()
     shape = (B, 2 * T, H, W, Co // 2) if inter else (B, T, 2 * H if up2 else H, 2 * W if up2 else W, Co)
     r = torch.randn(shape, generator=g).bfloat16() if res else None
     ref = _conv_ref(x, w, b, *k, res=r, up2=up2, interleave=inter)
-    K.set_tuning(K.TUNE_VAE_CONV, kernel)      # 0 = default (row tiles, one gather per (dt, dh)); 1 = the first kernel
+    K.set_tuning(K.TUNE_VAE_CONV, kernel)      # include/turbodiffusion_amd.h: TD_TUNE_VAE_CONV
     try:
         out = _run_conv(K, x, w, b, k, r, up2, inter, g)
     finally:

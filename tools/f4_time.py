@@ -29,6 +29,10 @@ def timed(fn, reps=3):
 
 def main():
     which = sys.argv[1:] or ["vae480", "vae720", "enc480", "umt5"]
+    if os.environ.get("F4_VAE_CONV"):        # A/B of the convolution kernels: TD_TUNE_VAE_CONV value
+        from turbodiffusion_amd import kernels as K0
+        K0.set_tuning(K0.TUNE_VAE_CONV, int(os.environ["F4_VAE_CONV"]))
+        print(f"TD_TUNE_VAE_CONV = {os.environ['F4_VAE_CONV']}", flush=True)
     if any(w.startswith("vae") for w in which):
         dec = WanVaeDecoder(vae_state_dict(), dtype=torch.bfloat16, device=DEV)          # HIP backend
         for tag, (h, w) in (("vae480", (480, 832)), ("vae720", (720, 1280))):

@@ -19,28 +19,9 @@
 // Epilogue: + bias (fp32) -> bf16 -> optional residual add in bf16 (the reference's rounding points) -> channels-last store;
 // for the time up-sampler the output channel n lands in frame 2 t + n / (N/2), channel n % (N/2).
 #include "td_common.h"
+#include "vae_conv.h"
 #include <type_traits>
 
-struct VaeConvP {
-  const uint16_t* x;      // [B, Ti, Hi, Wi, Ci] bf16 (batch stride xs_b elements)
-  const uint16_t* w;      // [Co, taps * Ci] bf16, K ordered (dt, dh, dw, c)
-  const uint16_t* bias;   // [Co] or null
-  const uint16_t* res;    // same layout as y, or null
-  uint16_t* y;            // [B, To', Ho, Wo, Co'] bf16 (batch stride ys_b elements)
-  int64_t xs_b, ys_b;
-  int B, Ti, Hi, Wi, Ci;
-  int To, Ho, Wo, Co;     // the GEMM's output grid (To = Ti; Ho = Hi or 2 Hi)
-  int kt, kh, kw;
-  int up2;                // 1: nearest x2 up-sampling of H, W before the convolution
-  int interleave;         // 1: time up-sampler output mapping (y has 2 To frames of Co / 2 channels)
-  int64_t M;              // B * To * Ho * Wo
-  int halves;             // taps * Ci / 32
-  int st, ss;             // output strides in time / space (the encoder's down-samplers: 2); 1 = plain
-  int t_fast;             // row-tile kernel: tile order (w tiles, FRAMES, rows) instead of (w tiles, rows, frames)
-  int pt, ph, pw;         // zero frames / rows / columns on the LEFT (kt - 1, kh / 2, kw / 2 = causal in time, centred in space;
-                          // the encoder's ZeroPad2d((0, 1, 0, 1)) and its unpadded stride-2 time convolution pass 0); whatever the
-                          // output grid reaches beyond the right edge is zero too
-};
 
 #define VC_BM 256
 #define VC_ROWB 128       // bytes per LDS row (64 bf16)
@@ -524,6 +505,14 @@ extern "C" int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void*
   hipStream_t st = (hipStream_t)stream;
   const bool v2_ok = plain && (Co % 16 == 0 || Co <= 32) && (!interleave || (Co / 2) % (32 * nbw) == 0) &&
                      (int64_t)y_batch_stride % 8 == 0;
+  {
+    // DEFAULT for the 3x3 spatial kernels with C_out % 96 == 0 (every heavy convolution of the VAE): the 2-D-tile LDS-DMA
+    // kernel (vae_conv3.hip), frames-first tile order (0, 8); 7 = tiles of a frame first.  2 (and the experiment values 3-6)
+    // = the row-tile kernel below, which also takes everything conv3 does not: 1x1 / (3,1,1) kernels, the 3-channel head,
+    // the encoder's strided down-samplers.  Measured (profiles/r04_conv3_ab.txt): 480p decode 0.394 -> 0.289 s.
+    const int tv = td_tuning(TD_TUNE_VAE_CONV);
+    if ((tv == 0 || tv == 7 || tv == 8) && vae_conv3_eligible(p, plain)) return vae_conv3_launch(p, tv == 7 ? 0 : 1, st);
+  }
   if (td_tuning(TD_TUNE_VAE_CONV) != 1 && v2_ok) {
     const bool wide = nbw == 3 && td_tuning(TD_TUNE_VAE_CONV) == 3;   // measured slower (549 vs 700 TFLOP/s at 480p): opt-in
     const int bm = wide ? 512 : 256;

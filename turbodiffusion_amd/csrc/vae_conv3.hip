@@ -1,0 +1,305 @@
+// f4 — the 3x3(x3) convolutions of the Wan VAE as an implicit GEMM on a TWO-DIMENSIONAL output tile, staged by LDS-DMA
+// (round 4; the round-3 verdict's "two-image-row tile", taken further).  Same semantics and rounding points as the row-tile
+// kernel in vae_conv.hip (reference: rcm/tokenizers/wan2pt1.py:37-55 CausalConv3d, :94-131 Resample's up-sampling convolution,
+// :195-209 ResidualBlock): fp32 accumulation on the bf16 matrix pipe, + bias in fp32, one rounding to bf16, optional residual
+// added in bf16.  The summation order over K differs from the row-tile kernel's (chunks of 32 channels instead of 64): equal
+// to fp32 rounding, not bit-identical.
+//
+// Why.  The row-tile kernel (one workgroup = 256 columns of ONE image row x 96 channels) pays, per 72 MFMAs of a wave, 33 KB of
+// gathered activations and 36 KB of weights through VGPRs and ds_write_b128 (the LDS store path: ~79 B/clk per CU, MI355X
+// guide §LDS) — with two workgroups per CU that path is busy ~75 % of the time the matrix pipe would need, and the counters
+// show the pipe 0.37 busy (profiles/r04_pmc_sq.json).  It also tiles rows of 104 * 2^k columns with 256-column segments: 19 % of
+// the workgroup slots at every level (59 % at the first) multiply nothing.
+//
+// Here: one workgroup (512 threads, 8 waves, 2 waves per SIMD) owns R image rows x Wt columns = 512 output positions of one
+// frame (Wt = 16 / 32 / 64 chosen per launch so that the image divides evenly: 832 = 13 x 64, 416 = 13 x 32, ...) x 96 output
+// channels; a wave owns 64 positions x 96 channels (2 x 3 v_mfma_f32_32x32x16_bf16 blocks, as before).
+//   * A step = (source frame dt, 32-channel chunk c): the haloed source tile, (R + 2) x (Wt + 2) pixels x 64 bytes, is brought
+//     to LDS ONCE by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPRs, no store path) and serves all NINE spatial taps — a tap
+//     is the same LDS tile read at a shifted row, the shift folded into per-lane fragment addresses computed once per kernel.
+//     Gather traffic per output drops from 9 x (halo 1.01) to 1.29 x per (dt, c); pixels outside the image are never fetched
+//     (their LDS rows are zeroed once; their DMA lanes point past the buffer's end), nearest x2 up-sampling is folded into the
+//     DMA addresses.
+//   * dh step = the weights of three taps (dh, dw = 0..2) x 96 channels x 32 input channels = 18 KB, by LDS-DMA, two stages.
+//   * ONE s_barrier per dh step (36 MFMAs per wave), placed before the step's last k-slot: by then every fragment of the step
+//     has been read and the wave's own DMA pieces of the next stage have landed (s_waitcnt vmcnt(0)); after it the first
+//     fragments of the next step are fetched while the last six MFMAs of this one run.  The next A tile arrives in thirds
+//     under the three dh steps of the current one (two A stages).
+//   * LDS: 2 x 42 KB (A) + 2 x 18 KB (B) = 120 KB, one workgroup per CU; 64-byte rows with the 16-byte slot XOR-swizzled by
+//     (row >> 2) & 3 (applied on the GLOBAL side of the DMA; the LDS image is lane-linear) — conflict-free ds_read_b128 fragments.
+//   * epilogue through LDS (the staging area re-used): every thread owns one position's 96 contiguous channels.
+// Tile order: XCD-contiguous (xcd_remap), then either the tiles of a frame before the next frame, or frames first.
+#include "td_common.h"
+#include "vae_conv.h"
+#include <type_traits>
+
+#define C3_NR 96
+#define C3_AROWS 672                      // >= (R + 2) (Wt + 2) for the three tile shapes (660 / 612 / 612), in 16-row DMA pieces
+#define C3_ASTAGE (C3_AROWS * 64)
+#define C3_BROWS 288                      // 3 taps x 96 channels
+#define C3_BSTAGE (C3_BROWS * 64)
+#define C3_LDS (2 * C3_ASTAGE + 2 * C3_BSTAGE)
+#define C3_OOB 0x80000000u
+
+typedef __attribute__((address_space(3))) void* c3_lptr_t;
+
+struct Conv3P {
+  VaeConvP c;
+  int lw;                                 // log2(Wt)
+  int tiles_w, tiles_h, tiles_n;
+  int order;
+};
+
+#define C3_FENCE()                            \
+  {                                           \
+    __builtin_amdgcn_sched_barrier(0);        \
+    asm volatile("" ::: "memory");            \
+  }
+
+__global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
+  const VaeConvP& p = P.c;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, hi = lane >> 5;
+  const int lw = P.lw, Wt = 1 << lw, R = 512 >> lw, RS = Wt + 2, AR = (R + 2) * RS;
+
+  uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = (int)(vid % P.tiles_n) * C3_NR;
+  vid /= P.tiles_n;
+  int t, wt, ht, b;
+  if (P.order) {
+    t = (int)(vid % p.To); vid /= p.To;
+    wt = (int)(vid % P.tiles_w); vid /= P.tiles_w;
+    ht = (int)(vid % P.tiles_h);
+    b = (int)(vid / P.tiles_h);
+  } else {
+    wt = (int)(vid % P.tiles_w); vid /= P.tiles_w;
+    ht = (int)(vid % P.tiles_h); vid /= P.tiles_h;
+    t = (int)(vid % p.To);
+    b = (int)(vid / p.To);
+  }
+  const int h0 = ht * R, w0 = wt * Wt;
+  const int64_t ktot = (int64_t)p.kt * 9 * p.Ci;
+  const uint16_t* xb = p.x + (int64_t)b * p.xs_b;
+  const int64_t frame = (int64_t)p.Hi * p.Wi * p.Ci;       // elements
+
+  // ---- DMA roles.  One piece = 16 rows x 64 B (lane -> row lane >> 2, physical slot lane & 3); wave w moves pieces w + 8 j ----
+  const int npieces = (AR + 15) >> 4;
+  uint32_t a_voff[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int e = wave + 8 * j, r = 16 * e + (lane >> 2);
+    uint32_t off = C3_OOB;
+    if (r < AR) {
+      const int tr = r / RS, tc = r - tr * RS;
+      const int hu = h0 - 1 + tr, wu = w0 - 1 + tc;
+      if (hu >= 0 && hu < p.Ho && wu >= 0 && wu < p.Wo) {
+        const int hs = p.up2 ? (hu >> 1) : hu, ws = p.up2 ? (wu >> 1) : wu;
+        off = (uint32_t)(((int64_t)hs * p.Wi + ws) * p.Ci) * 2u + ((uint32_t)((lane & 3) ^ ((r >> 2) & 3)) << 4);
+      }
+    }
+    a_voff[j] = off;
+  }
+  uint32_t b_voff[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    int r = 16 * (wave + 8 * j) + (lane >> 2);
+    if (r > C3_BROWS - 1) r = C3_BROWS - 1;                  // (pieces 18.. are never issued)
+    const int dw = r / C3_NR, n = n0 + (r - dw * C3_NR);
+    b_voff[j] = (uint32_t)(((int64_t)n * ktot + (int64_t)dw * p.Ci) * 2) + ((uint32_t)((lane & 3) ^ ((r >> 2) & 3)) << 4);
+  }
+  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(uint32_t)((int64_t)p.Co * ktot * 2), 0x00020000);
+  const int frame_bytes = (int)(uint32_t)(frame * 2);
+
+  // ---- fragment addresses (within a stage).  Output position q = 64 wave + 32 i + li -> tile (q >> lw, q & (Wt - 1)); tap
+  //      (dh, dw) reads the source tile's row (rr + dh) RS + cc + dw.  k-step ks: logical slot 2 ks + hi ----
+  uint32_t a_addr[9][2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int q = 64 * wave + 32 * i + li;
+    const int rr = q >> lw, cc = q & (Wt - 1);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const uint32_t row = (uint32_t)((rr + tap / 3) * RS + cc + tap % 3);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) a_addr[tap][i][ks] = row * 64u + ((uint32_t)((2 * ks + hi) ^ ((row >> 2) & 3u)) << 4);
+    }
+  }
+  uint32_t b_addr[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) b_addr[ks] = (uint32_t)li * 64u + ((uint32_t)((2 * ks + hi) ^ ((li >> 2) & 3)) << 4);
+
+  // ---- the A steps: valid source frames x 32-channel chunks ----
+  const int nc = p.Ci >> 5;
+  const int dt_lo = max(0, (p.kt - 1) - t);                  // frames before the first are zero: their steps are skipped
+  const int na = (p.kt - dt_lo) * nc;
+
+  // (dt, c) of an A step advance incrementally; the source frame's buffer descriptor is rebuilt per A step (SALU only)
+  auto rsrc_of = [&](int dt) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (int64_t)(t - (p.kt - 1) + dt) * frame), 0, frame_bytes, 0x00020000);
+  };
+  auto issue_a = [&](int stage, decltype(rsrc_b) rsrc_a, int c, int j) {      // piece j of the A step (frame of rsrc_a, chunk c)
+    if (wave + 8 * j < npieces)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (c3_lptr_t)(smem + stage * C3_ASTAGE + (wave + 8 * j) * 1024), 16,
+                                               a_voff[j], c * 64, 0, 0);
+  };
+  auto issue_b = [&](int stage, int dt, int c, int dh) {     // the three taps (dh, *) of (dt, c) -> B stage
+    const int soff = ((dt * 3 + dh) * 3 * p.Ci + c * 32) * 2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (wave + 8 * j < C3_BROWS / 16)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (c3_lptr_t)(smem + 2 * C3_ASTAGE + stage * C3_BSTAGE + (wave + 8 * j) * 1024),
+                                                 16, b_voff[j], soff, 0, 0);
+  };
+
+  // ---- zero both A stages once (rows outside the image stay zero: their DMA lanes are out of range) ----
+  for (int v = tid; v < 2 * C3_ASTAGE / 16; v += 512) *reinterpret_cast<uint4*>(smem + v * 16) = make_uint4(0u, 0u, 0u, 0u);
+  __syncthreads();
+  int dt_cur = dt_lo, c_cur = 0;
+  {
+    const auto r0 = rsrc_of(dt_lo);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) issue_a(0, r0, 0, j);
+    issue_b(0, dt_lo, 0, 0);
+  }
+
+  v16f acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][nb][r] = 0.f;
+  v8bf af[2][2], bfr[2][3];
+
+#define C3_LOAD(buf_, pa_, pb_, dh_, j_)                                                                                   \
+  {                                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                          \
+      af[buf_][i] = *reinterpret_cast<const v8bf*>(smem + (pa_) * C3_ASTAGE + a_addr[(dh_) * 3 + ((j_) >> 1)][i][(j_) & 1]); \
+    _Pragma("unroll") for (int nb = 0; nb < 3; ++nb)                                                                       \
+      bfr[buf_][nb] = *reinterpret_cast<const v8bf*>(smem + 2 * C3_ASTAGE + (pb_) * C3_BSTAGE +                            \
+                                                     (((j_) >> 1) * C3_NR + 32 * nb) * 64 + b_addr[(j_) & 1]);             \
+  }
+#define C3_MMA(buf_)                                                                                                       \
+  {                                                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                          \
+      _Pragma("unroll") for (int nb = 0; nb < 3; ++nb)                                                                     \
+        acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf_][i], bfr[buf_][nb], acc[i][nb], 0, 0, 0);             \
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  C3_LOAD(0, 0, 0, 0, 0)
+
+  auto a_step = [&](auto pa_c, int a) {
+    constexpr int PA = decltype(pa_c)::value;
+    const bool next_a = a + 1 < na;
+    int c_nx = c_cur + 1, dt_nx = dt_cur;
+    if (c_nx == nc) { c_nx = 0; ++dt_nx; }
+    const auto rsrc_nx = rsrc_of(next_a ? dt_nx : dt_cur);
+#pragma clang loop unroll(full)
+    for (int dh = 0; dh < 3; ++dh) {
+      const int PB = PA ^ (dh & 1);                          // parity of the dh step 3 a + dh
+      const bool next_step = dh < 2 || next_a;
+      // DMA: the next dh step's weights into the other B stage, a third of the next A tile into the other A stage (both
+      // were released by the barrier that ended the previous step)
+      if (dh < 2) issue_b(PB ^ 1, dt_cur, c_cur, dh + 1);
+      else if (next_a) issue_b(PB ^ 1, dt_nx, c_nx, 0);
+      if (next_a) { issue_a(PA ^ 1, rsrc_nx, c_nx, 2 * dh); issue_a(PA ^ 1, rsrc_nx, c_nx, 2 * dh + 1); }
+      C3_FENCE()
+#pragma clang loop unroll(full)
+      for (int j = 0; j < 6; ++j) {
+        if (j < 5) {
+          C3_LOAD((j + 1) & 1, PA, PB, dh, j + 1)
+        } else {
+          // every fragment of this step is in registers (or on its way: lgkmcnt) and this wave's pieces have landed
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          C3_FENCE()
+          __builtin_amdgcn_s_barrier();
+          C3_FENCE()
+          if (next_step) {
+            if (dh < 2) { C3_LOAD(0, PA, PB ^ 1, dh + 1, 0) }
+            else { C3_LOAD(0, PA ^ 1, PB ^ 1, 0, 0) }
+          }
+        }
+        C3_FENCE()
+        C3_MMA(j & 1)
+        C3_FENCE()
+      }
+    }
+    c_cur = c_nx;
+    dt_cur = dt_nx;
+  };
+  for (int a = 0; a < na; a += 2) {
+    a_step(std::integral_constant<int, 0>{}, a);
+    if (a + 1 < na) a_step(std::integral_constant<int, 1>{}, a + 1);
+  }
+
+  // ---- epilogue through LDS: O[512 positions][96 channels] bf16, row stride 208 bytes; a thread = one position ----
+  constexpr int OS = C3_NR * 2 + 16;
+  float bias_v[3];
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb) bias_v[nb] = p.bias ? bf16_bits_to_f32(p.bias[n0 + 32 * nb + li]) : 0.f;
+  __syncthreads();                                           // (every LDS read was before the last barrier already)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 64 * wave + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        *reinterpret_cast<uint16_t*>(smem + row * OS + (32 * nb + li) * 2) = (uint16_t)f32_to_bf16_bits(acc[i][nb][r] + bias_v[nb]);
+      }
+  __syncthreads();
+  const int h = h0 + (tid >> lw), w = w0 + (tid & (Wt - 1));
+  if (h < p.Ho && w < p.Wo) {
+    const int64_t o = (int64_t)b * p.ys_b + (((int64_t)t * p.Ho + h) * p.Wo + w) * p.Co + n0;
+    const char* orow = smem + tid * OS;
+#pragma unroll
+    for (int v = 0; v < C3_NR / 8; ++v) {
+      uint4 ov = *reinterpret_cast<const uint4*>(orow + 16 * v);
+      if (p.res) {
+        const uint4 rv = *reinterpret_cast<const uint4*>(p.res + o + 8 * v);
+        float x[8], c[8];
+        unpack8<TD_BF16>(ov, x);
+        unpack8<TD_BF16>(rv, c);
+        uint32_t qq[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qq[j] = f32_to_bf16_bits(x[j] + c[j]);
+        ov.x = qq[0] | (qq[1] << 16); ov.y = qq[2] | (qq[3] << 16); ov.z = qq[4] | (qq[5] << 16); ov.w = qq[6] | (qq[7] << 16);
+      }
+      *reinterpret_cast<uint4*>(p.y + o + 8 * v) = ov;
+    }
+  }
+}
+
+bool vae_conv3_eligible(const VaeConvP& p, bool plain) {
+  return plain && p.kh == 3 && p.kw == 3 && p.Ci % 32 == 0 && p.Co % C3_NR == 0 && !p.interleave && p.ys_b % 8 == 0 &&
+         (int64_t)p.Hi * p.Wi * p.Ci * 2 < (1ll << 31) && (int64_t)p.Co * p.kt * 9 * p.Ci * 2 < (1ll << 31);
+}
+
+int vae_conv3_launch(const VaeConvP& p, int order, hipStream_t st) {
+  Conv3P P;
+  P.c = p;
+  P.order = order;
+  // tile shape: fewest workgroups, then the smaller haloed tile
+  int64_t best = -1;
+  P.lw = 6;
+  for (int lw = 4; lw <= 6; ++lw) {
+    const int Wt = 1 << lw, R = 512 >> lw;
+    const int64_t cost = (int64_t)td_cdiv(p.Wo, Wt) * td_cdiv(p.Ho, R) * (3 * C3_BROWS + (R + 2) * (Wt + 2));
+    if (best < 0 || cost < best) { best = cost; P.lw = lw; }
+  }
+  const int Wt = 1 << P.lw, R = 512 >> P.lw;
+  P.tiles_w = (int)td_cdiv(p.Wo, Wt);
+  P.tiles_h = (int)td_cdiv(p.Ho, R);
+  P.tiles_n = p.Co / C3_NR;
+  const int64_t tiles = (int64_t)p.B * p.To * P.tiles_h * P.tiles_w * P.tiles_n;
+  TD_REQUIRE(tiles < (1ll << 31), TD_ERR_UNSUPPORTED, "td_vae_conv: %lld tiles", (long long)tiles);
+  static std::atomic<uint64_t> m3{0};
+  td_ensure_dyn_lds((const void*)vae_conv3_kernel, C3_LDS, m3);
+  vae_conv3_kernel<<<(unsigned)tiles, 512, C3_LDS, st>>>(P);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
