@@ -50,7 +50,7 @@ def _conv_ref(x, w, b, kt, kh, kw, res=None, up2=False, interleave=False):
 # two stages + unrolled multiply | 2-D tiles, frame-by-frame order
 @pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 6, 7])
 @pytest.mark.parametrize("case", ["3x3x3", "residual+tail", "up2", "time-interleave", "head", "1x3x3 Ci96", "wide rows", "time-interleave 192",
-                                  "up2 Co96", "tall", "two tiles each way"])
+                                  "up2 Co96", "tall", "two tiles each way", "head 96"])
 def test_vae_conv_kernel_vs_torch(K, case, kernel):
     """td_vae_conv (implicit GEMM on the bf16 matrix pipe, csrc/vae_conv.hip) against an fp32 torch convolution of the same
     bf16 inputs: within one bf16 step of the correctly rounded result."""
@@ -75,6 +75,8 @@ def test_vae_conv_kernel_vs_torch(K, case, kernel):
         B, T, H, W, Ci, Co, k, up2 = 2, 2, 9, 21, 192, 96, (1, 3, 3), True
     elif case == "tall":                                           # more rows than a 2-D tile is high, narrower than one is wide
         B, T, H, W, Ci, Co, res = 1, 4, 70, 11, 32, 96, True
+    elif case == "head 96":                                        # the decoder's last convolution: 96 -> 3 channels, ragged tiles
+        T, H, W, Ci, Co = 3, 21, 45, 96, 3
     elif case == "two tiles each way":                             # 2-D tiles: 3 x 2 tiles of 32 x 16 with ragged right / bottom edges
         B, T, H, W, Ci, Co = 1, 3, 37, 70, 64, 192
     x = torch.randn(B, T, H, W, Ci, generator=g).bfloat16()

@@ -27,18 +27,17 @@
 //     under the three dh steps of the current one (two A stages).
 //   * LDS: 2 x 42 KB (A) + 2 x 18 KB (B) = 120 KB, one workgroup per CU; 64-byte rows with the 16-byte slot XOR-swizzled by
 //     (row >> 2) & 3 (applied on the GLOBAL side of the DMA; the LDS image is lane-linear) — conflict-free ds_read_b128 fragments.
-//   * epilogue through LDS (the staging area re-used): every thread owns one position's 96 contiguous channels.
+//   * the MFMAs run as D = W . X^T, so a lane ends with one position's channels: 8-byte LDS stores in the epilogue, and the
+//     tile leaves in 16-byte chunks laid over the lanes in memory order (whole 128-byte lines per store / residual load).
 // Tile order: XCD-contiguous (xcd_remap), then either the tiles of a frame before the next frame, or frames first.
 #include "td_common.h"
 #include "vae_conv.h"
 #include <type_traits>
 
-#define C3_NR 96
 #define C3_AROWS 672                      // >= (R + 2) (Wt + 2) for the three tile shapes (660 / 612 / 612), in 16-row DMA pieces
 #define C3_ASTAGE (C3_AROWS * 64)
-#define C3_BROWS 288                      // 3 taps x 96 channels
-#define C3_BSTAGE (C3_BROWS * 64)
-#define C3_LDS (2 * C3_ASTAGE + 2 * C3_BSTAGE)
+#define C3_BSTAGE_OF(nb_) (3 * 32 * (nb_) * 64)   // 3 taps x 32 NB channels x 64 bytes
+#define C3_LDS_OF(nb_) (2 * C3_ASTAGE + 2 * C3_BSTAGE_OF(nb_))
 #define C3_OOB 0x80000000u
 
 typedef __attribute__((address_space(3))) void* c3_lptr_t;
@@ -56,7 +55,11 @@ struct Conv3P {
     asm volatile("" ::: "memory");            \
   }
 
+// NB = 32-channel blocks of the output tile: 3 (C_out % 96 == 0: every level of the VAE) | 1 (C_out <= 32: the 3-channel head, whose
+// weight rows past C_out are never fetched — their LDS rows are zeroed once)
+template <int NB>
 __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
+  constexpr int C3_NR = 32 * NB, C3_BROWS = 3 * C3_NR, C3_BSTAGE = C3_BSTAGE_OF(NB);
   const VaeConvP& p = P.c;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -105,9 +108,10 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     int r = 16 * (wave + 8 * j) + (lane >> 2);
-    if (r > C3_BROWS - 1) r = C3_BROWS - 1;                  // (pieces 18.. are never issued)
+    if (r > C3_BROWS - 1) r = C3_BROWS - 1;                  // (pieces past the slab are never issued)
     const int dw = r / C3_NR, n = n0 + (r - dw * C3_NR);
-    b_voff[j] = (uint32_t)(((int64_t)n * ktot + (int64_t)dw * p.Ci) * 2) + ((uint32_t)((lane & 3) ^ ((r >> 2) & 3)) << 4);
+    b_voff[j] = n < p.Co ? (uint32_t)(((int64_t)n * ktot + (int64_t)dw * p.Ci) * 2) + ((uint32_t)((lane & 3) ^ ((r >> 2) & 3)) << 4)
+                         : C3_OOB;
   }
   const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(uint32_t)((int64_t)p.Co * ktot * 2), 0x00020000);
   const int frame_bytes = (int)(uint32_t)(frame * 2);
@@ -154,8 +158,13 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
   };
 
   // ---- zero both A stages once (rows outside the image stay zero: their DMA lanes are out of range) ----
-  for (int v = tid; v < 2 * C3_ASTAGE / 16; v += 512) *reinterpret_cast<uint4*>(smem + v * 16) = make_uint4(0u, 0u, 0u, 0u);
-  __syncthreads();
+  //      interior tiles have no such rows and skip this (the stage's tail rows past AR are never read)
+  const bool partial_n = n0 + C3_NR > p.Co;                   // weight rows past C_out: zero rows of the B stages
+  if (h0 == 0 || w0 == 0 || h0 + R >= p.Ho || w0 + Wt >= p.Wo || partial_n) {
+    const int nz = partial_n ? (2 * C3_ASTAGE + 2 * C3_BSTAGE) / 16 : 2 * C3_ASTAGE / 16;
+    for (int v = tid; v < nz; v += 512) *reinterpret_cast<uint4*>(smem + v * 16) = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+  }
   int dt_cur = dt_lo, c_cur = 0;
   {
     const auto r0 = rsrc_of(dt_lo);
@@ -164,28 +173,28 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
     issue_b(0, dt_lo, 0, 0);
   }
 
-  v16f acc[2][3];
+  v16f acc[2][NB];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
+    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][nb][r] = 0.f;
-  v8bf af[2][2], bfr[2][3];
+  v8bf af[2][2], bfr[2][NB];
 
 #define C3_LOAD(buf_, pa_, pb_, dh_, j_)                                                                                   \
   {                                                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                          \
       af[buf_][i] = *reinterpret_cast<const v8bf*>(smem + (pa_) * C3_ASTAGE + a_addr[(dh_) * 3 + ((j_) >> 1)][i][(j_) & 1]); \
-    _Pragma("unroll") for (int nb = 0; nb < 3; ++nb)                                                                       \
+    _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                      \
       bfr[buf_][nb] = *reinterpret_cast<const v8bf*>(smem + 2 * C3_ASTAGE + (pb_) * C3_BSTAGE +                            \
                                                      (((j_) >> 1) * C3_NR + 32 * nb) * 64 + b_addr[(j_) & 1]);             \
   }
 #define C3_MMA(buf_)                                                                                                       \
   {                                                                                                                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                          \
-      _Pragma("unroll") for (int nb = 0; nb < 3; ++nb)                                                                     \
-        acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[buf_][i], bfr[buf_][nb], acc[i][nb], 0, 0, 0);             \
+      _Pragma("unroll") for (int nb = 0; nb < NB; ++nb)                                                                    \
+        acc[i][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[buf_][nb], af[buf_][i], acc[i][nb], 0, 0, 0);             \
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -202,11 +211,14 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
     for (int dh = 0; dh < 3; ++dh) {
       const int PB = PA ^ (dh & 1);                          // parity of the dh step 3 a + dh
       const bool next_step = dh < 2 || next_a;
-      // DMA: the next dh step's weights into the other B stage, a third of the next A tile into the other A stage (both
-      // were released by the barrier that ended the previous step)
+      // DMA: the next dh step's weights into the other B stage, then half of the next A tile into the other A stage (both were
+      // released by the barrier that ended the previous step).  The A pieces go out in the FIRST two dh steps and are only
+      // waited for at the end of the third: the wait at the end of a step covers this step's weight pieces (issued first, and
+      // VMEM returns in order) and leaves the A pieces issued after them in flight — vmcnt(3) after dh = 0 (every wave has
+      // pieces 0-2), vmcnt(1) after dh = 1 (a wave has one to three of pieces 3-5), vmcnt(0) after dh = 2.
       if (dh < 2) issue_b(PB ^ 1, dt_cur, c_cur, dh + 1);
       else if (next_a) issue_b(PB ^ 1, dt_nx, c_nx, 0);
-      if (next_a) { issue_a(PA ^ 1, rsrc_nx, c_nx, 2 * dh); issue_a(PA ^ 1, rsrc_nx, c_nx, 2 * dh + 1); }
+      if (next_a && dh < 2) { issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh); issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh + 1); issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh + 2); }
       C3_FENCE()
 #pragma clang loop unroll(full)
       for (int j = 0; j < 6; ++j) {
@@ -214,7 +226,9 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
           C3_LOAD((j + 1) & 1, PA, PB, dh, j + 1)
         } else {
           // every fragment of this step is in registers (or on its way: lgkmcnt) and this wave's pieces have landed
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          if (dh == 0 && next_a) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+          else if (dh == 1 && next_a) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the last A step issues no A pieces)
           C3_FENCE()
           __builtin_amdgcn_s_barrier();
           C3_FENCE()
@@ -236,46 +250,78 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
     if (a + 1 < na) a_step(std::integral_constant<int, 1>{}, a + 1);
   }
 
-  // ---- epilogue through LDS: O[512 positions][96 channels] bf16, row stride 208 bytes; a thread = one position ----
+  // ---- epilogue through LDS: O[512 positions][96 channels] bf16, row stride 208 bytes.  The MFMAs ran as D = W . X^T (weights
+  //      as the row operand): a lane holds ONE position (32 i + li) and, per block, channels 8 g + 4 hi + (0..3) for g = 0..3 —
+  //      four consecutive channels per 8-byte LDS store.  Then the tile goes out in 16-byte chunks with consecutive lanes on
+  //      consecutive chunks: a tile row of Wt positions x 96 channels is one contiguous run of memory, so every store (and
+  //      residual load) instruction covers whole 128-byte lines. ----
   constexpr int OS = C3_NR * 2 + 16;
-  float bias_v[3];
-#pragma unroll
-  for (int nb = 0; nb < 3; ++nb) bias_v[nb] = p.bias ? bf16_bits_to_f32(p.bias[n0 + 32 * nb + li]) : 0.f;
   __syncthreads();                                           // (every LDS read was before the last barrier already)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int nb = 0; nb < 3; ++nb)
+    for (int g = 0; g < 4; ++g) {
+      const int ch = 32 * nb + 8 * g + 4 * hi;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        if (!partial_n) {
+          const uint2 b4 = *reinterpret_cast<const uint2*>(p.bias + n0 + ch);
+          bv[0] = bf16_bits_to_f32(b4.x & 0xffffu); bv[1] = bf16_bits_to_f32(b4.x >> 16);
+          bv[2] = bf16_bits_to_f32(b4.y & 0xffffu); bv[3] = bf16_bits_to_f32(b4.y >> 16);
+        } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = 64 * wave + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        *reinterpret_cast<uint16_t*>(smem + row * OS + (32 * nb + li) * 2) = (uint16_t)f32_to_bf16_bits(acc[i][nb][r] + bias_v[nb]);
+          for (int e = 0; e < 4; ++e) bv[e] = n0 + ch + e < p.Co ? bf16_bits_to_f32(p.bias[n0 + ch + e]) : 0.f;
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        uint2 o2;
+        o2.x = f32_to_bf16_bits(acc[i][nb][4 * g + 0] + bv[0]) | (f32_to_bf16_bits(acc[i][nb][4 * g + 1] + bv[1]) << 16);
+        o2.y = f32_to_bf16_bits(acc[i][nb][4 * g + 2] + bv[2]) | (f32_to_bf16_bits(acc[i][nb][4 * g + 3] + bv[3]) << 16);
+        *reinterpret_cast<uint2*>(smem + (64 * wave + 32 * i + li) * OS + ch * 2) = o2;
+      }
+    }
   __syncthreads();
-  const int h = h0 + (tid >> lw), w = w0 + (tid & (Wt - 1));
-  if (h < p.Ho && w < p.Wo) {
-    const int64_t o = (int64_t)b * p.ys_b + (((int64_t)t * p.Ho + h) * p.Wo + w) * p.Co + n0;
-    const char* orow = smem + tid * OS;
+  const int64_t obase = (int64_t)b * p.ys_b + (int64_t)t * p.Ho * p.Wo * p.Co + n0;
+  if (!partial_n) {
+    constexpr int CPP = C3_NR / 8;                             // 16-byte chunks per position
 #pragma unroll
-    for (int v = 0; v < C3_NR / 8; ++v) {
-      uint4 ov = *reinterpret_cast<const uint4*>(orow + 16 * v);
-      if (p.res) {
-        const uint4 rv = *reinterpret_cast<const uint4*>(p.res + o + 8 * v);
-        float x[8], c[8];
-        unpack8<TD_BF16>(ov, x);
-        unpack8<TD_BF16>(rv, c);
-        uint32_t qq[8];
+    for (int it = 0; it < CPP; ++it) {
+      const int g = it * 512 + tid;                           // chunk: position g / CPP, channels 8 (g % CPP) ..
+      const int pos = g / CPP, ck = g - pos * CPP;
+      const int h = h0 + (pos >> lw), w = w0 + (pos & (Wt - 1));
+      if (h < p.Ho && w < p.Wo) {
+        const int64_t o = obase + ((int64_t)h * p.Wo + w) * p.Co + 8 * ck;
+        uint4 ov = *reinterpret_cast<const uint4*>(smem + pos * OS + 16 * ck);
+        if (p.res) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(p.res + o);
+          float x[8], c[8];
+          unpack8<TD_BF16>(ov, x);
+          unpack8<TD_BF16>(rv, c);
+          uint32_t qq[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qq[j] = f32_to_bf16_bits(x[j] + c[j]);
-        ov.x = qq[0] | (qq[1] << 16); ov.y = qq[2] | (qq[3] << 16); ov.z = qq[4] | (qq[5] << 16); ov.w = qq[6] | (qq[7] << 16);
+          for (int j = 0; j < 8; ++j) qq[j] = f32_to_bf16_bits(x[j] + c[j]);
+          ov.x = qq[0] | (qq[1] << 16); ov.y = qq[2] | (qq[3] << 16); ov.z = qq[4] | (qq[5] << 16); ov.w = qq[6] | (qq[7] << 16);
+        }
+        *reinterpret_cast<uint4*>(p.y + o) = ov;
       }
-      *reinterpret_cast<uint4*>(p.y + o + 8 * v) = ov;
+    }
+  } else {                                                   // a partial channel tile (the 3-channel head): element stores
+    const int h = h0 + (tid >> lw), w = w0 + (tid & (Wt - 1));
+    if (h < p.Ho && w < p.Wo) {
+      const int64_t o = obase + ((int64_t)h * p.Wo + w) * p.Co;
+      for (int c = 0; n0 + c < p.Co; ++c) {
+        float v = bf16_bits_to_f32(*reinterpret_cast<const uint16_t*>(smem + tid * OS + 2 * c));
+        if (p.res) v = round_bf16(v + bf16_bits_to_f32(p.res[o + c]));
+        p.y[o + c] = (uint16_t)f32_to_bf16_bits(v);
+      }
     }
   }
 }
 
 bool vae_conv3_eligible(const VaeConvP& p, bool plain) {
-  return plain && p.kh == 3 && p.kw == 3 && p.Ci % 32 == 0 && p.Co % C3_NR == 0 && !p.interleave && p.ys_b % 8 == 0 &&
+  return plain && p.kh == 3 && p.kw == 3 && p.Ci % 32 == 0 && (p.Co % 96 == 0 || p.Co <= 32) && !p.interleave &&
+         (p.ys_b % 8 == 0 || p.Co <= 32) &&
          (int64_t)p.Hi * p.Wi * p.Ci * 2 < (1ll << 31) && (int64_t)p.Co * p.kt * 9 * p.Ci * 2 < (1ll << 31);
 }
 
@@ -283,23 +329,29 @@ int vae_conv3_launch(const VaeConvP& p, int order, hipStream_t st) {
   Conv3P P;
   P.c = p;
   P.order = order;
+  const int nbw = p.Co <= 32 ? 1 : 3;
   // tile shape: fewest workgroups, then the smaller haloed tile
   int64_t best = -1;
   P.lw = 6;
   for (int lw = 4; lw <= 6; ++lw) {
     const int Wt = 1 << lw, R = 512 >> lw;
-    const int64_t cost = (int64_t)td_cdiv(p.Wo, Wt) * td_cdiv(p.Ho, R) * (3 * C3_BROWS + (R + 2) * (Wt + 2));
+    const int64_t cost = (int64_t)td_cdiv(p.Wo, Wt) * td_cdiv(p.Ho, R) * (9 * 32 * nbw + (R + 2) * (Wt + 2));
     if (best < 0 || cost < best) { best = cost; P.lw = lw; }
   }
   const int Wt = 1 << P.lw, R = 512 >> P.lw;
   P.tiles_w = (int)td_cdiv(p.Wo, Wt);
   P.tiles_h = (int)td_cdiv(p.Ho, R);
-  P.tiles_n = p.Co / C3_NR;
+  P.tiles_n = (int)td_cdiv(p.Co, 32 * nbw);
   const int64_t tiles = (int64_t)p.B * p.To * P.tiles_h * P.tiles_w * P.tiles_n;
   TD_REQUIRE(tiles < (1ll << 31), TD_ERR_UNSUPPORTED, "td_vae_conv: %lld tiles", (long long)tiles);
-  static std::atomic<uint64_t> m3{0};
-  td_ensure_dyn_lds((const void*)vae_conv3_kernel, C3_LDS, m3);
-  vae_conv3_kernel<<<(unsigned)tiles, 512, C3_LDS, st>>>(P);
+  static std::atomic<uint64_t> m3{0}, m1{0};
+  if (nbw == 3) {
+    td_ensure_dyn_lds((const void*)vae_conv3_kernel<3>, C3_LDS_OF(3), m3);
+    vae_conv3_kernel<3><<<(unsigned)tiles, 512, C3_LDS_OF(3), st>>>(P);
+  } else {
+    td_ensure_dyn_lds((const void*)vae_conv3_kernel<1>, C3_LDS_OF(1), m1);
+    vae_conv3_kernel<1><<<(unsigned)tiles, 512, C3_LDS_OF(1), st>>>(P);
+  }
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
