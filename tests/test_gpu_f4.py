@@ -47,8 +47,8 @@ def _conv_ref(x, w, b, kt, kh, kw, res=None, up2=False, interleave=False):
 
 
 # default (2-D tiles by LDS-DMA where eligible) | first kernel | row tiles (the former default) | 512-column row tiles | two LDS stages |
-# two stages + unrolled multiply | 2-D tiles, frame-by-frame order
-@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 6, 7])
+# two stages + unrolled multiply | 2-D tiles of 512 positions, frame-by-frame order / frames first | 2-D tiles of 256 positions
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4, 6, 7, 8, 9])
 @pytest.mark.parametrize("case", ["3x3x3", "residual+tail", "up2", "time-interleave", "head", "1x3x3 Ci96", "wide rows", "time-interleave 192",
                                   "up2 Co96", "tall", "two tiles each way", "head 96"])
 def test_vae_conv_kernel_vs_torch(K, case, kernel):

@@ -24,6 +24,7 @@ struct VaeConvP {
 };
 
 // vae_conv3.hip: eligible = plain geometry (stride 1, centred in space, causal in time), 3x3 in space, C_in % 32 == 0,
-// C_out % 96 == 0, no time-up-sampler mapping.  order: 0 = (n, w, h) tiles of a frame then the next frame; 1 = frames first.
+// C_out % 96 == 0 or <= 32, no time-up-sampler mapping.  order bit 0: 0 = (n, w, h) tiles of a frame then the next frame, 1 = frames
+// first; bit 1: 256-position tiles (16 x 16) with two workgroups per CU instead of 512-position tiles with one.
 bool vae_conv3_eligible(const VaeConvP& p, bool plain);
 int vae_conv3_launch(const VaeConvP& p, int order, hipStream_t st);

@@ -506,12 +506,17 @@ extern "C" int td_vae_conv_ex(const void* x, int64_t x_batch_stride, const void*
   const bool v2_ok = plain && (Co % 16 == 0 || Co <= 32) && (!interleave || (Co / 2) % (32 * nbw) == 0) &&
                      (int64_t)y_batch_stride % 8 == 0;
   {
-    // DEFAULT for the 3x3 spatial kernels with C_out % 96 == 0 (every heavy convolution of the VAE): the 2-D-tile LDS-DMA
-    // kernel (vae_conv3.hip), frames-first tile order (0, 8); 7 = tiles of a frame first.  2 (and the experiment values 3-6)
-    // = the row-tile kernel below, which also takes everything conv3 does not: 1x1 / (3,1,1) kernels, the 3-channel head,
-    // the encoder's strided down-samplers.  Measured (profiles/r04_conv3_ab.txt): 480p decode 0.394 -> 0.289 s.
+    // DEFAULT for the 3x3 spatial kernels with C_out % 96 == 0 or <= 32 (every heavy convolution of the VAE): the 2-D-tile
+    // LDS-DMA kernel (vae_conv3.hip), frames-first tile order.  0 = automatic tile size: 256 positions with two workgroups
+    // per CU unless the reduction is 384 channels x 27 taps deep (one's prologue / epilogue under the other's main loop pays
+    // -3...-6 % for the short reductions of the 96- / 192-channel levels, +3...+5 % for the deepest: profiles/r04_conv3_ab.txt);
+    // 8 / 9 = always 512 / 256 positions; 7 = 512, tiles of a frame first.  2 (and the experiment values 3-6) = the row-tile
+    // kernel below, which also takes everything conv3 does not: 1x1 / (3,1,1) kernels, the encoder's strided down-samplers.
     const int tv = td_tuning(TD_TUNE_VAE_CONV);
-    if ((tv == 0 || tv == 7 || tv == 8) && vae_conv3_eligible(p, plain)) return vae_conv3_launch(p, tv == 7 ? 0 : 1, st);
+    if ((tv == 0 || (tv >= 7 && tv <= 9)) && vae_conv3_eligible(p, plain)) {
+      const bool four = tv == 9 || (tv == 0 && (int64_t)Ci * kt * 9 < 384 * 27);
+      return vae_conv3_launch(p, (tv == 7 ? 0 : 1) | (four ? 2 : 0), st);      // bit 0: frames first; bit 1: 256-position tiles
+    }
   }
   if (td_tuning(TD_TUNE_VAE_CONV) != 1 && v2_ok) {
     const bool wide = nbw == 3 && td_tuning(TD_TUNE_VAE_CONV) == 3;   // measured slower (549 vs 700 TFLOP/s at 480p): opt-in

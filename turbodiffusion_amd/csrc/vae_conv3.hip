@@ -34,10 +34,11 @@
 #include "vae_conv.h"
 #include <type_traits>
 
-#define C3_AROWS 672                      // >= (R + 2) (Wt + 2) for the three tile shapes (660 / 612 / 612), in 16-row DMA pieces
-#define C3_ASTAGE (C3_AROWS * 64)
+// A stage rows: >= (R + 2) (Wt + 2), in 16-row DMA pieces.  8 waves (512 positions): 660 / 612 / 612 for 64 x 8 / 32 x 16 / 16 x 32;
+// 4 waves (256 positions): 324 for 16 x 16 — with it two A stages + two weight stages are 78 KB: TWO workgroups per CU
+#define C3_AROWS_OF(waves_) ((waves_) == 8 ? 672 : 336)
 #define C3_BSTAGE_OF(nb_) (3 * 32 * (nb_) * 64)   // 3 taps x 32 NB channels x 64 bytes
-#define C3_LDS_OF(nb_) (2 * C3_ASTAGE + 2 * C3_BSTAGE_OF(nb_))
+#define C3_LDS_OF(nb_, waves_) (2 * C3_AROWS_OF(waves_) * 64 + 2 * C3_BSTAGE_OF(nb_))
 #define C3_OOB 0x80000000u
 
 typedef __attribute__((address_space(3))) void* c3_lptr_t;
@@ -57,15 +58,20 @@ struct Conv3P {
 
 // NB = 32-channel blocks of the output tile: 3 (C_out % 96 == 0: every level of the VAE) | 1 (C_out <= 32: the 3-channel head, whose
 // weight rows past C_out are never fetched — their LDS rows are zeroed once)
-template <int NB>
+// WAVES = 8: one 120-KB workgroup per CU, 512 positions.  WAVES = 4: 256 positions as 16 x 16, 78 KB: two INDEPENDENT workgroups per
+// CU — one's prologue (first DMA) and epilogue (stores) run under the other's main loop, which a single resident workgroup
+// cannot do (≈ 10 µs per tile, a quarter of a 96-channel tile); it pays with the weights fetched per 4 waves instead of per 8.
+template <int NB, int WAVES>
 __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
   constexpr int C3_NR = 32 * NB, C3_BROWS = 3 * C3_NR, C3_BSTAGE = C3_BSTAGE_OF(NB);
+  constexpr int NT = 64 * WAVES, C3_ASTAGE = C3_AROWS_OF(WAVES) * 64;
+  constexpr int NBJ = (C3_BROWS / 16 + WAVES - 1) / WAVES;    // weight pieces per wave and dh step
   const VaeConvP& p = P.c;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, hi = lane >> 5;
-  const int lw = P.lw, Wt = 1 << lw, R = 512 >> lw, RS = Wt + 2, AR = (R + 2) * RS;
+  const int lw = P.lw, Wt = 1 << lw, R = NT >> lw, RS = Wt + 2, AR = (R + 2) * RS;
 
   uint32_t vid = xcd_remap(blockIdx.x, gridDim.x);
   const int n0 = (int)(vid % P.tiles_n) * C3_NR;
@@ -87,12 +93,12 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
   const uint16_t* xb = p.x + (int64_t)b * p.xs_b;
   const int64_t frame = (int64_t)p.Hi * p.Wi * p.Ci;       // elements
 
-  // ---- DMA roles.  One piece = 16 rows x 64 B (lane -> row lane >> 2, physical slot lane & 3); wave w moves pieces w + 8 j ----
+  // ---- DMA roles.  One piece = 16 rows x 64 B (lane -> row lane >> 2, physical slot lane & 3); wave w moves pieces w + WAVES j ----
   const int npieces = (AR + 15) >> 4;
   uint32_t a_voff[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    const int e = wave + 8 * j, r = 16 * e + (lane >> 2);
+    const int e = wave + WAVES * j, r = 16 * e + (lane >> 2);
     uint32_t off = C3_OOB;
     if (r < AR) {
       const int tr = r / RS, tc = r - tr * RS;
@@ -104,10 +110,11 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
     }
     a_voff[j] = off;
   }
-  uint32_t b_voff[3];
+  uint32_t b_voff[5];   // (NBJ <= 5.  A fixed bound on purpose: with `b_voff[NBJ]` the HOST pass of hipcc silently fails to
+                        // instantiate the kernel's stub — the library then carries undefined symbols; ROCm 7.2)
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    int r = 16 * (wave + 8 * j) + (lane >> 2);
+  for (int j = 0; j < NBJ; ++j) {
+    int r = 16 * (wave + WAVES * j) + (lane >> 2);
     if (r > C3_BROWS - 1) r = C3_BROWS - 1;                  // (pieces past the slab are never issued)
     const int dw = r / C3_NR, n = n0 + (r - dw * C3_NR);
     b_voff[j] = n < p.Co ? (uint32_t)(((int64_t)n * ktot + (int64_t)dw * p.Ci) * 2) + ((uint32_t)((lane & 3) ^ ((r >> 2) & 3)) << 4)
@@ -144,16 +151,16 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)(xb + (int64_t)(t - (p.kt - 1) + dt) * frame), 0, frame_bytes, 0x00020000);
   };
   auto issue_a = [&](int stage, decltype(rsrc_b) rsrc_a, int c, int j) {      // piece j of the A step (frame of rsrc_a, chunk c)
-    if (wave + 8 * j < npieces)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (c3_lptr_t)(smem + stage * C3_ASTAGE + (wave + 8 * j) * 1024), 16,
+    if (wave + WAVES * j < npieces)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (c3_lptr_t)(smem + stage * C3_ASTAGE + (wave + WAVES * j) * 1024), 16,
                                                a_voff[j], c * 64, 0, 0);
   };
   auto issue_b = [&](int stage, int dt, int c, int dh) {     // the three taps (dh, *) of (dt, c) -> B stage
     const int soff = ((dt * 3 + dh) * 3 * p.Ci + c * 32) * 2;
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      if (wave + 8 * j < C3_BROWS / 16)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (c3_lptr_t)(smem + 2 * C3_ASTAGE + stage * C3_BSTAGE + (wave + 8 * j) * 1024),
+    for (int j = 0; j < NBJ; ++j)
+      if (wave + WAVES * j < C3_BROWS / 16)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (c3_lptr_t)(smem + 2 * C3_ASTAGE + stage * C3_BSTAGE + (wave + WAVES * j) * 1024),
                                                  16, b_voff[j], soff, 0, 0);
   };
 
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
   const bool partial_n = n0 + C3_NR > p.Co;                   // weight rows past C_out: zero rows of the B stages
   if (h0 == 0 || w0 == 0 || h0 + R >= p.Ho || w0 + Wt >= p.Wo || partial_n) {
     const int nz = partial_n ? (2 * C3_ASTAGE + 2 * C3_BSTAGE) / 16 : 2 * C3_ASTAGE / 16;
-    for (int v = tid; v < nz; v += 512) *reinterpret_cast<uint4*>(smem + v * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int v = tid; v < nz; v += NT) *reinterpret_cast<uint4*>(smem + v * 16) = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
   }
   int dt_cur = dt_lo, c_cur = 0;
@@ -218,7 +225,11 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
       // pieces 0-2), vmcnt(1) after dh = 1 (a wave has one to three of pieces 3-5), vmcnt(0) after dh = 2.
       if (dh < 2) issue_b(PB ^ 1, dt_cur, c_cur, dh + 1);
       else if (next_a) issue_b(PB ^ 1, dt_nx, c_nx, 0);
-      if (next_a && dh < 2) { issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh); issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh + 1); issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh + 2); }
+      if constexpr (WAVES == 8) {
+        if (next_a && dh < 2) { issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh); issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh + 1); issue_a(PA ^ 1, rsrc_nx, c_nx, 3 * dh + 2); }
+      } else {   // four waves: a third per step, everything waited for at the end of its own step
+        if (next_a) { issue_a(PA ^ 1, rsrc_nx, c_nx, 2 * dh); issue_a(PA ^ 1, rsrc_nx, c_nx, 2 * dh + 1); }
+      }
       C3_FENCE()
 #pragma clang loop unroll(full)
       for (int j = 0; j < 6; ++j) {
@@ -226,8 +237,8 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
           C3_LOAD((j + 1) & 1, PA, PB, dh, j + 1)
         } else {
           // every fragment of this step is in registers (or on its way: lgkmcnt) and this wave's pieces have landed
-          if (dh == 0 && next_a) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-          else if (dh == 1 && next_a) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+          if (WAVES == 8 && dh == 0 && next_a) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+          else if (WAVES == 8 && dh == 1 && next_a) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (the last A step issues no A pieces)
           C3_FENCE()
           __builtin_amdgcn_s_barrier();
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
     constexpr int CPP = C3_NR / 8;                             // 16-byte chunks per position
 #pragma unroll
     for (int it = 0; it < CPP; ++it) {
-      const int g = it * 512 + tid;                           // chunk: position g / CPP, channels 8 (g % CPP) ..
+      const int g = it * NT + tid;                            // chunk: position g / CPP, channels 8 (g % CPP) ..
       const int pos = g / CPP, ck = g - pos * CPP;
       const int h = h0 + (pos >> lw), w = w0 + (pos & (Wt - 1));
       if (h < p.Ho && w < p.Wo) {
@@ -319,6 +330,12 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(const Conv3P P) {
   }
 }
 
+template <int NB, int WAVES> static void c3_go(const Conv3P& P, unsigned tiles, hipStream_t st) {
+  static std::atomic<uint64_t> mask{0};
+  td_ensure_dyn_lds((const void*)vae_conv3_kernel<NB, WAVES>, C3_LDS_OF(NB, WAVES), mask);
+  vae_conv3_kernel<NB, WAVES><<<tiles, 64 * WAVES, C3_LDS_OF(NB, WAVES), st>>>(P);
+}
+
 bool vae_conv3_eligible(const VaeConvP& p, bool plain) {
   return plain && p.kh == 3 && p.kw == 3 && p.Ci % 32 == 0 && (p.Co % 96 == 0 || p.Co <= 32) && !p.interleave &&
          (p.ys_b % 8 == 0 || p.Co <= 32) &&
@@ -328,30 +345,27 @@ bool vae_conv3_eligible(const VaeConvP& p, bool plain) {
 int vae_conv3_launch(const VaeConvP& p, int order, hipStream_t st) {
   Conv3P P;
   P.c = p;
-  P.order = order;
-  const int nbw = p.Co <= 32 ? 1 : 3;
+  P.order = order & 1;
+  const bool four = (order & 2) != 0;       // 256-position tiles (16 x 16), two workgroups per CU
+  const int nbw = p.Co <= 32 ? 1 : 3, npos = four ? 256 : 512;
   // tile shape: fewest workgroups, then the smaller haloed tile
   int64_t best = -1;
-  P.lw = 6;
-  for (int lw = 4; lw <= 6; ++lw) {
-    const int Wt = 1 << lw, R = 512 >> lw;
+  P.lw = four ? 4 : 6;
+  for (int lw = 4; lw <= (four ? 4 : 6); ++lw) {
+    const int Wt = 1 << lw, R = npos >> lw;
     const int64_t cost = (int64_t)td_cdiv(p.Wo, Wt) * td_cdiv(p.Ho, R) * (9 * 32 * nbw + (R + 2) * (Wt + 2));
     if (best < 0 || cost < best) { best = cost; P.lw = lw; }
   }
-  const int Wt = 1 << P.lw, R = 512 >> P.lw;
+  const int Wt = 1 << P.lw, R = npos >> P.lw;
   P.tiles_w = (int)td_cdiv(p.Wo, Wt);
   P.tiles_h = (int)td_cdiv(p.Ho, R);
   P.tiles_n = (int)td_cdiv(p.Co, 32 * nbw);
   const int64_t tiles = (int64_t)p.B * p.To * P.tiles_h * P.tiles_w * P.tiles_n;
   TD_REQUIRE(tiles < (1ll << 31), TD_ERR_UNSUPPORTED, "td_vae_conv: %lld tiles", (long long)tiles);
-  static std::atomic<uint64_t> m3{0}, m1{0};
-  if (nbw == 3) {
-    td_ensure_dyn_lds((const void*)vae_conv3_kernel<3>, C3_LDS_OF(3), m3);
-    vae_conv3_kernel<3><<<(unsigned)tiles, 512, C3_LDS_OF(3), st>>>(P);
-  } else {
-    td_ensure_dyn_lds((const void*)vae_conv3_kernel<1>, C3_LDS_OF(1), m1);
-    vae_conv3_kernel<1><<<(unsigned)tiles, 512, C3_LDS_OF(1), st>>>(P);
-  }
+  if (nbw == 3 && !four) c3_go<3, 8>(P, (unsigned)tiles, st);
+  else if (nbw == 3) c3_go<3, 4>(P, (unsigned)tiles, st);
+  else if (!four) c3_go<1, 8>(P, (unsigned)tiles, st);
+  else c3_go<1, 4>(P, (unsigned)tiles, st);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
