@@ -3,6 +3,7 @@ share cuda:0 and talk over gloo (RCCL refuses two ranks on one device); the coll
 from the 8-GPU run — sharding, packing, the gathered K/V layouts, the LUT against global pooled K and every HIP
 kernel are the production path (``turbodiffusion_amd.seqpar`` + ``WanModel``)."""
 import os
+import sys
 import socket
 
 import pytest
@@ -181,3 +182,21 @@ def test_seqpar_over_rccl_one_rank(attention):
     # to segments (and still replays bit-identically, asserted above); the error text is then printed for the record.
     print(f"\n[seqpar over RCCL, {attention}] whole-graph capture: mode = {ret['whole_mode']!r}, error = {ret['whole_error']!r}")
     assert ret["whole_is_one_graph"] == (ret["whole_error"] is None), dict(ret)
+
+
+@pytest.mark.gpu
+def test_capture_after_eager_collectives_survives_the_rccl_watchdog():
+    """graph.quiesce_collective_watchdog: an eager RCCL collective that completed just before a capture with collectives
+    inside stays on ProcessGroupNCCL's watchdog list; the capture pulls the communicator stream into capture mode and the
+    watchdog's next poll aborts the process (tools/rccl_capture_race.py reproduces it: leg "nodrain").  With the drain in
+    front of the capture — what GraphedModel does — the process lives and the replay is correct.  The undrained leg's outcome
+    is printed, not asserted (a torch that guards this itself would make it pass)."""
+    import subprocess
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rccl_capture_race.py")
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    good = subprocess.run([sys.executable, tool, "drain"], capture_output=True, text=True, timeout=300, env=env)
+    assert good.returncode == 0 and "replay correct = True" in good.stdout, (good.stdout[-500:], good.stderr[-1500:])
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    bad = subprocess.run([sys.executable, tool, "nodrain"], capture_output=True, text=True, timeout=300, env=env)
+    print(f"\n[RCCL watchdog vs capture] without the drain: exit code {bad.returncode} "
+          f"({'captured-event abort' if 'capturing stream' in bad.stderr else 'no abort on this stack'})")

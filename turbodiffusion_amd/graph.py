@@ -22,6 +22,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 
 
@@ -97,6 +99,36 @@ class SegmentRecorder:
     @property
     def n_segments(self):
         return sum(1 for k, _ in self.chain if k == "graph")
+
+
+def quiesce_collective_watchdog(group=None):
+    """Call right before a hipGraph capture that will contain RCCL collectives.  torch's ProcessGroupNCCL keeps every EAGER
+    collective's Work in a list that its watchdog thread polls every 100 ms (``hipEventQuery`` on the Work's end event, which
+    was recorded on the communicator's own stream) until the Work is complete, then drops it.  A capture pulls that same
+    communicator stream into capture mode at its first collective; if the watchdog then polls a leftover eager Work — one
+    that finished milliseconds before the capture began, e.g. the warm-up forward's — HIP answers ``hipErrorCapturedEvent``
+    ("operation not permitted on an event last recorded in a capturing stream"), the watchdog thread throws and the process
+    aborts.  Seen once in the 1-rank RCCL test on the MI355X box (round 4; a toy forward whose capture lasts tens of ms: a
+    narrow window) — with a full-size forward the capture lasts about a second and the poll would land in it every time.
+    This torch build has no guard of its own (no "pending event queries" wait in ``capture_begin``) and exposes no way to ask
+    whether the list is empty, so: finish all device work, then give the watchdog a few of its periods to retire it
+    (``TD_SP_WATCHDOG_DRAIN_S``, default 0.4 s; once per captured input signature).  Works issued DURING a capture are not
+    put on that list by torch (it checks the current stream's capture status), so nothing new appears until the capture ends."""
+    import time
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 0.0
+        g = group if group is not None and not type(group).__name__ == "EmulatedGroup" else None
+        if "nccl" not in str(dist.get_backend(g)):
+            return 0.0
+    except Exception:
+        return 0.0
+    torch.cuda.synchronize()
+    t = float(os.environ.get("TD_SP_WATCHDOG_DRAIN_S", "0.4"))
+    if t > 0:
+        time.sleep(t)
+    return t
 
 
 _AGREE_SEQ = {}   # per group: how many capture outcomes have been exchanged (identical on every rank: same code path)
@@ -218,6 +250,7 @@ class GraphedModel(torch.nn.Module):
                     # ``work.wait()`` — stream-ordered work like any kernel.  No host work between the ~1100 launches of a
                     # rank's forward (the segmented form below re-issues ~6 collectives per layer from Python).
                     err = None
+                    quiesce_collective_watchdog(sp_group if real_group else None)   # no eager Work left for the watchdog to poll
                     try:
                         wg = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(wg, capture_error_mode="thread_local"):
