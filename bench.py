@@ -309,6 +309,10 @@ def main():
                     "split (its token shard, its launches, gathered buffers of the real size filled with copies of its own shard, "
                     "no communication) and report the measured per-rank time beside a modelled wire term (`emulated_rank`); "
                     "a measurement tool for DESIGN.md §6 — the line is marked and carries no vs_baseline")
+    ap.add_argument("--rccl-one-rank", action="store_true", help="ONE GPU: run the sequence-parallel code path over a REAL 1-rank "
+                    "RCCL communicator (torch.distributed 'nccl', world size 1): every collective of the multi-GPU forward is "
+                    "issued, captured inside the forward's hipGraph and replayed for real — all a one-GPU box can host of the "
+                    "N-GPU run.  The line is marked (`rccl_one_rank`) and carries no vs_baseline")
     ap.add_argument("--collect-traffic", action="store_true", help="N = 1: collect `roofline.traffic` / `roofline_attention.traffic` in "
                     "THIS run (two rocprofv3 --pmc child passes over one eager DiT forward after the timed region, ~40 s each) "
                     "instead of reading the committed counter summary")
@@ -420,6 +424,19 @@ def main():
         from turbodiffusion_amd import seqpar
         for m_ in filter(None, (net, net_low)):
             seqpar.enable(m_, seqpar.EmulatedGroup(*emu))
+    if args.rccl_one_rank:
+        assert world == 1 and emu is None and sp == 1, "--rccl-one-rank runs on ONE GPU, alone"
+        from turbodiffusion_amd import seqpar
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        for m_ in filter(None, (net, net_low)):
+            seqpar.enable(m_, dist.group.WORLD)
 
     w, h = RES[args.res]
     lat_shape = (1, 16, 21, h // 8, w // 8)  # 81 frames -> 21 latent frames, VAE 8x spatial
@@ -778,6 +795,18 @@ def main():
             res["launch_mode"] = "hipGraph replay: " + run_net.sp_graph_mode + "; kernel events from one eager video after the timed region"
             if getattr(run_net, "sp_whole_graph_error", None):
                 res["sp_whole_graph_error"] = run_net.sp_whole_graph_error
+        if args.rccl_one_rank:
+            res["metric"] = "ONE-RANK RCCL rig: " + res["metric"]
+            res["vs_baseline"] = None
+            res["config"]["parallelism"] = "the sequence-parallel path over a 1-rank RCCL communicator on one GPU"
+            res["rccl_one_rank"] = {
+                "backend": dist.get_backend(), "graph_mode": getattr(run_net, "sp_graph_mode", None) if use_graph else "eager",
+                "whole_graph_error": getattr(run_net, "sp_whole_graph_error", None) if use_graph else None,
+                "dit_step_ms": per_video * 1e3 / args.num_steps,
+                "what": "every collective of the N-GPU forward (smooth-K mean, the K-side all-gather per head group and layer, the "
+                        "head output's gather) issued on a real RCCL communicator of ONE rank, captured inside the forward's "
+                        "hipGraph and replayed; the difference to the single-GPU line is the sharded path's own overhead "
+                        "(pack kernels, gathered-layout reads, RCCL's copy kernels)"}
         if emu is not None:
             from turbodiffusion_amd.seqpar import PackLayout
             spo = net.seq_parallel.sp
@@ -838,7 +867,7 @@ def main():
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or args.rccl_one_rank:
         dist.destroy_process_group()
 
 

@@ -89,6 +89,21 @@ def test_bench_emulated_rank_reports_compute_and_wire_terms():
     assert "one hipGraph" in r["launch_mode"], r["launch_mode"]
 
 
+def test_bench_one_rank_rccl_rig_captures_the_collectives_at_full_token_count():
+    """--rccl-one-rank: the sequence-parallel forward over a REAL (one-rank) RCCL communicator at the full 32 760 tokens (two
+    layers): every all-gather issued, captured inside ONE hipGraph — a capture that stays open long enough for the process
+    group's watchdog to poll in it (graph.quiesce_collective_watchdog) — and replayed for every DiT step of the videos."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--rccl-one-rank", "--steps", "2", "--warmup", "1",
+                          "--layers", "2", "--no-cpu-baseline", "--no-box-calibration"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    o = r["rccl_one_rank"]
+    assert r["metric"].startswith("ONE-RANK RCCL") and r["vs_baseline"] is None and o["backend"] == "nccl"
+    assert o["whole_graph_error"] is None and "one hipGraph" in o["graph_mode"], o
+    assert o["dit_step_ms"] > 0 and "one hipGraph" in r["launch_mode"]
+
+
 def test_bench_collects_its_traffic_counters_in_the_run():
     """--collect-traffic: `roofline.traffic` from two rocprofv3 --pmc child passes of THIS run instead of the committed summary."""
     import shutil
