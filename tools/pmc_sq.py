@@ -22,7 +22,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEEP = ("gemm_w8a8_fi_kernel", "gemm_w8a8_kernel", "gemm_w8a8_m32_kernel", "attn_kernel", "attn_i8_q64_kernel",
-        "vae_conv2_kernel", "vae_conv_kernel", "gemm_bf16_kernel", "ln_apply_quant_kernel", "qk_norm_rope_kernel",
+        "vae_conv3_kernel", "vae_conv2_kernel", "vae_conv_kernel", "vae_chan_rms_kernel", "gemm_bf16_kernel", "ln_apply_quant_kernel", "qk_norm_rope_kernel",
         "sage_quant_pool_kernel", "linear_out_kernel", "linear_kv_partial_kernel")
 N_SIMD = 1024
 N_XCD = 8
