@@ -197,6 +197,9 @@ def test_capture_after_eager_collectives_survives_the_rccl_watchdog():
     good = subprocess.run([sys.executable, tool, "drain"], capture_output=True, text=True, timeout=300, env=env)
     assert good.returncode == 0 and "replay correct = True" in good.stdout, (good.stdout[-500:], good.stderr[-1500:])
     env = dict(os.environ, MASTER_PORT=str(_free_port()))
-    bad = subprocess.run([sys.executable, tool, "nodrain"], capture_output=True, text=True, timeout=300, env=env)
-    print(f"\n[RCCL watchdog vs capture] without the drain: exit code {bad.returncode} "
-          f"({'captured-event abort' if 'capturing stream' in bad.stderr else 'no abort on this stack'})")
+    try:      # informational leg: whatever it does (abort, pass, hang) must not fail the suite
+        bad = subprocess.run([sys.executable, tool, "nodrain"], capture_output=True, text=True, timeout=120, env=env)
+        print(f"\n[RCCL watchdog vs capture] without the drain: exit code {bad.returncode} "
+              f"({'captured-event abort' if 'capturing stream' in bad.stderr else 'no abort on this stack'})")
+    except subprocess.TimeoutExpired:
+        print("\n[RCCL watchdog vs capture] without the drain: no exit within 120 s (killed)")
