@@ -9,7 +9,8 @@ variants:
   no_finalize     td_row_stats_finalize (4 launches per layer) returns its warm-up result
   no_topk         td_sla_topk returns its warm-up LUT
   no_qpool        td_sage_quant_pool returns its warm-up outputs (both Q and K side)
-  no_linear       the linear branch's two passes (kv, out) return their warm-up outputs"""
+  no_linear       the linear branch's two passes (kv, out) return their warm-up outputs
+  no_norm_rope    td_qk_norm_rope (q and k) returns its warm-up outputs"""
 import os
 import sys
 import time
@@ -44,6 +45,8 @@ VARIANTS = {
     "no_topk": ["sla_topk"],
     "no_qpool": ["sage_quant_pool"],
     "no_linear": ["sla_linear_kv", "sla_linear_out_t"],
+    "no_norm_rope": ["qk_norm_rope"],          # the ceiling of folding norm + RoPE into the kernels that read q / k next
+    "no_norm_rope_no_qpool": ["qk_norm_rope", "sage_quant_pool"],
 }
 
 
