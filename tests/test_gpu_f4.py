@@ -462,6 +462,20 @@ def test_prompt_text_to_embedding_through_the_reference_entry_points(tmp_path):
     assert torch.equal(emb, direct)
     for b, n in enumerate(lens):
         assert not emb[b, n:].any() and emb[b, :n].abs().sum() > 0
+    # ... and prompt TEXT straight into the pipeline (the tokenizer + encoder object in the text-encoder slot)
+    from turbodiffusion_amd.pipeline import t2v
+    from turbodiffusion_amd.vae_decode import WanVaeDecoder, synthetic_state_dict as vae_sd
+    from turbodiffusion_amd.wan import WanModel
+    cfg = dict(model_type="t2v", dim=256, ffn_dim=512, num_heads=2, num_layers=2, text_dim=256, freq_dim=64, text_len=32)
+    with torch.device(DEV):
+        net = WanModel(attention_type="sagesla", sla_topk=0.5, quant_linear=True, **cfg)
+    own = net.state_dict()
+    net.load_from_float_state_dict({k: (v.to(DEV).to(own[k].dtype) if k in own else v.to(DEV)) for k, v in W.make_state_dict(cfg, 5).items()})
+    vae = WanVaeDecoder(vae_sd(dim=32, seed=21), dtype=torch.bfloat16, device=DEV)
+    v1 = t2v(TE.t5_encoder, net.eval(), vae, "a cat riding a horse", height=128, width=128, num_frames=13, seed=3, device=DEV)
+    idsp, maskp = HuggingfaceTokenizer(str(tmp_path), seq_len=32, clean="whitespace")("a cat riding a horse", return_mask=True)
+    v2 = t2v(TE.t5_encoder.model, net, vae, idsp, maskp, height=128, width=128, num_frames=13, seed=3, device=DEV)   # ids + mask form
+    assert v1.shape == (1, 3, 13, 128, 128) and torch.isfinite(v1).all() and torch.equal(v1, v2)
     TE.clear_umt5_memory()
     assert TE.t5_encoder is None
 

@@ -7,7 +7,9 @@ text embedding :73-76, sampling loop :95-140, VAE decode :141-149) on one GPU, a
     vae = WanVaeDecoder(...)         # turbodiffusion_amd.vae_decode    (f4)
     video = t2v(text, net, vae, ids, mask, height=480, width=832)
 
-Tokenisation (a HuggingFace tokenizer) and video file writing stay with the caller."""
+``ids`` may also be the prompt TEXT (a str or a list of str) when ``text_encoder`` is a ``text_encoder.UMT5EncoderModel`` (tokenizer +
+encoder, the reference's class of that name): ``t2v(UMT5EncoderModel(...), net, vae, "a cat surfing a wave")``.  Video file
+writing stays with the caller."""
 from __future__ import annotations
 
 from typing import Callable, Optional
@@ -22,12 +24,19 @@ def latent_shape(num_frames: int, height: int, width: int, latent_ch: int = 16):
     return (latent_ch, 1 + (num_frames - 1) // 4, height // 8, width // 8)
 
 
+def _embed(text_encoder, ids, mask):
+    """token ids (+ mask) -> encoder(ids, mask); prompt text -> encoder(texts) (UMT5EncoderModel tokenises itself)"""
+    if isinstance(ids, str) or (isinstance(ids, (list, tuple)) and ids and isinstance(ids[0], str)):
+        return text_encoder([ids] if isinstance(ids, str) else list(ids))
+    return text_encoder(ids, mask)
+
+
 @torch.no_grad()
 def t2v(text_encoder: Callable, net: Callable, vae, ids: torch.Tensor, mask: Optional[torch.Tensor] = None, *,
         height: int = 480, width: int = 832, num_frames: int = 81, num_steps: int = 4, sigma_max: float = 80.0,
         seed: int = 0, num_samples: int = 1, dtype=torch.bfloat16, device="cuda"):
     """Returns video [num_samples * B, 3, num_frames, height, width] in [0, 1] (the script's ``(1 + clamp(v, -1, 1)) / 2``)."""
-    emb = text_encoder(ids, mask).to(device=device, dtype=dtype)                  # [B, L_text, text_dim]
+    emb = _embed(text_encoder, ids, mask).to(device=device, dtype=dtype)          # [B, L_text, text_dim]
     emb = emb.repeat(num_samples, 1, 1)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
@@ -57,7 +66,7 @@ def i2v(text_encoder: Callable, net_high: Callable, net_low: Callable, vae_enc, 
         boundary: float = 0.9, seed: int = 0, dtype=torch.bfloat16, device="cuda"):
     """Image + prompt ids -> video in [0, 1]: the stages of ``inference/wan2.2_i2v_infer.py`` (text :96-99, conditioning
     :139-152, the loop with the expert switch at ``boundary`` :173-213, decode :214-222), both experts resident."""
-    emb = text_encoder(ids, mask).to(device=device, dtype=dtype)
+    emb = _embed(text_encoder, ids, mask).to(device=device, dtype=dtype)
     y = i2v_condition(vae_enc, image.to(device), num_frames, dtype)
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
