@@ -299,3 +299,27 @@ def test_input_broadcast_from_the_groups_first_rank():
     mp.spawn(_bcast_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     ones, twos = [[1.0] * 3] * 2, [[2.0] * 3] * 2
     assert ret[0] == (ones, ones, True, False) and ret[1] == (ones, twos, True, False), dict(ret)
+
+
+def _quiesce_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import time
+        from turbodiffusion_amd.graph import quiesce_collective_watchdog
+        t0 = time.perf_counter()
+        ret[rank] = (quiesce_collective_watchdog(dist.group.WORLD), time.perf_counter() - t0)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_watchdog_drain_is_a_no_op_off_rccl():
+    """graph.quiesce_collective_watchdog only waits where torch's NCCL (= RCCL) watchdog exists: no process group, a gloo group
+    and an emulated group return at once (the GPU leg: tests/test_gpu_seqpar.py)."""
+    from turbodiffusion_amd.graph import quiesce_collective_watchdog
+    from turbodiffusion_amd.seqpar import EmulatedGroup
+    assert quiesce_collective_watchdog() == 0.0 and quiesce_collective_watchdog(EmulatedGroup(0, 8)) == 0.0
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_quiesce_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert all(ret[r][0] == 0.0 and ret[r][1] < 0.2 for r in range(2)), dict(ret)
