@@ -74,11 +74,12 @@ def _attention(q, k, v, kind, sd, prefix, topk, dt):
 
 def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=None, mode="eager",
                 attention="original", quant=False, topk=0.1, act_dtype=torch.bfloat16, num_layers=None,
-                return_tokens=False, tap=None, clip_emb=None):
+                return_tokens=False, tap=None, clip_emb=None, on_layer=None):
     """``tap``: optional dict that receives the intermediates of block 0 (fixture generation only).
     ``return_tokens``: True -> the [B, L, dim] tokens after the last block; "both" -> (tokens, velocity) from ONE pass.
     ``sd`` may be any mapping with ``__getitem__`` / ``get`` / ``__contains__`` (make_golden_r04.LazyLayers generates a
-    14B-width model's layers one at a time)."""
+    14B-width model's layers one at a time).
+    ``on_layer(i, x)``: optional callback with the tokens after block ``i`` (fixture generation: depth profiles, progress)."""
     dt = act_dtype
     dim, H = cfg["dim"], cfg["num_heads"]
     D = dim // H
@@ -163,6 +164,8 @@ def wan_forward(sd, cfg, x_B_C_T_H_W, timesteps_B_T, crossattn_emb, y_B_C_T_H_W=
         h = O.modulate(ln(x), em[4], em[3])
         f = lin(p + ".ffn.2", lin(p + ".ffn.0", h, gelu=True))
         x = O.gated_residual(x, f, em[5])
+        if on_layer is not None:
+            on_layer(i, x)
         if getattr(sd, "evict_finished_layers", False):
             lin.cache = {k_: v_ for k_, v_ in lin.cache.items() if not k_.startswith(p + ".")}
 

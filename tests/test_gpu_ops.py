@@ -117,6 +117,27 @@ def test_gemm_fused_output_quant_bit_exact(K, m, n, k, bias, gelu, variant):
     assert torch.equal(q, q_ref), f"codes differ at {(q != q_ref).sum().item()} positions"
 
 
+@pytest.mark.parametrize("m,n,k,amp", [(1024, 2048, 256, 1.0), (1000, 1552, 384, 0.05), (4096, 8960, 1536, 1.0), (777, 512, 128, 30.0)])
+def test_gemm_fused_gelu_table_is_bit_identical_to_inline(K, m, n, k, amp):
+    """Round 5: the fused FFN GEMM looks the GELU of its (already bf16-rounded) value up in the device-built 65 536-entry table
+    (csrc/gemm_w8a8_fi.hip: g_gelu_tab_bf16) instead of evaluating it; TD_TUNE_GELU_TABLE = 1 keeps the inline form.  Same
+    codes and scales bit for bit over tiny (|x| ~ 1e-3: gelu(x) = x / 2), ordinary and saturating (|x| ~ 1e2: x or -0) ranges."""
+    g = torch.Generator().manual_seed(m + n + k)
+    x = (torch.randn(m, k, generator=g) * amp).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(n, generator=g) * 0.3 * amp).to(torch.bfloat16).to(DEV)
+    xq, xs = K.quant_i8_block128(x.to(DEV))
+    wq, ws = K.quant_i8_block128(w.to(DEV))
+    K.set_tuning(K.TUNE_GELU_TABLE, 1)
+    try:
+        q1, s1 = K.gemm_w8a8_quant(xq, xs, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True)
+    finally:
+        K.set_tuning(K.TUNE_GELU_TABLE, 0)
+    q0, s0 = K.gemm_w8a8_quant(xq, xs, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True)
+    assert torch.equal(s0, s1), "scales"
+    assert torch.equal(q0, q1), f"codes differ at {(q0 != q1).sum().item()} positions"
+
+
 @pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1000, 1536, 384), (300, 264, 256), (1111, 1544, 1280), (4096, 1536, 1536)])
 @pytest.mark.parametrize("bias,gated", [(True, True), (True, False), (False, True)])
 @pytest.mark.parametrize("variant", [4, 5])

@@ -66,6 +66,42 @@ __device__ __forceinline__ uint32_t f_swz(uint32_t row, uint32_t chunk) {
     __builtin_amdgcn_sched_barrier(0);        \
   }
 
+// GELU-tanh as a TABLE (QOUT epilogue, bf16; round 5).  The value the GELU is applied to has already been rounded to the
+// 16-bit output dtype (cast(acc) + bias -> cast, ops/core.py:408-412) and its result is rounded to it again
+// (wan2pt1.py:375 on a bf16 tensor): a function from 65 536 bit patterns to 65 536 bit patterns.  td_gelu_tanh costs 7
+// VALU + 2 quarter-rate transcendentals + 1.5 conversions per element, i.e. most of the 19 VALU-class instructions per
+// element that made ffn.0 (K = 1536: only 12 K blocks to amortise an epilogue over) the slowest GEMM of the block per FLOP
+// (profiles/r04_ffn0_epilogue_instruction_count.txt).  The table is td_gelu_tanh evaluated ON THE DEVICE for every bit
+// pattern (gelu_table_kernel, once per device) — bit-identical to the inline form by construction — and the epilogue
+// fetches its 128 KB into the stage buffers (free after the main loop) by LDS-DMA while the accumulators are converted,
+// then looks every element up with ds_read_u16_d16(_hi): 2 VALU (address) + 1 LDS gather per element.
+__device__ uint16_t g_gelu_tab_bf16[65536];
+
+__global__ void gelu_table_kernel(uint16_t* __restrict__ t) {
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  t[b] = (uint16_t)(pack2<TD_BF16>(td_gelu_tanh(bf16_bits_to_f32(b)), 0.f) & 0xffffu);
+}
+
+// the device's table, initialised on first use (eagerly and synchronously; a first use INSIDE a stream capture records the
+// init kernel into the graph instead and leaves the device marked uninitialised, so that the first eager use still does it)
+static const uint16_t* td_gelu_table_bf16(hipStream_t st) {
+  static std::atomic<uint64_t> ready{0};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  uint16_t* p = nullptr;
+  if (hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_gelu_tab_bf16)) != hipSuccess) return nullptr;
+  const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+  if (bit && (ready.load(std::memory_order_acquire) & bit)) return p;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  gelu_table_kernel<<<256, 256, 0, st>>>(p);
+  if (cs == hipStreamCaptureStatusNone) {
+    (void)hipStreamSynchronize(st);   // once per device: launches on OTHER streams may follow immediately
+    if (bit) ready.fetch_or(bit, std::memory_order_release);
+  }
+  return p;
+}
+
 // DBG = 1: profiling instantiation, records s_memtime at every group boundary of K blocks 8 and 9 for waves 0
 // and 4 of workgroup 0 (read back with td_debug_read; tools/gemm_trace.py)
 // SCHED bit 0: issue all 8 LDS-DMA pieces of stage kb+2 in groups 7 and 0 (right after the barrier) instead of
@@ -101,7 +137,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int tiles_m, int tiles_n, int group_m,
-    unsigned long long* __restrict__ dbg, float* __restrict__ QS, int64_t ldqs, const float* __restrict__ gate) {
+    unsigned long long* __restrict__ dbg, float* __restrict__ QS, int64_t ldqs, const float* __restrict__ gate,
+    const uint16_t* __restrict__ gelu_tab = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -369,6 +406,21 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 #endif
   if constexpr (QOUT) {
     F_MARK("qout_begin")
+    // TAB: the GELU as a table lookup (see g_gelu_tab_bf16).  The table's 128 KB replace the stage buffers: every wave must
+    // be past its last fragment read (barrier), then each wave fetches its eighth (16 pieces of 1 KB) by LDS-DMA — in
+    // flight while the accumulators are cast and biased below.
+    constexpr bool TAB = (EPI == TD_EPI_GELU_TANH) && (ODT == TD_BF16);
+    const bool use_tab = TAB && gelu_tab != nullptr;    // (kernel argument: workgroup-uniform)
+    if constexpr (TAB) {
+      if (use_tab) {
+        F_BARRIER()
+        const auto rsrc_t = __builtin_amdgcn_make_buffer_rsrc((void*)gelu_tab, 0, 131072, 0x00020000);
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_t, (lptr_t)(smem + (t * 8 + wave) * 1024), 16,
+                                                   (uint32_t)((t * 8 + wave) * 1024 + lane * 16), 0, 0, 0);
+      }
+    }
     // (1) the 16-bit results exactly as the plain epilogue would store them, kept in 64 VGPRs
     uint32_t pk[8][4][2];
     const bool tail = (m0 + F_BM > M) || (n0 + F_BN > N);
@@ -386,9 +438,47 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
           unpack2<ODT>(bb.x, bf[0], bf[1]);
           unpack2<ODT>(bb.y, bf[2], bf[3]);
         }
-        pk[i][j][0] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][0], accf[i][j][1], bf[0], bf[1]);
-        pk[i][j][1] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][2], accf[i][j][3], bf[2], bf[3]);
-        if (tail && !ok) { pk[i][j][0] = 0u; pk[i][j][1] = 0u; }  // rows/cols outside the matrix: zero-filled (load.hpp:24-47)
+        if (TAB && use_tab) {   // cast, + bias, cast — the GELU follows below
+          pk[i][j][0] = td_gemm_epilogue2<ODT, TD_EPI_NONE, HAS_BIAS>(accf[i][j][0], accf[i][j][1], bf[0], bf[1]);
+          pk[i][j][1] = td_gemm_epilogue2<ODT, TD_EPI_NONE, HAS_BIAS>(accf[i][j][2], accf[i][j][3], bf[2], bf[3]);
+        } else {
+          pk[i][j][0] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][0], accf[i][j][1], bf[0], bf[1]);
+          pk[i][j][1] = td_gemm_epilogue2<ODT, EPI, HAS_BIAS>(accf[i][j][2], accf[i][j][3], bf[2], bf[3]);
+        }
+        if (tail && !ok) { pk[i][j][0] = 0u; pk[i][j][1] = 0u; }  // rows/cols outside the matrix: zero-filled (load.hpp:24-47); gelu(0) = 0
+      }
+    }
+    if constexpr (TAB) {
+      if (use_tab) {
+        F_MARK("qout_table")
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the table have landed ...
+        F_BARRIER()                                        // ... and everyone's
+        const uint32_t tb = (uint32_t)(uintptr_t)(lptr_t)smem;
+        // Measured (tools/ffn0_epilogue_split.py, tools/gelu_table_ab.py -> profiles/r05_gelu_table.txt): the inline GELU costs
+        // a [32760 x 8960 x 1536] launch 80-85 us over the same fused quantiser without it, this form 68-75 — 1024 16-bit
+        // gathers per tile at ~7 LDS cycles each (32 random addresses on 32 banks) instead of 2 quarter-rate transcendentals
+        // + 7 VALU per element.  Splitting a wave's rows between the two forms (the two waves of a SIMD in opposite order, so
+        // that the LDS serves one while the transcendental unit serves the other) measured BETWEEN the two, not below: dropped.
+        // gfx950 runs with SRAM-ECC: a d16 load ZEROES the other half of its destination — two registers, OR-ed.
+#define F_GELU_LOOKUP(i0_)                                                                          \
+        _Pragma("unroll") for (int i = (i0_); i < (i0_) + 4; ++i) {                                 \
+          uint32_t glo[4][2], ghi[4][2];                                                            \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                         \
+              const uint32_t w = pk[i][j][e];                                                       \
+              const uint32_t a_lo = tb + ((w << 1) & 0x1fffeu), a_hi = tb + ((w >> 15) & 0x1fffeu); \
+              asm volatile("ds_read_u16 %0, %1" : "=v"(glo[j][e]) : "v"(a_lo));                     \
+              asm volatile("ds_read_u16_d16_hi %0, %1" : "=v"(ghi[j][e]) : "v"(a_hi));              \
+            }                                                                                       \
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                         \
+              asm volatile("" : "+v"(glo[j][e]), "+v"(ghi[j][e]));   /* uses stay behind the wait */ \
+              pk[i][j][e] = glo[j][e] | ghi[j][e];                                                  \
+            }                                                                                       \
+        }
+        F_GELU_LOOKUP(0) F_GELU_LOOKUP(4)
+#undef F_GELU_LOOKUP
       }
     }
     F_MARK("qout_amax")
@@ -410,7 +500,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     F_MARK("qout_exchange")
     // (3) the other half belongs to wave ^ 1: exchange through LDS (free: every wave is past the last barrier
     //     of the main loop, nothing reads or lands in the stages any more)
-    uint32_t* red = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* red = reinterpret_cast<uint32_t*>(smem + F_LDS + 2048);   // (behind the stages: those may hold the GELU table)
     if (lane == 0) red[wave] = m16;
     __syncthreads();
     m16 = max(red[wave], red[wave ^ 1]);
@@ -650,6 +740,10 @@ static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, co
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
   auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT>;
+  const uint16_t* gelu_tab = nullptr;
+  if constexpr (QOUT && EPI == TD_EPI_GELU_TANH && ODT == TD_BF16) {
+    if (td_tuning(TD_TUNE_GELU_TABLE) != 1) gelu_tab = td_gelu_table_bf16(st);   // 1 = the inline form (cross-check / A-B)
+  }
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), F_LDS + F_DUMP, attr_mask);
   const int tiles_m = (int)td_cdiv(m, F_BM), tiles_n = (int)td_cdiv(n, F_BN);
@@ -658,7 +752,7 @@ static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, co
   // profiling only: row stride of both int8 operands = k + pad (the caller's buffers must be that large)
   const int64_t ldab = k + td_tuning(TD_TUNE_GEMM_LDPAD);
   kern<<<nwg, 512, F_LDS + F_DUMP, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldab, ldab, ldd,
-                                tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr, qs, ldqs, gate);
+                                tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr, qs, ldqs, gate, gelu_tab);
   TD_CHECK_LAUNCH();
   return TD_OK;
 }
