@@ -28,9 +28,10 @@ videos in flight on two streams, enqueued step by step from one host thread (a s
 Workloads (BASELINE.json configs):
   turbo    TurboWan2.1-T2V-1.3B-480P as published: SageSLA top-k 0.1 + W8A8 linears + fused norms
            (the configuration the reference's 1.9 s / 0.526 video/s figure is quoted on)  [default]
-  c2       configs[1]: dense SageAttention INT8-QK (no sparsity), W8A8 linears, fused norms
-  c3       configs[2]: SageSLA top-k 0.1, bf16 library linears
-  original dense bf16 attention, bf16 library linears (the arithmetic of configs[0] on the GPU)
+  c2       configs[1]: dense SageAttention INT8-QK (no sparsity), bf16 linears on td_gemm_bf16 (`c2w8a8`: with W8A8)
+  c3       configs[2]: SageSLA top-k 0.1, bf16 linears on td_gemm_bf16
+  original dense bf16 attention, bf16 linears (the arithmetic of configs[0] on the GPU)
+``--config C2|C3|C4|C5`` selects workload + model + resolution (+ both experts for C5) of a BASELINE.json configuration in one flag.
 """
 import argparse
 import json
@@ -47,12 +48,63 @@ sys.path.insert(0, ROOT)
 _T0 = time.perf_counter()
 
 
+class NoProgressWatchdog:
+    """A multi-rank run that STOPS MAKING PROGRESS (a collective whose peer died, a graph replay that never returns) must end
+    with a message and a non-zero status, not sit until someone's outer timeout.  A limit on the time since the last sign of
+    progress — ``phase()`` and every timed video re-arm it — not on the whole run: a healthy long run (A14B at 720p on 8
+    ranks with two experts and the replica leg) is never cut, and the final JSON line is printed with the watchdog cancelled."""
+
+    def __init__(self):
+        self.timer, self.limit, self.rank = None, 0.0, 0
+
+    def start(self, limit_s, rank):
+        self.limit, self.rank = float(limit_s), rank
+        self.kick()
+
+    def _fire(self):
+        print(f"[bench] rank {self.rank}: no progress for {self.limit:.0f} s (TD_BENCH_HARD_TIMEOUT_S) — a collective or a graph "
+              f"replay is stuck; Python stacks follow", file=sys.stderr, flush=True)
+        import faulthandler
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        os._exit(3)
+
+    def kick(self):
+        if self.limit <= 0:
+            return
+        import threading
+        if self.timer is not None:
+            self.timer.cancel()
+        self.timer = threading.Timer(self.limit, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def cancel(self):
+        if self.timer is not None:
+            self.timer.cancel()
+        self.timer, self.limit = None, 0.0
+
+
+WATCHDOG = NoProgressWatchdog()
+
+
 def phase(msg):
     """Progress on stderr (rank 0), stamped with the seconds since start: a slow box and a hang must be
-    distinguishable from the log of a timed-out run (the 720p configurations of round 2, profiles/r02_head_note.txt)."""
+    distinguishable from the log of a timed-out run (the 720p configurations of round 2, profiles/r02_head_note.txt).
+    Every rank's no-progress watchdog is re-armed here."""
+    WATCHDOG.kick()
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.perf_counter() - _T0:8.1f} s] {msg}", file=sys.stderr, flush=True)
 
+# BASELINE.json's configurations as ONE flag each (SURVEY.md §8d; `--config C2` etc.; C1 = the reference's eager path on the
+# CPU = this line's `cpu_baseline`; on the GPU its arithmetic is `--workload original`).  Explicit flags still override.
+CONFIGS = {
+    "C1": dict(workload="original", model="Wan2.1-1.3B", res="480p"),
+    "C2": dict(workload="c2", model="Wan2.1-1.3B", res="480p"),
+    "C3": dict(workload="c3", model="Wan2.1-1.3B", res="480p"),
+    "C4": dict(workload="turbo", model="Wan2.1-14B", res="720p"),
+    "C5": dict(workload="turbo", model="Wan2.2-A14B", res="720p", two_experts=True),
+    "headline": dict(workload="turbo", model="Wan2.1-1.3B", res="480p"),
+}
 BASELINE_VIDEOS_PER_S = 1.0 / 1.9  # README.md:32,298 — TurboWan2.1-T2V-1.3B-480P, 1x RTX 5090
 # published TurboDiffusion latencies (s per video, 1x RTX 5090; BASELINE.md) for the other model/resolution pairs
 PUBLISHED_S = {("Wan2.1-1.3B", "480p"): 1.9, ("Wan2.1-14B", "480p"): 9.9, ("Wan2.1-14B", "720p"): 24.0,
@@ -64,8 +116,10 @@ RES = {"480p": (832, 480), "720p": (1280, 720)}
 WORKLOADS = {
     "turbo": dict(attention_type="sagesla", quant_linear=True,
                   desc="TurboWan2.1-T2V-1.3B-480P 4-step: SageSLA top-k 0.1 + W8A8 + fused norms"),
-    "c2": dict(attention_type="sage", quant_linear=True,
-               desc="Wan2.1-T2V-1.3B 480p 4-step: dense SageAttention INT8-QK + W8A8 + fused norms"),
+    "c2": dict(attention_type="sage", quant_linear=False,
+               desc="Wan2.1-T2V-1.3B 480p 4-step: dense SageAttention INT8-QK (no sparsity), bf16 linears (SURVEY §8d: C2)"),
+    "c2w8a8": dict(attention_type="sage", quant_linear=True,
+                   desc="Wan2.1-T2V-1.3B 480p 4-step: dense SageAttention INT8-QK + W8A8 + fused norms (rounds 2-4 ran this as 'c2')"),
     "c3": dict(attention_type="sagesla", quant_linear=False,
                desc="Wan2.1-T2V-1.3B 480p 4-step: SageSLA top-k 0.1, bf16 linears"),
     "original": dict(attention_type="original", quant_linear=False,
@@ -197,11 +251,53 @@ def traffic_of(kernels, prefixes):
     return (b / n) if n else None
 
 
-def cpu_baseline(cfg, lat_shape, topk, reps=3):
+def cpu_operator_times(cfg, cores):
+    """each operator's CPU restatement (oracle/ops_ref.py, oracle/sla_ref.py — the reference's arithmetic,
+    the port the parity tests hold the HIP kernels to) timed on the host cores on a bounded slice (4096 of the L rows; per-row
+    costs scale linearly, the attention entries carry their own L): ms per call, the cores used."""
+    from oracle import ops_ref as O, sla_ref as S
+    dim, H = cfg["dim"], cfg["num_heads"]
+    Mc = 4096
+    use = min(cores, 32)                 # the oracle's small per-block ops do not scale past a few dozen threads
+    torch.set_num_threads(use)
+
+    def ms(fn, reps=2):
+        fn()
+        t0 = time.time()
+        for _ in range(reps):
+            fn()
+        return (time.time() - t0) / reps * 1e3
+
+    g = torch.Generator().manual_seed(1)
+    xc = torch.randn(Mc, dim, generator=g).bfloat16()
+    wc = (torch.randn(dim, dim, generator=g) / math.sqrt(dim)).bfloat16()
+    xq_, xs_ = O.quant_block128(xc)
+    wq_, ws_ = O.quant_block128(wc)
+    z = torch.zeros(1, 1, dim)
+    H = min(H, 4)                        # attention entries: 4 heads (per-head cost is independent of the head count)
+    qc, kc, vc = [torch.randn(1, Mc, H, 128, generator=g).bfloat16() for _ in range(3)]
+    wp_, bp_ = torch.randn(128, 128, generator=g) * 0.05, torch.zeros(128)
+    ops = {
+        f"quant_block128 [{Mc}, {dim}]": ms(lambda: O.quant_block128(xc)),
+        f"gemm_w8a8 [{Mc} x {dim} x {dim}]": ms(lambda: O.gemm_w8a8(xq_, xs_, wq_, ws_)),
+        f"layernorm_fast + modulate [{Mc}, {dim}]": ms(lambda: O.modulate(O.layernorm_fast(xc, None, None, 1e-6), z, z)),
+        f"rmsnorm_fast [{Mc}, {dim}]": ms(lambda: O.rmsnorm_fast(xc, torch.ones(dim), 1e-6)),
+        f"sagesla_forward (block map + sparse INT8 attention + linear branch) L = {Mc}, H = {H}, top-k 0.1":
+            ms(lambda: S.sagesla_forward(qc, kc, vc, wp_, bp_, 0.1), 1),
+        f"scaled_dot_product_attention (C1's dense bf16) L = {Mc}, H = {H}":
+            ms(lambda: torch.nn.functional.scaled_dot_product_attention(qc.transpose(1, 2), kc.transpose(1, 2), vc.transpose(1, 2)), 1),
+    }
+    return {"rows": Mc, "cores": use, "ms_per_call": {k: round(v, 2) for k, v in ops.items()},
+            "what": "the oracle's CPU restatement of each accelerated operator (oracle/ops_ref.py, oracle/sla_ref.py) on a bounded slice"}
+
+
+def cpu_baseline(cfg, lat_shape, topk, reps=3, blocks=2, full_video=False):
     """The reference's ORIGINAL eager path (config C1: SDPA, plain Linear, eager norms) timed on the host cores on a bounded
-    sample of the same workload: the embeddings once (a forward with 0 blocks) and ONE block of ONE DiT step at the full
-    token count, ``reps`` times (BASELINE.md §3 asks for repetitions; a whole video on these cores is ~45 min, far beyond a
-    default bench run); only the per-block time (median of the repetitions) is extrapolated (x num_layers x 4 steps).
+    sample of the same workload, by BASELINE.md §3's protocol: (ii) a reduced-depth model — ``blocks`` = 2 of the 30 blocks,
+    so that the block -> block path is in the sample — of ONE DiT step at the full token count, ``reps`` = 3 repetitions, raw
+    times and the extrapolation (x num_layers / blocks x 4 steps) both in the record; the embeddings + head once (a forward
+    with 0 blocks), not extrapolated; (iii) the accelerated operators' CPU restatements in ``operators``; (i) one whole
+    4-step video timed once only with ``--cpu-full-video`` (tens of minutes on any host: beyond a default bench run).
 
     kind "reference": the reference's own ``WanModel`` (rcm/networks/wan2pt1.py:598-721), imported unmodified through
     oracle/ref_harness.py — only where the reference tree exists (``TD_REFERENCE_ROOT`` / ``/root/reference``: the build
@@ -212,8 +308,8 @@ def cpu_baseline(cfg, lat_shape, topk, reps=3):
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    c1 = dict(cfg, num_layers=1)
-    sd = W.make_state_dict(c1, seed=0, with_proj_l=False)
+    cb = dict(cfg, num_layers=blocks)
+    sd = W.make_state_dict(cb, seed=0, with_proj_l=False)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(lat_shape, generator=g)
     ctx = torch.randn(1, 512, cfg.get("text_dim", 4096), generator=g).bfloat16()
@@ -223,7 +319,7 @@ def cpu_baseline(cfg, lat_shape, topk, reps=3):
     if RH.available() and os.environ.get("TD_CPU_BASELINE", "") != "port":
         try:
             nets = {}
-            for nl in (0, 1):
+            for nl in (0, blocks):
                 cn = dict(cfg, num_layers=nl)
                 sdn = {k: v for k, v in sd.items() if nl or not k.startswith("blocks.")}
                 nets[nl] = RH.reference_wan_from_sd(cn, sdn, act_dtype=torch.bfloat16)
@@ -238,24 +334,45 @@ def cpu_baseline(cfg, lat_shape, topk, reps=3):
             if nets is not None:
                 nets[nl](x.bfloat16(), t, ctx)
             else:
-                W.wan_forward(sd, c1, x, t, ctx, mode="eager", act_dtype=torch.bfloat16, return_tokens=True, num_layers=nl)
+                W.wan_forward(sd, cb, x, t, ctx, mode="eager", act_dtype=torch.bfloat16, return_tokens=True, num_layers=nl)
         return time.time() - t0
 
     run(0)             # untimed: one-time costs (the reference's rope tables, first-call dispatch) are not the workload
     t_emb = run(0)
-    blks = []
+    raws = []
     for r in range(reps):
-        blks.append(run(1) - t_emb)
-        phase(f"cpu baseline ({kind}): block repetition {r + 1} of {reps}: {blks[-1]:.1f} s")
-    blk = sorted(blks)[len(blks) // 2]
+        raws.append(run(blocks))
+        phase(f"cpu baseline ({kind}): {blocks}-block forward, repetition {r + 1} of {reps}: {raws[-1]:.1f} s")
+    raw = sorted(raws)[len(raws) // 2]
+    blk = (raw - t_emb) / blocks
     video_s = 4 * (t_emb + cfg["num_layers"] * blk)
     what = ("the reference's own WanModel (rcm/networks/wan2pt1.py, imported unmodified; bf16 weights, SDPA + nn.Linear)"
             if kind == "reference" else "oracle eager bf16 DiT (SDPA + nn.Linear; the port pinned bit for bit to the reference)")
-    return {"value": 1.0 / video_s, "unit": "videos/s", "cores": cores, "kind": kind,
-            "embeddings_s": t_emb, "block_s": blk, "block_s_repetitions": blks,
-            "sample": f"{what}: embeddings + head {t_emb:.1f} s (measured once, not "
-                      f"extrapolated) + 1 of {cfg['num_layers']} blocks of 1 of 4 steps at full L, {reps} repetitions "
-                      f"({', '.join('%.1f' % b for b in blks)} s; median {blk:.1f} s per block), blocks x{cfg['num_layers']}, steps x4"}
+    rec = {"value": 1.0 / video_s, "unit": "videos/s", "cores": cores, "kind": kind,
+           "embeddings_s": t_emb, "block_s": blk, "blocks_in_sample": blocks, "forward_s_repetitions": raws,
+           "extrapolation": f"x{cfg['num_layers'] / blocks:g} (blocks) x4 (steps)",
+           "sample": f"{what}: embeddings + head {t_emb:.1f} s (measured once, not extrapolated) + {blocks} of {cfg['num_layers']} "
+                     f"blocks of 1 of 4 steps at full L, {reps} repetitions (raw forwards {', '.join('%.1f' % b for b in raws)} s; "
+                     f"median {raw:.1f} s = {blk:.1f} s per block), blocks x{cfg['num_layers'] / blocks:g}, steps x4 "
+                     f"(BASELINE.md §3 (ii)); per-operator CPU timings in `operators` ((iii))"}
+    try:
+        rec["operators"] = cpu_operator_times(cfg, cores)
+    except Exception as e:   # reported beside the baseline, never required for it
+        rec["operators"] = {"error": repr(e)}
+    if full_video:
+        # (i) one whole 4-step video, once, through the reference's own sampler update on the full-depth model
+        sdf = W.make_state_dict(cfg, seed=0, with_proj_l=False)
+        gn = torch.Generator().manual_seed(1)
+        noises = [torch.randn(lat_shape, generator=gn) for _ in range(4)]
+        netf = RH.reference_wan_from_sd(cfg, sdf, act_dtype=torch.bfloat16) if kind == "reference" else None
+        t0 = time.time()
+        with torch.no_grad():
+            W.rcm_sample((lambda xb, tb: netf(xb, tb, ctx)) if netf is not None else
+                         (lambda xb, tb: W.wan_forward(sdf, cfg, xb, tb, ctx, mode="eager", act_dtype=torch.bfloat16)), x, noises)
+        rec["full_video_s_measured_once"] = time.time() - t0
+        phase(f"cpu baseline ({kind}): one whole 4-step video: {rec['full_video_s_measured_once']:.0f} s")
+    torch.set_num_threads(cores)
+    return rec
 
 
 def box_record(net, cfg, L_tok, dev):
@@ -283,9 +400,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3, help="timed videos (each = 4 DiT steps)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="turbo", choices=sorted(WORKLOADS))
-    ap.add_argument("--model", default="Wan2.1-1.3B")
-    ap.add_argument("--res", default="480p", choices=sorted(RES))
+    ap.add_argument("--config", default="", choices=[""] + sorted(CONFIGS), help="a BASELINE.json configuration (SURVEY.md §8d) as one "
+                    "flag: sets --workload / --model / --res (/ --two-experts); explicit flags override")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--model", default=None)
+    ap.add_argument("--res", default=None, choices=sorted(RES))
     ap.add_argument("--num-steps", type=int, default=4, help="sampler steps per video")
     ap.add_argument("--topk", type=float, default=0.1)
     ap.add_argument("--two-experts", action="store_true", help="Wan2.2-A14B as the reference runs it (wan2.2_i2v_infer.py:"
@@ -299,6 +418,8 @@ def main():
     ap.add_argument("--sigma-max", type=float, default=0.0, help="0: 80 for T2V, 200 for I2V (the scripts' defaults)")
     ap.add_argument("--layers", type=int, default=0, help="debug: override num_layers (INVALID as a bench number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full-video", action="store_true", help="cpu_baseline: also time ONE whole 4-step video of the eager path on "
+                    "the host cores, once (BASELINE.md §3 (i); tens of minutes)")
     ap.add_argument("--no-box-calibration", action="store_true", help="skip the ~0.1 s in-run calibration of the box "
                     "(INT8 MFMA rate, HBM read bandwidth, shader clock under the ffn.2 GEMM) reported in `box`")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel eagerly instead of replaying "
@@ -332,6 +453,11 @@ def main():
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
                     help="td_set_tuning knob for A/B runs (integers, include/turbodiffusion_amd.h: TD_TUNE_*)")
     args = ap.parse_args()
+    preset = CONFIGS[args.config or "headline"]
+    args.workload = args.workload or preset["workload"]
+    args.model = args.model or preset["model"]
+    args.res = args.res or preset["res"]
+    args.two_experts = args.two_experts or preset.get("two_experts", False)
     wd = float(os.environ.get("TD_BENCH_WATCHDOG_S", "0"))
     if wd > 0:   # every thread's Python stack to stderr if the run is still going after wd seconds (and every wd after)
         import faulthandler
@@ -358,20 +484,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1:
-        # a multi-rank run that stops making progress (a collective whose peer died, a graph replay that never returns) must
-        # END with a message and a non-zero status, not sit until someone's outer timeout: every rank arms a hard limit
-        import threading
-        limit = float(os.environ.get("TD_BENCH_HARD_TIMEOUT_S", "900"))
-
-        def _hard_stop():
-            print(f"[bench] rank {rank}: no result after {limit:.0f} s (TD_BENCH_HARD_TIMEOUT_S) — a collective or a graph replay "
-                  f"is stuck; Python stacks follow", file=sys.stderr, flush=True)
-            import faulthandler
-            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
-            os._exit(3)
-        _t = threading.Timer(limit, _hard_stop)
-        _t.daemon = True
-        _t.start()
+        WATCHDOG.start(float(os.environ.get("TD_BENCH_HARD_TIMEOUT_S", "900")), rank)   # (re-armed by phase() and per timed video)
     emu = None
     if args.emulate_rank:
         er, en = (int(v) for v in args.emulate_rank.split("/"))
@@ -434,6 +547,7 @@ def main():
                 s_.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("TD_SP_WHOLE_GRAPH", "1")   # this rig is where the collectives-inside-the-graph form is exercised
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         for m_ in filter(None, (net, net_low)):
             seqpar.enable(m_, dist.group.WORLD)
@@ -511,13 +625,14 @@ def main():
         out = one_video()
         torch.cuda.synchronize()
         phase(f"warm-up video {wi + 1} done ({torch.cuda.memory_reserved() / 2**30:.1f} GiB reserved)")
-    timer = K.KernelTimer({"td_gemm_w8a8", "td_attn_i8"})
+    timer = K.KernelTimer({"td_gemm_w8a8", "td_attn_i8", "td_gemm_bf16"})
     if not use_graph:
         K.set_timer(timer)  # HIP events around the dominant kernels, on the launch stream, in the timed region
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_video()
+        WATCHDOG.kick()
     sync()
     elapsed = time.perf_counter() - t0
     K.set_timer(None)
@@ -715,6 +830,19 @@ def main():
                     "share_of_step": gs["total_ms"] * 1e-3 / per_video}
             if box and box.get("i8_pops"):
                 roof["frac_of_box"] = ach / (box["i8_pops"] * 1e15)
+        roof16 = None
+        if "td_gemm_bf16" in summ and not wl["quant_linear"]:
+            # C2 / C3 / original: the blocks' Linears are plain 16-bit GEMMs on td_gemm_bf16 (only launches with m >= 1024 count:
+            # the text MLP's and the split-K pieces are another regime)
+            gs = summ["td_gemm_bf16"]
+            recs = [(m_, ms_) for m_, ms_ in zip(gs["metas"], [a_.elapsed_time(b_) for a_, b_, _ in timer.records["td_gemm_bf16"]]) if m_[0] >= 1024]
+            if recs:
+                fl16 = sum(2.0 * m * n * k for (m, n, k), _ in recs)
+                t16 = sum(ms_ for _, ms_ in recs) * 1e-3
+                roof16 = {"kernel": "gemm_bf16_kernel (16-bit GEMM, fp32 accumulate)", "bound": "mfma", "achieved": fl16 / t16 / 1e12,
+                          "peak": F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": fl16 / t16 / F16_PEAK, "traffic": None,
+                          "algorithmic_bytes": sum(2.0 * (m * k + n * k + m * n) for (m, n, k), _ in recs) / len(recs),
+                          "avg_launch_ms": t16 * 1e3 / len(recs), "launches": len(recs), "share_of_step": t16 / per_video}
         roof_attn = None
         if "td_attn_i8" in summ:
             # The sparse attention kernel re-streams K/V per Q block from the L2 / Infinity Cache (PMC: ~0.8 GB of
@@ -736,7 +864,7 @@ def main():
                          "frac": mt / t_l, "traffic": pmc_traffic(("attn_kernel<true",)),
                          "traffic_unit": "B/launch (HBM-side fetch+write, PMC)",
                          # K/V tiles are re-read per Q block from L2 / the Infinity Cache: that stream is CACHE traffic, not
-                         # HBM traffic — the HBM-side rate is `hbm_frac` below
+                         # HBM traffic — the HBM-side rate is `hbm_side_frac_informational` below
                          "cache_streamed_bytes": by, "cache_streamed_GBps": by / t_l / 1e9,
                          "avg_launch_ms": a["avg_ms"], "launches": a["launches"],
                          "share_of_step": a["total_ms"] * 1e-3 / per_video}
@@ -744,8 +872,10 @@ def main():
                 # HBM side of the attention kernel: counter bytes per launch / launch time / 8 TB/s.  The north star's ">= 60 %
                 # of the HBM roofline" is NOT met and cannot be by a kernel whose K/V re-reads hit in cache: it is
                 # issue-bound on the matrix / VALU port, so its roofline is `frac` (matrix pipe)
-                roof_attn["hbm_GBps"] = roof_attn["traffic"] / t_l / 1e9
-                roof_attn["hbm_frac"] = roof_attn["traffic"] / t_l / HBM_PEAK
+                roof_attn["hbm_side_GBps"] = roof_attn["traffic"] / t_l / 1e9
+                roof_attn["hbm_side_frac_informational"] = roof_attn["traffic"] / t_l / HBM_PEAK
+                roof_attn["held_to"] = ("the matrix pipe (`frac`; DESIGN.md §5: target >= 0.45) — the HBM-side figure is information: "
+                                        "the kernel's K / V re-reads are L2 / Infinity-Cache hits and it is issue-bound")
                 roof_attn.update(pmc_meta())
         if live_traffic is not None:     # counters of THIS run replace the committed summary's
             for r_, pre in ((roof, ("gemm_w8a8_",)), (roof_attn, ("attn_kernel<true",))):
@@ -757,12 +887,13 @@ def main():
                         r_.pop(k_, None)
                     r_["traffic_stale"] = False
                     if r_ is roof_attn:
-                        r_["hbm_GBps"] = tv / (r_["avg_launch_ms"] * 1e-3) / 1e9
-                        r_["hbm_frac"] = tv / (r_["avg_launch_ms"] * 1e-3) / HBM_PEAK
+                        r_["hbm_side_GBps"] = tv / (r_["avg_launch_ms"] * 1e-3) / 1e9
+                        r_["hbm_side_frac_informational"] = tv / (r_["avg_launch_ms"] * 1e-3) / HBM_PEAK
         elif live_err is not None and roof is not None:
             roof["traffic_collect_error"] = live_err
-        if roof is None:
-            roof = roof_attn
+        if roof is None:    # no W8A8 GEMM in this workload: `roofline` = whichever of the 16-bit GEMM / the attention kernel holds more of the step
+            cands = [r_ for r_ in (roof16, roof_attn) if r_ is not None]
+            roof = max(cands, key=lambda r_: r_["share_of_step"]) if cands else None
         res = {
             "metric": f"end-to-end videos/sec (4-step rCM denoising loop, {args.model} {args.res})",
             "value": value, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -785,7 +916,7 @@ def main():
                                        else "single GPU") if world == 1 else (
                            f"dp{dp} x sp{sp}: {dp} independent videos, each sharded by sequence over {sp} GPUs "
                            f"(RCCL all-gather of the quantised K/V per layer)" if sp > 1 else f"dp{dp}: {dp} independent videos")},
-            "roofline": roof, "roofline_attention": roof_attn,
+            "roofline": roof, "roofline_attention": roof_attn, **({"roofline_gemm16": roof16} if roof16 is not None else {}),
             "launch_mode": (("hipGraph replay, one graph per DiT forward" if sp == 1 else
                              "hipGraph replay in segments, the all-gathers issued eagerly between them") +
                             "; kernel events from one eager video (full-size launches, token-half split off) after the timed region"
@@ -863,10 +994,12 @@ def main():
             res["config"]["DEBUG_num_layers_override"] = args.layers
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(cfg, lat_shape, args.topk)
+                res["cpu_baseline"] = cpu_baseline(cfg, lat_shape, args.topk, full_video=args.cpu_full_video)
             except Exception as e:  # the baseline is reported, never required for the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
+        WATCHDOG.cancel()
         print(json.dumps(res), flush=True)
+    WATCHDOG.cancel()
     if world > 1 or args.rccl_one_rank:
         dist.destroy_process_group()
 

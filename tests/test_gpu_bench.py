@@ -117,4 +117,4 @@ def test_bench_collects_its_traffic_counters_in_the_run():
     roof, ra = r["roofline"], r["roofline_attention"]
     assert "collected in this run" in roof.get("traffic_source", ""), (roof.get("traffic_collect_error"), out.stderr[-1500:])
     assert roof["traffic_stale"] is False and roof["traffic"] > roof["algorithmic_bytes"] * 0.5
-    assert ra["traffic"] > 0 and 0 < ra["hbm_frac"] < 1
+    assert ra["traffic"] > 0 and 0 < ra["hbm_side_frac_informational"] < 1

@@ -407,6 +407,11 @@ def test_vae_pointwise_convolutions_and_frame_attention_vs_torch(K):
     e = rel_l2(got, want)
     print(f"\n[VAE frame attention on GEMMs, bf16] rel-L2 vs fp32 torch: {e:.4f}")
     assert e < 1.5e-2
+    # round 5: frames go through ONE reused score / probability buffer pair in chunks; the chunk size is a memory
+    # knob only — one frame at a time and two give the bits of all three at once
+    for cb in (1, 2 * 6 * (H * W) * K.cdiv(H * W, 64) * 64):
+        att.chunk_bytes = cb
+        assert torch.equal(att(x.to(DEV)).float().cpu(), got), cb
 
 
 def test_prompt_ids_to_video_runs_the_three_stages():

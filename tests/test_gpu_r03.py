@@ -328,27 +328,45 @@ def test_head_vs_the_operator_sequence(K, dim, dtype, L_grid):
     assert torch.equal(got_tok, tok), "unpatchify is a pure permutation of the token-major result"
 
 
-def test_forward_with_hip_embeddings_and_head_matches_the_library_path():
-    """WanModel.fuse_embed_head on / off on the dense bf16 configuration (no block-map near-ties to amplify a last-bit
-    difference of the embedding): the outputs agree to bf16 rounding noise; T2V and the I2V channel concatenation."""
+def test_forward_runs_no_library_operator_and_refuses_what_the_kernels_do_not_take(monkeypatch):
+    """Round 5: ONE path.  A toy-width model (dim 256, K = 64 patch reduction) — T2V and the I2V channel
+    concatenation, dense bf16 linears and W8A8 — goes through td_patch_embed / td_gemv_f32 / td_gemm_bf16 / td_head: every
+    library Linear / GELU / SDPA entry point raises while the forward runs.  What the kernels do not take is refused by name."""
+    import torch.nn.functional as F
     from oracle import wan_ref as W
     from tests.test_gpu_wan import make_net
     gold = torch.load(os.path.join(GOLD, "wan_tiny.pt"), weights_only=False)
-    for in_dim, mt in ((16, "t2v"), (36, "i2v")):
+
+    def boom(name):
+        def f(*a, **k):
+            raise AssertionError(f"library operator {name} called inside WanModel.forward")
+        return f
+
+    for in_dim, mt, attention, quant in ((16, "t2v", "original", False), (36, "i2v", "sagesla", True)):
         cfg = dict(gold["cfg"], in_dim=in_dim, model_type=mt)
         sd = W.make_state_dict(cfg, 21)
-        net = make_net(cfg, sd, "original", False)
+        net = make_net(cfg, sd, attention, quant)
         g = torch.Generator().manual_seed(4)
         x = torch.randn(2, 16, 3, 16, 24, generator=g).to(DEV).bfloat16()
         y = torch.randn(2, 20, 3, 16, 24, generator=g).to(DEV).bfloat16() if mt == "i2v" else None
         t = torch.tensor([[933.781], [608.979]], device=DEV).bfloat16()
         ctx = gold["ctx"].to(DEV).bfloat16().expand(2, -1, -1).contiguous()
-        assert net.fuse_embed_head
-        a = net(x, t, ctx, y_B_C_T_H_W=y)
-        net.fuse_embed_head = False
-        b = net(x, t, ctx, y_B_C_T_H_W=y)
-        assert a.shape == b.shape == (2, 16, 3, 16, 24) and torch.isfinite(a).all()
-        assert rel_l2(a, b) < 5e-3, rel_l2(a, b)
+        with monkeypatch.context() as mp:
+            for name in ("linear", "gelu", "scaled_dot_product_attention", "layer_norm", "silu"):
+                mp.setattr(F, name, boom(name))
+            mp.setattr(torch, "matmul", boom("matmul"))
+            a = net(x, t, ctx, y_B_C_T_H_W=y)
+        assert a.shape == (2, 16, 3, 16, 24) and torch.isfinite(a).all()
+        ref = W.wan_forward(sd, cfg, x.float().cpu(), t.cpu(), ctx.cpu(), None if y is None else y.float().cpu(),
+                            mode="turbo" if quant else "eager", attention=attention, quant=quant, topk=0.5)
+        assert rel_l2(a, ref) < 2.5e-2, rel_l2(a, ref)
+        with pytest.raises(ValueError, match="timesteps in torch.float32"):
+            net(x, t.float(), ctx, y_B_C_T_H_W=y)
+    net.time_embedding[0].float()
+    with pytest.raises(ValueError, match="time_embedding.0 parameters in torch.float32"):
+        net(x, t, ctx, y_B_C_T_H_W=y)
+    with pytest.raises(TypeError, match="td_gemm_bf16 takes one 16-bit dtype"):
+        net._lin16(torch.zeros(4, 64, device=DEV), torch.zeros(8, 64, device=DEV), None)
 
 
 def test_twelve_layers_deep_against_the_oracle(K, capsys):

@@ -138,11 +138,11 @@ def _nccl_worker(rank, world, port, attention, ret):
         seqpar.enable(net, dist.group.WORLD)
         ret["backend"] = dist.get_backend(dist.group.WORLD)
         eager = [net(x, t, ctx).clone() for x, t in zip(xs, ts)]
-        # (1) segments around eager collectives (TD_SP_WHOLE_GRAPH=0), (2) the default: ONE graph, collectives captured
+        # (1) segments around eager collectives (the default for real RCCL groups), (2) TD_SP_WHOLE_GRAPH=1: ONE graph, collectives captured
         ret["same"] = []
         for whole in (False, True):
             gm = GraphedModel(net)
-            gm._no_whole_graph = not whole
+            gm._whole_graph_env = "1" if whole else "0"   # (real RCCL groups: whole-graph capture is opt-in since round 5)
             outs = [gm(x, t, ctx).clone() for x, t in zip(xs, ts)]
             outs.append(gm(xs[0], ts[0], ctx).clone())
             torch.cuda.synchronize()

@@ -287,6 +287,20 @@ def _bcast_worker(rank, world, port, ret):
         mine = torch.full((2, 3), float(rank + 1))
         got = sp.broadcast(mine)
         ret[rank] = (got.tolist(), mine.tolist(), sp.broadcast(None) is None, sp.capturable)
+        # round 5: receivers get the SAME buffer object every time; a non-contiguous input is received
+        # contiguous; cached=True ships the payload only when the first rank's tensor (object / version) changed, and the
+        # receivers' buffer then keeps its version — what WanModel.prepare_text keys its text K / V^T cache on
+        again = sp.broadcast(torch.full((2, 3), float(rank + 1)))
+        nc = sp.broadcast(torch.full((3, 2), float(rank + 5)).t(), slot=1)
+        text = torch.full((4,), float(10 * (rank + 1)))
+        b1 = sp.broadcast(text, slot=2, cached=True)
+        v1 = b1._version
+        b2 = sp.broadcast(text, slot=2, cached=True)          # same object, same version: flag only
+        v2 = b2._version
+        text.add_(1.0)                                        # new contents on the first rank
+        b3 = sp.broadcast(text, slot=2, cached=True)
+        ret[f"r5_{rank}"] = (again is got if rank else True, nc.is_contiguous(), nc.tolist(), b2 is b1 and b3 is b1, v2 == v1,
+                             b3.tolist(), (b3._version > v2) if rank else True)
     finally:
         dist.destroy_process_group()
 
@@ -299,6 +313,9 @@ def test_input_broadcast_from_the_groups_first_rank():
     mp.spawn(_bcast_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     ones, twos = [[1.0] * 3] * 2, [[2.0] * 3] * 2
     assert ret[0] == (ones, ones, True, False) and ret[1] == (ones, twos, True, False), dict(ret)
+    for r in range(2):
+        same_obj, contig, nc, same_text_obj, version_kept, b3, bumped = ret[f"r5_{r}"]
+        assert same_obj and contig and nc == [[5.0] * 3] * 2 and same_text_obj and version_kept and b3 == [11.0] * 4 and bumped, (r, ret[f"r5_{r}"])
 
 
 def _quiesce_worker(rank, world, port, ret):

@@ -189,7 +189,13 @@ class GraphedModel(torch.nn.Module):
         self.sp_whole_graph_error = None   # why the collectives could not be captured inside ONE graph (None: they were / not tried)
         self.sp_graph_mode = None          # how the sequence-parallel forward is replayed (set at capture)
         import os
-        self._no_whole_graph = os.environ.get("TD_SP_WHOLE_GRAPH", "1") == "0"   # A/B switch: segments even where capture works
+        # Collectives INSIDE one hipGraph: always for an emulated group (no communicator, no watchdog); for a real RCCL group
+        # OPT-IN (TD_SP_WHOLE_GRAPH=1) until it has passed on more than one physical GPU — torch's ProcessGroupNCCL watchdog
+        # aborts the PROCESS (no exception, no fallback) if it polls a leftover eager Work while the communicator stream is
+        # in capture mode, and the only guard available from Python is a drain by time (quiesce_collective_watchdog).  The
+        # default for real groups is the segmented form: graph segments around eagerly re-issued collectives, which needs
+        # no such guard.  TD_SP_WHOLE_GRAPH=0 forces segments everywhere (A/B).
+        self._whole_graph_env = os.environ.get("TD_SP_WHOLE_GRAPH", "")
 
     def _key(self, x, t, ctx, y):
         return (tuple(x.shape), x.dtype, tuple(t.shape), t.dtype, tuple(ctx.shape), ctx.dtype,
@@ -244,7 +250,8 @@ class GraphedModel(torch.nn.Module):
                 sp_group = getattr(sp_obj, "group", None)
                 real_group = sp_group is not None and not type(sp_group).__name__ == "EmulatedGroup"
                 g = None
-                if getattr(sp_obj, "capturable", False) and not self._no_whole_graph:
+                whole = (self._whole_graph_env == "1") if real_group else (self._whole_graph_env != "0")
+                if getattr(sp_obj, "capturable", False) and whole:
                     # (1) ONE graph for the whole sharded forward, the collectives inside it: the nccl (= RCCL) backend issues
                     # them on its communicator stream, which forks off the capturing stream and joins it again at
                     # ``work.wait()`` — stream-ordered work like any kernel.  No host work between the ~1100 launches of a

@@ -922,8 +922,9 @@ def gemm_bf16(a, w, bias=None, res=None, epilogue="none", out_dtype=None, out=No
         call("td_gemm_bf16_splitk_reduce", ptr(ws), splits, ptr(bias), ptr(res), ptr(out), L.dt_code(a.dtype), GEMM16_EPI[epilogue],
              m, n, out.stride(0), 0 if res is None else res.stride(0), stream_ptr())
         return out
-    call("td_gemm_bf16", ptr(a), ptr(w), ptr(bias), ptr(res), ptr(out), L.dt_code(a.dtype), L.dt_code(odt), GEMM16_EPI[epilogue],
-         m, n, k, a.stride(0), w.stride(0), out.stride(0), 0 if res is None else res.stride(0), 1, 0, 0, 0, 0, stream_ptr())
+    _timed("td_gemm_bf16", (m, n, k), lambda: call(
+        "td_gemm_bf16", ptr(a), ptr(w), ptr(bias), ptr(res), ptr(out), L.dt_code(a.dtype), L.dt_code(odt), GEMM16_EPI[epilogue],
+        m, n, k, a.stride(0), w.stride(0), out.stride(0), 0 if res is None else res.stride(0), 1, 0, 0, 0, 0, stream_ptr()))
     return out
 
 

@@ -57,6 +57,10 @@ class EmulatedGroup:
         self.rank, self.world = rank, world
 
 
+WAIT_PROBE = None   # bench.py (N > 1): a list that receives (event before, event after, bytes gathered) of every stream-side wait
+#                     for an asynchronous gather — the time the compute stream sat waiting for the wire, per collective
+
+
 class _Gather:
     """One all-gather on fixed buffers: ``issue()`` / ``wait()`` may be called again (graph replay) — same tensors.
     Issue and wait are ``graph.eager_point``s: a plain call, except under a SEGMENTED capture (graph.SegmentRecorder),
@@ -81,7 +85,15 @@ class _Gather:
 
     def _wait(self):
         if self.work is not None:
-            self.work.wait()
+            probe = WAIT_PROBE
+            if probe is not None and self.out.is_cuda:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self.work.wait()
+                b.record()
+                probe.append((a, b, self.out.numel() * self.out.element_size()))
+            else:
+                self.work.wait()
             self.work = None
 
     def wait(self):
@@ -152,6 +164,8 @@ class SeqParallel:
         # (bench.py --emulate-rank 0/8, round 4: 33.5 ms per DiT step against 84 / 8 = 10.5)
         self.parallel_groups = True
         self._group_streams = {}
+        self._bcast_bufs = {}      # receiving ranks of ``broadcast``: one persistent buffer per (slot, shape, dtype)
+        self._bcast_sent = {}      # first rank: per slot (tag of the tensor last sent with cached=True, the tensor itself)
         import os   # A/B switches for the measurement tools (tools/gpu/*.sh); results do not depend on them
         self._groups_forced = bool(os.environ.get("TD_SP_HEAD_GROUPS"))
         if self._groups_forced:
@@ -206,26 +220,61 @@ class SeqParallel:
         eager_point(h.issue)
         return (out, h) if async_op else out
 
-    def broadcast(self, t):
+    def broadcast(self, t, slot=0, cached=False):
         """The group's first rank's contents of ``t`` on every rank (``broadcast`` of rcm/utils/context_parallel.py:167-184 as
         ``WanModel.forward`` uses it, wan2pt1.py:629-636).  Data only: the reference also ships the SHAPE first, which costs a
         host synchronisation per input; here a shape mismatch between ranks is the caller's error.  The caller's tensor is
-        not written on the receiving ranks (they get a copy)."""
+        not written on the receiving ranks: they receive into a PERSISTENT contiguous buffer per (slot, shape, dtype) — the
+        same tensor object every forward (``dist.broadcast`` on nccl refuses non-contiguous tensors; a fresh clone per
+        forward left a stale entry per step in ``WanModel.prepare_text``'s cache).
+        cached (the text embedding: constant over the steps of a video): the first rank first broadcasts ONE flag — "same
+        tensor object at the same version as last time?" — and the payload only when it changed; the receivers' buffer then
+        keeps its identity AND its version, so their text K / V^T cache hits on the steps after the first like the first
+        rank's does (every rank runs in lockstep: a miss on any rank set the step time)."""
         if t is None:
             return None
         if isinstance(self.group, EmulatedGroup):
             return t
         src = min(dist.get_process_group_ranks(self.group))
-        buf = t if dist.get_rank() == src else t.clone()
-        via_host = buf.is_cuda and dist.get_backend(self.group) == "gloo"
+        me_src = dist.get_rank() == src
+        via_host = t.is_cuda and dist.get_backend(self.group) == "gloo"
+        if me_src:
+            buf = t if t.is_contiguous() else t.contiguous()
+        else:
+            key = (slot, tuple(t.shape), t.dtype, str(t.device))
+            buf = self._bcast_bufs.get(key)
+            if buf is None:    # (one per distinct input signature; never evicted: the first rank's "unchanged" flag refers to it)
+                buf = self._bcast_bufs[key] = torch.empty(t.shape, dtype=t.dtype, device=t.device)
 
-        def fn():
+        def payload():
             if via_host:
                 host = buf.cpu()
                 dist.broadcast(host, src, group=self.group)
-                buf.copy_(host)
+                if not me_src:
+                    buf.copy_(host)
+            elif cached and not me_src:
+                # c10d writes through the data pointer and does not bump the tensor's version counter: receive into a scratch
+                # buffer and copy_ (which does), or a new prompt would look like the cached one to whatever keys on
+                # (address, version) — WanModel.prepare_text
+                recv = torch.empty_like(buf)
+                dist.broadcast(recv, src, group=self.group)
+                buf.copy_(recv)
             else:
                 dist.broadcast(buf, src, group=self.group)
+
+        def fn():
+            if not cached:
+                return payload()
+            flag = torch.zeros(1, dtype=torch.int64, device="cpu" if (via_host or not t.is_cuda) else t.device)
+            if me_src:
+                tag = (t.data_ptr(), t._version, tuple(t.shape), t.dtype)
+                last = self._bcast_sent.get(slot)
+                changed = last is None or last[0] != tag
+                self._bcast_sent[slot] = (tag, t)      # (the OBJECT is held: its address cannot be recycled for another text)
+                flag.fill_(1 if changed else 0)
+            dist.broadcast(flag, src, group=self.group)
+            if int(flag.item()):
+                payload()
         eager_point(fn)
         return buf
 
@@ -366,7 +415,8 @@ class _ModelAdapter:
     def broadcast(self, *tensors):
         """Inputs of one forward from the group's first rank (only when enabled through the reference's hook,
         ``WanModel.enable_context_parallel``; ``seqpar.enable`` callers hand identical inputs to every rank)."""
-        return tuple(self.sp.broadcast(t) for t in tensors)
+        # (x, t, text, y) as WanModel.forward passes them: the text (index 2) is constant over the steps of a video
+        return tuple(self.sp.broadcast(t, slot=i, cached=(i == 2 and len(tensors) == 4)) for i, t in enumerate(tensors))
 
     def shard_tokens(self, x, cos, sin):
         return self.sp.shard_tokens(x, cos, sin)

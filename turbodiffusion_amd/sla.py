@@ -104,9 +104,12 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
         if not sage and not dense and not quant_out and vt is None:
             return _general_sla_hld(q if q is not None else q_fn(), k, vt_src, proj_w, proj_b, topk_ratio, out, o_stride_h,
                                     o_stride_l, v_strides, blkq, feature_map)
-        if feature_map != "softmax":
-            return _sage_other_feature_map(q if q is not None else q_fn(), k, vt_src, proj_w, proj_b, topk_ratio, out, o_stride_h,
-                                           o_stride_l, v_strides, dense, quant_out, km, pv, vt, feature_map)
+        if blkq != 128:
+            # every remaining combination would land on the BLKQ = 128 fast path with a LUT of one row per 64 queries
+            raise ValueError("BLKQ = 64 (the class default, SLA/core.py:39) runs through the general 16-bit SLA path only: no dense "
+                             "attention, no fused INT8 output (quant_out), no caller-supplied V^T tiles (vt)")
+        return _other_feature_map(q if q is not None else q_fn(), k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h,
+                                  o_stride_l, v_strides, dense, quant_out, km, pv, vt, feature_map)
     kb = K.cdiv(L_, blkk)
     topk = min(kb, int(topk_ratio * kb))
     if not dense and topk < 1:
@@ -156,13 +159,14 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     return res, topk, kb
 
 
-def _sage_other_feature_map(q, k, vt_src, proj_w, proj_b, topk_ratio, out, o_stride_h, o_stride_l, v_strides, dense, quant_out,
-                            km, pv, vt, feature_map):
-    """SageSLA with the elu / relu feature map (SLA/core.py:139-147): the sparse branch as always, the linear branch's two
+def _other_feature_map(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l, v_strides, dense, quant_out,
+                       km, pv, vt, feature_map):
+    """BLKQ = 128 with the elu / relu feature map (SLA/core.py:139-147) outside the general path (SageSLA, or 16-bit SLA with
+    caller-supplied V^T tiles): the sparse branch as always — in the CALLER's arithmetic (``sage``) — the linear branch's two
     passes with the other map, added into the output afterwards (no epilogue fusion, no fused quantiser)."""
     if quant_out:
         raise ValueError("the attention epilogue's fused INT8 output needs the softmax feature map's fused linear branch")
-    res, topk, kb = sparse_linear_attention_hld(q, k, vt_src, None, None, topk_ratio, True, out, o_stride_h, o_stride_l,
+    res, topk, kb = sparse_linear_attention_hld(q, k, vt_src, None, None, topk_ratio, sage, out, o_stride_h, o_stride_l,
                                                 v_strides, dense=dense, km=km, pv=pv, vt=vt)
     if proj_w is not None and not dense:
         H, L_, D = k.shape

@@ -108,11 +108,24 @@ class _HipFrameAttention:
         k = pointwise_conv(K, xn, self.wk, self.bk).view(n, hw, C)
         vt = torch.zeros((n, C, hwp), dtype=x.dtype, device=x.device)         # V^T per frame, zero behind the hw positions
         K.gemm_bf16_batched(self.wv.unsqueeze(0).expand(n, C, C), xn.view(n, hw, C), out=vt[:, :, :hw])
-        s = K.gemm_bf16_batched(q, k, out_dtype=torch.float32)                # [n, hw, hw] fp32
-        p = K.softmax_rows(s.view(n * hw, hw), C ** -0.5, out_dtype=x.dtype, padded=True)   # [n * hw, hwp]
-        del s
-        o = K.gemm_bf16_batched(p.view(n, hw, hwp), vt, bias=self.bv)         # [n, hw, C]
+        # scores / probabilities of a few frames at a time through ONE reused pair of buffers: fp32 [c, hw, hw] + 16-bit
+        # [c, hw, hwp] — about 1 GiB together whatever the clip (720p: one frame = 0.8 + 0.4 GB, where all 21 frames at once were
+        # 17 + 9 GB transient, growing with batch and frames, beside two resident A14B experts).  One frame's GEMMs already
+        # fill the chip (480p: 6240 x 6240 x 384 = 600 tiles).
+        per = 6 * hw * hwp                                                     # bytes of one frame's scores + probabilities
+        c = max(1, min(n, self.chunk_bytes // per))
+        s = torch.empty((c, hw, hw), dtype=torch.float32, device=x.device)
+        p = torch.empty((c * hw, hwp), dtype=x.dtype, device=x.device)
+        o = torch.empty((n, hw, C), dtype=x.dtype, device=x.device)
+        for f0 in range(0, n, c):
+            m = min(c, n - f0)
+            K.gemm_bf16_batched(q[f0:f0 + m], k[f0:f0 + m], out_dtype=torch.float32, out=s[:m])
+            K.softmax_rows(s[:m].view(m * hw, hw), C ** -0.5, out=p[:m * hw, :hw], out_dtype=x.dtype)   # zero-fills the padded tail
+            K.gemm_bf16_batched(p[:m * hw].view(m, hw, hwp), vt[f0:f0 + m], bias=self.bv, out=o[f0:f0 + m])
+        del s, p
         return pointwise_conv(K, o.reshape(B, T, H, W, C), self.wp, self.bp, res=x)
+
+    chunk_bytes = 1 << 30
 
 
 class _HipUp:

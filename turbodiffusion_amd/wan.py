@@ -27,7 +27,6 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import kernels as K
 from .ops import FastLayerNorm, FastRMSNorm, Int8Linear
@@ -187,7 +186,6 @@ class WanModel(nn.Module):
         self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
         self.fuse_vt = True         # self-attention V leaves the q|k|v GEMM as the attention kernel's V^T tiles (K.gemm_w8a8_vt)
         self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
-        self.fuse_embed_head = True  # patchify+patch_embedding, time MLPs, AdaLN vectors, head+unpatchify in HIP (embed_head.hip)
         self.split_tokens = True    # everything after self-attention is token-local: two token halves on two streams (_block)
         self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
@@ -299,14 +297,18 @@ class WanModel(nn.Module):
 
     def _lin16(self, x, w, b, gelu=False):
         """A plain 16-bit Linear (BASELINE config 3's "bf16 linears", the text MLP, C1's arithmetic on the GPU) on
-        ``td_gemm_bf16`` — bias and GELU-tanh in the GEMM's epilogue with the operator sequence's rounding points."""
-        if (x.dtype in (torch.bfloat16, torch.float16) and w.dtype == x.dtype and x.shape[-1] % 64 == 0
-                and w.shape[0] % 8 == 0 and (b is None or b.dtype == x.dtype)):
-            x2 = x.reshape(-1, x.shape[-1])
-            y = K.gemm_bf16(x2, w.detach(), None if b is None else b.detach(), epilogue="gelu_tanh" if gelu else "none")
-            return y.view(*x.shape[:-1], w.shape[0])
-        y = F.linear(x, w, b)          # widths the kernel does not take (k % 64 != 0: toy models in tests) and fp32 models
-        return F.gelu(y, approximate="tanh") if gelu else y
+        ``td_gemm_bf16`` — bias and GELU-tanh in the GEMM's epilogue with the operator sequence's rounding points.  Any
+        width (``K.gemm_bf16`` zero-pads a reduction that is not a multiple of 64: toy models); there is no library-GEMM
+        path beside it — what the kernel does not take raises."""
+        if x.dtype not in (torch.bfloat16, torch.float16) or w.dtype != x.dtype or (b is not None and b.dtype != x.dtype):
+            raise TypeError(f"plain Linear on the MI355X path: activation {x.dtype}, weight {w.dtype}, bias "
+                            f"{None if b is None else b.dtype} — td_gemm_bf16 takes one 16-bit dtype (bfloat16 or float16) for all "
+                            "three; build the model with dtype=torch.bfloat16 (fp32 models are the CPU oracle's, oracle/wan_ref.py)")
+        if w.shape[0] % 8:
+            raise ValueError(f"plain Linear with {w.shape[0]} output features: td_gemm_bf16 stores 16-byte row pieces (a multiple of 8)")
+        x2 = x.reshape(-1, x.shape[-1])
+        y = K.gemm_bf16(x2, w.detach(), None if b is None else b.detach(), epilogue="gelu_tanh" if gelu else "none")
+        return y.view(*x.shape[:-1], w.shape[0])
 
     def _lin_q(self, mod, xq, xs, dtype, gelu=False):
         """Int8Linear on an already block-quantised activation."""
@@ -749,42 +751,23 @@ class WanModel(nn.Module):
         cos, sin = self._rope(T, H, W, x_B_C_T_H_W.device)
         sp = self.seq_parallel
         # f3 in HIP (csrc/embed_head.hip): patchify + patch_embedding, the time MLPs, the AdaLN vectors, head + unpatchify —
-        # no library GEMM and no torch elementwise kernel inside a captured forward
-        fe = (self.fuse_embed_head and (kt, kh, kw) == (1, 2, 2) and C % 4 == 0 and C <= 64 and dt in (torch.bfloat16, torch.float16)
-              and self.patch_embedding.weight.dtype == dt and self.patch_embedding.bias.dtype == dt
-              and all(m.weight.dtype in (torch.bfloat16, torch.float16)       # K.gemv_f32 reads 16-bit weights
-                      for m in (self.time_embedding[0], self.time_embedding[2], self.time_projection[1]))
-              and timesteps_B_T.dtype in (torch.bfloat16, torch.float16)
-              and self.dim % 8 == 0 and self.out_dim * 4 <= 64)
+        # no library GEMM and no torch elementwise kernel inside a captured forward.  ONE path: what those kernels do not
+        # take is refused here, by name (there is no library-operator branch beside them; the operator sequence they are
+        # checked against lives in the tests and in oracle/wan_ref.py)
+        self._check_embed_head_support(C, dt, timesteps_B_T.dtype)
         row0 = 0
-        if fe:
-            if sp is not None:
-                row0, stop = sp.shard_range(L_)
-                cos, sin = cos[row0:stop].contiguous(), sin[row0:stop].contiguous()
-            else:
-                stop = L_
-            x = K.patch_embed(x_B_C_T_H_W.to(dt).contiguous(), None if y_B_C_T_H_W is None else y_B_C_T_H_W.to(dt).contiguous(),
-                              self.patch_embedding.weight, self.patch_embedding.bias, row0, stop - row0)   # [B, L_loc, dim]
-            # time embeddings in fp32 (the reference's autocast(float32) island, wan2pt1.py:671-674)
-            te, tp = self.time_embedding, self.time_projection
-            e = K.gemv_f32(K.time_sinusoid(t_B.contiguous(), self.freq_dim), te[0].weight, te[0].bias)
-            e_B_D = K.gemv_f32(e, te[2].weight, te[2].bias, silu_input=True)
-            e0 = K.gemv_f32(e_B_D, tp[1].weight, tp[1].bias, silu_input=True).unflatten(1, (6, self.dim))
+        if sp is not None:
+            row0, stop = sp.shard_range(L_)
+            cos, sin = cos[row0:stop].contiguous(), sin[row0:stop].contiguous()
         else:
-            if y_B_C_T_H_W is not None:
-                x_B_C_T_H_W = torch.cat([x_B_C_T_H_W, y_B_C_T_H_W], dim=1)
-            # patchify "b c (t kt) (h kh) (w kw) -> b (t h w) (c kt kh kw)"   (wan2pt1.py:653-660)
-            x = x_B_C_T_H_W.to(dt).view(B, C, T, kt, H, kh, W, kw).permute(0, 2, 4, 6, 1, 3, 5, 7)
-            x = x.reshape(B, L_, C * kt * kh * kw)
-            if sp is not None:
-                x, cos, sin = sp.shard_tokens(x, cos, sin)
-            x = self.patch_embedding(x).contiguous()  # [B, L_loc, dim]
-            # time embeddings in fp32 (the reference's autocast(float32) island, wan2pt1.py:671-674)
-            te, tp = self.time_embedding, self.time_projection
-            e = sinusoidal_embedding_1d(self.freq_dim, t_B).float()
-            e = F.linear(e, te[0].weight.float(), te[0].bias.float())
-            e_B_D = F.linear(F.silu(e), te[2].weight.float(), te[2].bias.float())
-            e0 = F.linear(F.silu(e_B_D), tp[1].weight.float(), tp[1].bias.float()).unflatten(1, (6, self.dim))
+            stop = L_
+        x = K.patch_embed(x_B_C_T_H_W.to(dt).contiguous(), None if y_B_C_T_H_W is None else y_B_C_T_H_W.to(dt).contiguous(),
+                          self.patch_embedding.weight, self.patch_embedding.bias, row0, stop - row0)   # [B, L_loc, dim]
+        # time embeddings in fp32 (the reference's autocast(float32) island, wan2pt1.py:671-674)
+        te, tp = self.time_embedding, self.time_projection
+        e = K.gemv_f32(K.time_sinusoid(t_B.contiguous(), self.freq_dim), te[0].weight, te[0].bias)
+        e_B_D = K.gemv_f32(e, te[2].weight, te[2].bias, silu_input=True)
+        e0 = K.gemv_f32(e_B_D, tp[1].weight, tp[1].bias, silu_input=True).unflatten(1, (6, self.dim))
         tkv = kvts = None
         if self.cache_text_kv:
             context, kvts = self.prepare_text(crossattn_emb)[2:4]   # once per text (keyed on the tensor's identity + version)
@@ -799,10 +782,7 @@ class WanModel(nn.Module):
         mods = self._fused.get("mods")
         if mods is None or mods[1] != ver:
             mods = self._fused["mods"] = (torch.stack([blk.modulation.detach().float() for blk in self.blocks], 0), ver)
-        if fe:
-            e_all = K.bcast_add(mods[0].view(len(self.blocks), 6, self.dim), e0.contiguous())   # fp32 [nblk, B, 6, dim]
-        else:
-            e_all = mods[0] + e0.unsqueeze(0)                    # fp32 [nblk, B, 6, dim]
+        e_all = K.bcast_add(mods[0].view(len(self.blocks), 6, self.dim), e0.contiguous())   # fp32 [nblk, B, 6, dim]
         self._carry_stats = None
         img_ctx = None
         if frame_cond_crossattn_emb_B_L_D is not None:
@@ -818,30 +798,46 @@ class WanModel(nn.Module):
         if return_tokens:
             return x if sp is None else sp.gather_tokens(x, L_)
         # head (wan2pt1.py:444-454): fp32 modulate of the (bf16) norm, fp32 Linear
-        L_loc = x.shape[1]
-        if fe:
-            hw = self._fused.get("head")
-            hver = (self.head.head.weight._version, self.head.head.bias._version, self.head.modulation._version)
-            if hw is None or hw[3] != hver:   # the fp32 island's up-cast of the (bf16) head parameters; in-place updates noticed
-                hw = self._fused["head"] = (self.head.head.weight.detach().float().contiguous(),
-                                           self.head.head.bias.detach().float().contiguous(),
-                                           self.head.modulation.detach().float().contiguous().view(1, 2, self.dim), hver)
-            em = K.bcast_add(hw[2], e_B_D.view(B, 1, self.dim))[0]    # [B, 2, dim] = modulation + e
-            out = K.head(x, em[:, 1].contiguous(), em[:, 0].contiguous(), hw[0], hw[1], self.eps, self.out_dim, T, H, W,
-                         unpatchify=sp is None, row0=row0)
-            if sp is None:
-                return out
-            out = sp.gather_tokens(out, L_)
-        else:
-            em = (self.head.modulation.float() + e_B_D.unsqueeze(1))  # [B, 2, dim]
-            hn = K.layernorm(x.view(B * L_loc, self.dim), None, None, self.eps, scale=em[:, 1].contiguous(),
-                             shift=em[:, 0].contiguous(), rows_per_batch=L_loc, out_dtype=torch.float32)
-            out = F.linear(hn, self.head.head.weight.float(), self.head.head.bias.float()).view(B, L_loc, -1)
-            if sp is not None:
-                out = sp.gather_tokens(out, L_)
+        hw = self._fused.get("head")
+        hver = (self.head.head.weight._version, self.head.head.bias._version, self.head.modulation._version)
+        if hw is None or hw[3] != hver:   # the fp32 island's up-cast of the (bf16) head parameters; in-place updates noticed
+            hw = self._fused["head"] = (self.head.head.weight.detach().float().contiguous(),
+                                       self.head.head.bias.detach().float().contiguous(),
+                                       self.head.modulation.detach().float().contiguous().view(1, 2, self.dim), hver)
+        em = K.bcast_add(hw[2], e_B_D.view(B, 1, self.dim))[0]    # [B, 2, dim] = modulation + e
+        out = K.head(x, em[:, 1].contiguous(), em[:, 0].contiguous(), hw[0], hw[1], self.eps, self.out_dim, T, H, W,
+                     unpatchify=sp is None, row0=row0)
+        if sp is None:
+            return out
+        out = sp.gather_tokens(out, L_)
         # unpatchify "b (t h w) (kt kh kw d) -> b d (t kt) (h kh) (w kw)"   (wan2pt1.py:710-721)
         out = out.view(B, T, H, W, kt, kh, kw, self.out_dim).permute(0, 7, 1, 4, 2, 5, 3, 6)
         return out.reshape(B, self.out_dim, T * kt, H * kh, W * kw)
+
+    def _check_embed_head_support(self, C, dt, t_dtype):
+        """What csrc/embed_head.hip is built for — checked once per forward, refused by name."""
+        kt, kh, kw = self.patch_size
+        bad = []
+        if (kt, kh, kw) != (1, 2, 2):
+            bad.append(f"patch_size {self.patch_size} (need (1, 2, 2), the Wan2.1 / 2.2 patch)")
+        if C % 4 or C > 64:
+            bad.append(f"{C} input channels (need a multiple of 4, at most 64: 16 for T2V, 36 for I2V)")
+        if dt not in (torch.bfloat16, torch.float16):
+            bad.append(f"model dtype {dt} (need bfloat16 or float16)")
+        pe = self.patch_embedding
+        if pe.weight.dtype != dt or pe.bias.dtype != dt:
+            bad.append(f"patch_embedding parameters in {pe.weight.dtype} (need the model dtype {dt})")
+        for name, m in (("time_embedding.0", self.time_embedding[0]), ("time_embedding.2", self.time_embedding[2]),
+                        ("time_projection.1", self.time_projection[1])):
+            if m.weight.dtype not in (torch.bfloat16, torch.float16) or m.bias.dtype != m.weight.dtype:
+                bad.append(f"{name} parameters in {m.weight.dtype} (td_gemv_f32 reads 16-bit weights and widens them, as the "
+                           "reference's autocast(float32) island does)")
+        if t_dtype not in (torch.bfloat16, torch.float16):
+            bad.append(f"timesteps in {t_dtype} (the reference passes them in the model dtype, wan2.1_t2v_infer.py:131)")
+        if self.dim % 8 or self.out_dim * 4 > 64:
+            bad.append(f"dim {self.dim} / out_dim {self.out_dim} (need dim % 8 == 0, out_dim <= 16)")
+        if bad:
+            raise ValueError("WanModel.forward on the MI355X kernels does not take: " + "; ".join(bad))
 
 
 MODEL_CONFIGS = {  # inference/modify_model.py:86-127
