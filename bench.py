@@ -759,10 +759,50 @@ def main():
         except Exception as e:  # an extra, never fatal
             p2p = {"error": repr(e)}
 
+    multi = None
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        cdev = dev if backend == "nccl" else "cpu"
+        mine = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                        # per-rank wall time of the timed region (same barriers on both sides)
+        per_rank = [t_.item() / args.steps / args.num_steps * 1e3 for t_ in every]
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
+        # ---- what the first real multi-GPU record must be able to validate (the 120 GB/s wire model, "only the
+        # first head group's transfer exposed"): one more DiT forward enqueued EAGERLY with an event pair around every
+        # stream-side wait for an asynchronous gather (seqpar.WAIT_PROBE) — the time the compute stream sat waiting for the
+        # wire, per collective, on every rank
+        waits = None
+        if sp > 1:
+            from turbodiffusion_amd import seqpar as _sq
+            _sq.WAIT_PROBE = []
+            sync()
+            with torch.no_grad():
+                net(init_noise.to(net.dtype), torch.full((1, 1), 900.0, device=dev, dtype=net.dtype), texts[0], y_B_C_T_H_W=y)
+            sync()
+            probe, _sq.WAIT_PROBE = _sq.WAIT_PROBE, None
+            ms = [a_.elapsed_time(b_) for a_, b_, _ in probe]
+            nl = cfg["num_layers"]
+            loc = torch.tensor([sum(ms), max(ms) if ms else 0.0, float(len(ms))], device=cdev, dtype=torch.float64)
+            allw = [torch.zeros_like(loc) for _ in range(world)]
+            dist.all_gather(allw, loc)
+            waits = {"waits_probed_per_forward": int(loc[2].item()),
+                     "exposed_wait_ms_per_dit_step": {"min_over_ranks": min(w_[0].item() for w_ in allw), "max_over_ranks": max(w_[0].item() for w_ in allw)},
+                     "exposed_wait_us_per_layer_rank0": (sum(ms) / nl * 1e3) if nl else None,
+                     "longest_single_wait_ms": max(w_[1].item() for w_ in allw),
+                     "bytes_gathered_per_forward_rank0": int(sum(b_ for _, _, b_ in probe)),
+                     "what": "HIP events around every work.wait() of an asynchronous all-gather in ONE eagerly enqueued DiT forward after the "
+                             "timed region (compute-stream time spent waiting for the wire; 0 probes: the backend gathers synchronously — the gloo rig)"}
+        nccl_ver = None
+        try:
+            nccl_ver = ".".join(str(v_) for v_ in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        multi = {"rccl": {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "nccl_version": nccl_ver,
+                          "sequence_parallel_group_size": sp, "graph_mode": None},
+                 "per_rank_dit_step_ms": {"min": min(per_rank), "max": max(per_rank), "all": [round(v_, 3) for v_ in per_rank]},
+                 "exposed_wait": waits}
     assert torch.isfinite(out).all(), "non-finite latents"
 
     # ---- throughput mode beside it (N > 1, sequence-parallel timed region): N independent videos, one per rank, the
@@ -944,22 +984,26 @@ def main():
             at = wl["attention_type"]
             lay = PackLayout(cfg["num_heads"], spo.per, 128, spo.groups_for(cfg["num_heads"], spo.per), at in ("sage", "sagesla"), at in ("original", "sage"),
                              torch.bfloat16)
-            pack = lay.gb * lay.G                       # bytes a rank sends to EVERY peer per self-attention layer
+            pack = lay.total                            # bytes a rank sends to EVERY peer per self-attention layer
             link = 120e9                                # effective B/s of one xGMI link (153 GB/s peak; full mesh: one link per peer)
             nl = cfg["num_layers"]
             wire_layer = pack / link                    # every peer's pack arrives over its own link, all in parallel
             # what the emulation ADDS to a real rank's kernels: the device copies that fill the peers' slots of the gathered
             # buffers (in a real run those bytes arrive over xGMI, written by the fabric, not by this GPU's CUs) — timed
             # alone here, the same shapes back to back, so that the table can state the compute term with and without them
-            src_ = torch.empty(lay.gb, dtype=torch.uint8, device=dev)
-            dst_ = torch.empty((emu[1], lay.gb), dtype=torch.uint8, device=dev)
+            srcs_ = [torch.empty(n_, dtype=torch.uint8, device=dev) for _, n_ in lay.pieces]
+            dsts_ = [torch.empty((emu[1], n_), dtype=torch.uint8, device=dev) for _, n_ in lay.pieces]
+
+            def copies():
+                for s_, d_ in zip(srcs_, dsts_):
+                    d_.copy_(s_.view(1, -1).expand(emu[1], -1))
             for _ in range(3):
-                dst_.copy_(src_.view(1, -1).expand(emu[1], -1))
+                copies()
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             ev0.record()
-            for _ in range(nl * lay.G):
-                dst_.copy_(src_.view(1, -1).expand(emu[1], -1))
+            for _ in range(nl):
+                copies()
             ev1.record()
             torch.cuda.synchronize()
             copy_ms = ev0.elapsed_time(ev1)
@@ -972,12 +1016,15 @@ def main():
                 "branches_in_parallel": bool(spo.branches_in_parallel(cfg["num_heads"], spo.per, lay.G)),
                 "pack_bytes_per_layer": pack, "head_groups": lay.G,
                 "modelled_wire_ms_per_dit_step": {"link_GBps": link / 1e9, "fully_exposed": nl * wire_layer * 1e3,
-                                                  "first_head_group_exposed": nl * wire_layer / lay.G * 1e3},
+                                                  "first_head_group_exposed": nl * wire_layer * lay.pieces[0][1] / lay.total * 1e3},
                 "what": "one rank's kernels of an N-way sequence split on one GPU: its token shard, gathered buffers of the real "
                         "size filled by device copies of its own pack (the HBM writes of the incoming xGMI traffic, NOT overlapped), "
                         "no communication; the step of a real N-GPU run = this compute term + the exposed part of the wire term"}
         if use_graph and getattr(run_net, "sp_capture_error", None):
             res["launch_mode"] = "eager enqueue (segmented hipGraph capture failed: " + run_net.sp_capture_error + ")"
+        if multi is not None:
+            multi["rccl"]["graph_mode"] = (getattr(run_net, "sp_graph_mode", None) or "one hipGraph per DiT forward") if use_graph else "eager enqueue"
+            res.update(multi)
         if box is not None:
             res["box"] = box
         res["config"]["prompts"] = ("a new text embedding per video: the per-prompt work (text MLP, all-blocks cross-attention "

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TD_ABI_VERSION 3
+#define TD_ABI_VERSION 4
 
 /* status codes */
 #define TD_OK 0
@@ -396,11 +396,32 @@ int td_attn_i8_sp(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, cons
                   const int32_t* lut, int nsel, void* o, int out_dtype, int64_t o_stride_h, int64_t o_stride_l,
                   float sm_scale, int64_t L, int64_t Lk, int H, int kb_per_rank, int64_t k_rank_stride,
                   int64_t ks_rank_stride, int64_t vt_rank_stride, const void* add_t, int8_t* q_out, float* q_scale,
-                  td_stream_t stream);
+                  int q_heads_total, td_stream_t stream);
 int td_attn_16_sp(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o, int dtype,
                   int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int H,
                   int kb_per_rank, int64_t k_rank_stride, int64_t vt_rank_stride, const void* add_t, int8_t* q_out,
-                  float* q_scale, td_stream_t stream);
+                  float* q_scale, int q_heads_total, td_stream_t stream);
+/* (ABI v4) q_heads_total: the head count of the WHOLE [L, heads * 128] quantised output row when this launch covers a head
+ * GROUP of it (q_out / q_scale then point at the group's first head: q_out + h0 * 128, q_scale + h0); 0 = H.
+ *
+ * Round-5 entry points of the sequence-parallel layer (fewer launches in front of its latency-bound exchanges):
+ *  td_seq_sum            per-head column sums of k [H, L, 128] -> out f32 [H, 128]: td_seq_sum_partial's 64 row chunks per head + a
+ *                        128-thread pass per head that adds the chunk partials in order (two launches; a one-launch form with an
+ *                        atomic ticket cost 10x more: a device-scope fence per workgroup flushes the XCD's L2 — csrc/sla_prep.hip).
+ *                        ws f32 [H, 64, 128] scratch; `tickets` is unused (kept in the v4 signature).
+ *  td_qk_norm_rope_pair  td_qk_norm_rope for the q AND the k columns of a fused projection in one launch (bit-identical).
+ *  td_sage_quant_pool_packed_kmsum
+ *                        td_sage_quant_pool_packed with the smooth-K mean either given (km) or formed in the kernel from km_n (<= 8)
+ *                        per-rank column sums (km_parts: the gathered td_seq_sum outputs, km_stride floats apart) over km_rows
+ *                        global rows — the arithmetic of td_seq_mean_final, without its launch — and a head layout of its own
+ *                        (pool_hg, pool_gs_bytes; hg = 0: flat) for `pooled`. */
+int td_seq_sum(const void* k, float* ws, float* out, unsigned int* tickets, int dtype, int64_t L, int H, int D, td_stream_t stream);
+int td_qk_norm_rope_pair(const void* src_q, const void* src_k, int64_t ld_src, const float* w_q, const float* w_k,
+                         const float* cosv, const float* sinv, void* dst_q, void* dst_k, int dtype, float eps, int64_t L, int H,
+                         int D, td_stream_t stream);
+int td_sage_quant_pool_packed_kmsum(const void* x, const void* km, const float* km_parts, int km_n, int64_t km_stride, int64_t km_rows,
+                                    int dtype, int pool_blk, void* pooled, int pool_hg, int64_t pool_gs_bytes, int8_t* xq, float* xs,
+                                    int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes, int H, int D, td_stream_t stream);
 int td_sla_topk_sp(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb, int Kb, int kb_per_rank,
                    int64_t pk_rank_stride, int D, int topk, td_stream_t stream);
 

@@ -27,6 +27,18 @@ def seq_sum_partial(k, out=None):
     return ws
 
 
+def seq_sum(k, tickets=None, out=None):
+    """kernels.seq_sum: this rank's per-head column sums f32 [H, D] (chunk partials added in order)."""
+    ws = seq_sum_partial(k)
+    s = torch.zeros(k.shape[0], k.shape[2])
+    for c in range(64):
+        s = s + ws[:, c]
+    if out is not None:
+        out.copy_(s)
+        return out
+    return s
+
+
 def seq_mean_final(ws, nch, stride_h, stride_c, L_total, H, D, dtype):
     v = _strided(ws, (H, nch, D), (stride_h, stride_c, 1))
     s = torch.zeros(H, D)
@@ -167,27 +179,63 @@ def sla_topk_sp(pq, pk_g, topk, kb):
     return sla_topk(pq, _seq_major(pk_g), topk, kb=kb)
 
 
-def attn_i8_sp(q_i8, q_s, k_g, ks_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
-    return attn_i8(q_i8, q_s, _seq_major(k_g), _seq_major(ks_g), _seq_major(vt_g), lut, out, o_stride_h, o_stride_l,
-                   sm_scale=sm_scale, lk=lk, add_t=add_t)
+def _group_quant(o, quant_out):
+    """the head group's [H, L, D] result block-quantised into its columns / scale entries of the whole-row outputs."""
+    from oracle import ops_ref as O
+    oq, os_, h0, Ht = quant_out
+    H, L, D = o.shape
+    q, sc = O.quant_block128(o.permute(1, 0, 2).reshape(L, H * D).contiguous())
+    oq[:, h0 * D:(h0 + H) * D] = q
+    os_[:, h0:h0 + H] = sc
 
 
-def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
-    return attn_16(q, _seq_major(k_g), _seq_major(vt_g), lut, out, o_stride_h, o_stride_l, sm_scale=sm_scale, lk=lk,
-                   add_t=add_t)
+def attn_i8_sp(q_i8, q_s, k_g, ks_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None, quant_out=None):
+    if quant_out is None:
+        return attn_i8(q_i8, q_s, _seq_major(k_g), _seq_major(ks_g), _seq_major(vt_g), lut, out, o_stride_h, o_stride_l,
+                       sm_scale=sm_scale, lk=lk, add_t=add_t)
+    H, L, D = q_i8.shape
+    tmp = torch.empty((H, L, D), dtype=out if isinstance(out, torch.dtype) else out.dtype)
+    attn_i8(q_i8, q_s, _seq_major(k_g), _seq_major(ks_g), _seq_major(vt_g), lut, tmp, L * D, D, sm_scale=sm_scale, lk=lk, add_t=add_t)
+    _group_quant(tmp, quant_out)
+    return out
 
 
-def sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay):
-    """CPU stand-in of kernels.sp_pack_k_side: the flat oracle results copied into the sections of the send buffer."""
+def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None, quant_out=None):
+    if quant_out is None:
+        return attn_16(q, _seq_major(k_g), _seq_major(vt_g), lut, out, o_stride_h, o_stride_l, sm_scale=sm_scale, lk=lk,
+                       add_t=add_t)
+    H, L, D = q.shape
+    tmp = torch.empty((H, L, D), dtype=q.dtype)
+    attn_16(q, _seq_major(k_g), _seq_major(vt_g), lut, tmp, L * D, D, sm_scale=sm_scale, lk=lk, add_t=add_t)
+    _group_quant(tmp, quant_out)
+    return out
+
+
+def sp_pack_begin(k, v_src, v_strides, L_loc, lay, lin_kv=None, lin_ks=None):
+    """CPU stand-in of kernels.sp_pack_begin: V^T tiles into the send buffer, the linear-branch partials into the early buffer."""
     H, _, D = k.shape
     kb_loc = -(-L_loc // 64)
-    pack = torch.zeros((lay.G, lay.gb), dtype=torch.uint8)
-
-    def put(name, t, n):   # t [H, n_valid, ...] -> section [G, hg, n_alloc, ...][:, :, :n]
-        lay.section(pack, name)[:, :, :n] = t.reshape((lay.G, lay.hg) + tuple(t.shape[1:]))
-
+    pack = torch.zeros((lay.total,), dtype=torch.uint8)
     vt = v_transpose(v_src, v_strides[0], v_strides[1], L_loc, H, D, lay.pdt)
-    put("vt", vt, kb_loc)
+    lay.group_section(pack, "vt")[:, :, :kb_loc] = vt.reshape((lay.G, lay.hg) + tuple(vt.shape[1:]))
+    if lay.linear:
+        kv32, ks32 = sla_linear_kv_partial_f32(k, vt)
+        lin_kv.copy_(kv32)
+        lin_ks.copy_(ks32)
+    return pack
+
+
+def sp_pack_finish(pack, k, km, L_loc, lay):
+    """CPU stand-in of kernels.sp_pack_finish.  km: [H, D] or (gathered column sums f32 [W, H, D], L_total)."""
+    H, _, D = k.shape
+    if isinstance(km, tuple):
+        allp, L_tot = km
+        km = seq_mean_final(allp, allp.shape[0], D, allp.stride(0), L_tot, H, D, k.dtype)
+    kb_loc = -(-L_loc // 64)
+
+    def put(name, t, n):   # t [H, n_valid, ...] -> group section [G, hg, n_alloc, ...][:, :, :n]
+        lay.group_section(pack, name)[:, :, :n] = t.reshape((lay.G, lay.hg) + tuple(t.shape[1:]))
+
     if lay.sage:
         pk, k_q, k_s = sage_quant_pool(k, km, 64, want_pool=not lay.dense)
         put("k", k_q, L_loc)
@@ -196,9 +244,5 @@ def sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay):
         put("k", k, L_loc)
         pk = sage_quant_pool(k, km, 64, want_quant=False)[0] if not lay.dense else None
     if not lay.dense:
-        put("pk", pk, kb_loc)
-    if lay.linear:
-        kv32, ks32 = sla_linear_kv_partial_f32(k, vt)
-        lay.section(pack, "kv").copy_(kv32.reshape(lay.G, lay.hg, D, D))
-        lay.section(pack, "kss").copy_(ks32.reshape(lay.G, lay.hg, D))
+        lay.all_section(pack, "pk")[:, :kb_loc] = pk
     return pack

@@ -72,6 +72,12 @@ def test_bench_self_spawns_ranks_without_a_launcher():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "strong"
     assert "sp2" in r["config"]["parallelism"]
+    # round 5: what the first real multi-GPU record needs in order to check the scaling model
+    assert r["rccl"]["world_size"] == 2 and r["rccl"]["backend"] == "gloo" and "segments" in r["rccl"]["graph_mode"], r["rccl"]
+    pr = r["per_rank_dit_step_ms"]
+    assert len(pr["all"]) == 2 and 0 < pr["min"] <= pr["max"]
+    ew = r["exposed_wait"]
+    assert ew["waits_probed_per_forward"] == 0 and "exposed_wait_ms_per_dit_step" in ew     # gloo gathers synchronously through the host
 
 
 def test_bench_emulated_rank_reports_compute_and_wire_terms():

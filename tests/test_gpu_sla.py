@@ -502,12 +502,14 @@ def test_sp_pack_k_side_is_bit_identical_to_flat_producers(K, sage, dense, L_loc
     km = K.seq_mean(k) if (sage or not dense) else None
     lay = PackLayout(H, per, D, 4, sage, dense, dt)
     assert (lay.G, lay.hg) == (3, 2)
-    pack = K.sp_pack_k_side(k, km, v, (D, H * D), L_loc, lay)
-    assert pack.shape == (lay.G, lay.gb) and pack.dtype == torch.uint8
+    lin_kv = torch.empty((H, D, D), dtype=torch.float32, device="cuda")
+    lin_ks = torch.empty((H, D), dtype=torch.float32, device="cuda")
+    pack = K.sp_pack_k_side(k, km, v, (D, H * D), L_loc, lay, lin_kv, lin_ks)
+    assert pack.shape == (lay.total,) and pack.dtype == torch.uint8 and lay.total == lay.ab + lay.G * lay.gb
     kb = -(-L_loc // 64)
 
     def sec(name, n):
-        return lay.section(pack, name)[:, :, :n].reshape((H, n) + lay.spec[name][1][2:])
+        return lay.group_section(pack, name)[:, :, :n].reshape((H, n) + lay.spec[name][1][2:])
 
     vt = K.v_transpose(v, D, H * D, L_loc, H, D, lay.pdt)
     assert torch.equal(sec("vt", kb), vt)
@@ -518,12 +520,11 @@ def test_sp_pack_k_side_is_bit_identical_to_flat_producers(K, sage, dense, L_loc
         assert torch.equal(sec("k", L_loc), k)
         pk = K.sage_quant_pool(k, km, 64, want_quant=False)[0] if not dense else None
     if not dense:
-        assert torch.equal(sec("pk", kb), pk)
+        assert torch.equal(lay.all_section(pack, "pk")[:, :kb], pk)          # pooled K of ALL heads: the flat all-head section
         kv32, ks32 = K.sla_linear_kv_partial_f32(k, vt)
-        assert torch.equal(lay.section(pack, "kv").reshape(H, D, D), kv32)
-        assert torch.equal(lay.section(pack, "kss").reshape(H, D), ks32)
+        assert torch.equal(lin_kv, kv32) and torch.equal(lin_ks, ks32)       # linear-branch partials: the early send buffer
     if L_loc < per:   # the padding of a short rank is zero (never read as valid, but must be finite)
-        assert int(lay.section(pack, "vt")[:, :, kb:].abs().sum()) == 0
+        assert int(lay.group_section(pack, "vt")[:, :, kb:].abs().sum()) == 0
 
 
 def test_attn_i8_two_per_cu_build_is_bit_identical(K):

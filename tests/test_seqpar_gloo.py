@@ -140,21 +140,35 @@ def test_plan_covers_all_tokens_block_aligned():
 
 
 def test_pack_layout_groups_and_alignment():
-    """PackLayout: equal head groups (largest divisor of H not above head_groups), 256-byte aligned sections, and the
-    section views address disjoint byte ranges of a group."""
+    """PackLayout (round-5 form): equal head groups (largest divisor of H not above head_groups); ONE flat buffer = the all-head
+    block (pooled K, linear-branch partials of ALL heads) followed by the group blocks (K codes, V^T tiles, K scales); 256-byte
+    aligned sections addressing disjoint byte ranges; G pieces, the first = all-head block + group 0; the views of the local
+    buffer and of the gathered pieces name the same bytes."""
     import torch
     from turbodiffusion_amd.seqpar import PackLayout
     for H, want in ((12, 4), (40, 4), (6, 3), (5, 1), (2, 2), (1, 1)):
         lay = PackLayout(H, 256, 128, 4, True, False, torch.bfloat16)
         assert lay.G == want and lay.hg * lay.G == H
-        assert all(o % 256 == 0 for o in lay.offs.values()) and lay.gb % 256 == 0
-        ends = sorted((lay.offs[n], lay.offs[n] + lay.sizes[n]) for n in lay.sizes if lay.sizes[n])
-        assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])) and ends[-1][1] <= lay.gb
-        buf = torch.zeros((lay.G, lay.gb), dtype=torch.uint8)
-        assert lay.section(buf, "vt").shape == (lay.G, lay.hg, 4, 128, 64) and lay.section(buf, "vt").dtype == torch.float16
-        assert lay.section(buf, "k").dtype == torch.int8 and lay.section(buf, "kv").shape == (lay.G, lay.hg, 128, 128)
+        for offs, sizes, ext in ((lay.offs, lay.sizes, lay.gb), (lay.aoffs, lay.asizes, lay.ab)):
+            assert all(o % 256 == 0 for o in offs.values()) and ext % 256 == 0
+            ends = sorted((offs[n], offs[n] + sizes[n]) for n in sizes if sizes[n])
+            assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])) and ends[-1][1] <= ext
+        assert lay.total == lay.ab + lay.G * lay.gb and len(lay.pieces) == lay.G
+        assert lay.pieces[0] == (0, lay.ab + lay.gb) and all(lay.pieces[g] == (lay.ab + g * lay.gb, lay.gb) for g in range(1, lay.G))
+        assert sum(n for _, n in lay.pieces) == lay.total
+        buf = torch.arange(lay.total, dtype=torch.int64).to(torch.uint8)
+        assert lay.group_section(buf, "vt").shape == (lay.G, lay.hg, 4, 128, 64) and lay.group_section(buf, "vt").dtype == torch.float16
+        assert lay.group_section(buf, "k").dtype == torch.int8 and lay.early_sum == H * 128 and lay.early_lin == H * 128 * 129
+        assert lay.all_section(buf, "pk").shape == (H, 4, 128) and lay.all_section(buf, "pk").dtype == torch.bfloat16
+        # "gathered" by one rank: the pieces of the local buffer ARE the rows of the gather outputs
+        outs = [lay.piece(buf, g).view(1, -1) for g in range(lay.G)]
+        assert torch.equal(lay.gathered(outs, None, "pk")[0].view(torch.uint8), lay.all_section(buf, "pk").view(torch.uint8))
+        for g in range(lay.G):
+            for name in ("k", "vt", "ks"):
+                assert torch.equal(lay.gathered(outs, g, name)[0].reshape(-1).view(torch.uint8),
+                                   lay.group_section(buf, name)[g].reshape(-1).view(torch.uint8)), (H, g, name)
     dense = PackLayout(12, 256, 128, 4, False, True, torch.bfloat16)     # "original": 16-bit K, no scales / pooled / partials
-    assert dense.sizes["ks"] == dense.sizes["pk"] == dense.sizes["kv"] == 0 and dense.spec["k"][0] == torch.bfloat16
+    assert dense.sizes["ks"] == dense.asizes["pk"] == dense.early_lin == 0 and dense.spec["k"][0] == torch.bfloat16 and dense.ab == 0
 
 
 def _reissue_worker(rank, world, port, ret):

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("TD_LIB_PATH") or os.path.join(_HERE, "libturbodiffusi
 
 TD_F16, TD_BF16, TD_F32 = 0, 1, 2
 TD_EPI_NONE, TD_EPI_GELU_TANH = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -66,9 +66,13 @@ SIGNATURES = {
     "td_row_stats_finalize": [_vp, _i32, _i64, _f32, _i64, _i32, _vp, _i64, _vp],
     "td_layernorm_quant_stats": [_vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp],
     "td_attn_i8_sp": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _i64,
-                      _vp, _vp, _vp, _vp],
+                      _vp, _vp, _vp, _i32, _vp],
     "td_attn_16_sp": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _vp, _vp, _vp,
-                      _vp],
+                      _i32, _vp],
+    "td_seq_sum": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
+    "td_qk_norm_rope_pair": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _i64, _i32, _i32, _vp],
+    "td_sage_quant_pool_packed_kmsum": [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _i64, _i64, _i32, _i64,
+                                        _i32, _i32, _vp],
     "td_sla_topk_sp": [_vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i64, _i32, _i32, _vp],
     "td_v_fp8_tiles": [_vp, _i32, _i64, _i64, _vp, _vp, _vp, _f32, _i64, _i32, _i32, _vp],
     "td_attn_i8_fp8pv": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp,

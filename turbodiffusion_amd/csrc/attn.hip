@@ -44,6 +44,7 @@ struct AttnParams {
   int8_t* q_out;          // optional: block-quantised output int8 [L, q_ld] instead of o ...
   float* q_scale;         // ... with scales [ceil(L/128), H]  (== td_quant_i8_block128 of the [L, H*128] output)
   int64_t q_ld;
+  int q_heads;            // heads of the WHOLE output row (>= H: a head-group launch writes its H heads' columns / scales at a shifted origin)
   // optional (16-bit kernel): Q read straight from a [L, ld] GEMM output with its RMSNorm applied on load
   int64_t q_stride_h, q_stride_l;   // bytes; 0 = the packed [H, L, 128] layout
   const float* q_rstd;              // [L] 1/rms of the row over the FULL model dim (td_rms_stats), or null
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
     m16 = max(max(red[0], red[1]), max(red[2], red[3]));
     const float amax = fmaxf(half_bits_to_f32<ODT>(m16), 1e-8f);
     const float mult = 128.0f / amax;
-    if (tid == 0) p.q_scale[(int64_t)qb * p.H + h] = amax / 128.0f;
+    if (tid == 0) p.q_scale[(int64_t)qb * p.q_heads + h] = amax / 128.0f;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
@@ -606,7 +607,7 @@ __device__ __forceinline__ void attn_tile_out(const AttnParams& p, char* smem, i
   m16 = max(max(red[0], red[1]), max(red[2], red[3]));
   const float amax = fmaxf(half_bits_to_f32<ODT>(m16), 1e-8f);
   const float mult = 128.0f / amax;
-  if (tid == 0) p.q_scale[(int64_t)qb * p.H + h] = amax / 128.0f;
+  if (tid == 0) p.q_scale[(int64_t)qb * p.q_heads + h] = amax / 128.0f;
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
     const int idx = tid + 256 * it, row = idx >> 4, ch = idx & 15;
@@ -925,8 +926,8 @@ static int attn_stride_check(const char* who, int64_t o_stride_h, int64_t o_stri
   return TD_OK;
 }
 
-struct AttnGather { int kbp; int64_t k_rs, v_rs, ks_rs; };
-static const AttnGather kFlat = {0, 0, 0, 0};
+struct AttnGather { int kbp; int64_t k_rs, v_rs, ks_rs; int q_heads; };
+static const AttnGather kFlat = {0, 0, 0, 0, 0};
 
 static int attn_i8_impl(const int8_t* q_i8, const float* q_s, const int8_t* k_i8, const float* k_s,
                              const void* vt, const float* v_scale, const int32_t* lut, int nsel, void* o, int out_dtype,
@@ -943,7 +944,7 @@ static int attn_i8_impl(const int8_t* q_i8, const float* q_s, const int8_t* k_i8
   AttnParams p;
   p.q = q_i8; p.q_s = q_s; p.k = k_i8; p.k_s = k_s; p.vt = (const uint16_t*)vt; p.lut = lut;
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
-  p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
+  p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_heads = ga.q_heads > 0 ? ga.q_heads : H; p.q_ld = (int64_t)p.q_heads * 128;
   p.q_stride_h = 0; p.q_stride_l = 0; p.q_rstd = nullptr; p.q_w = nullptr; p.v_scale = v_scale;
   p.kbp = ga.kbp; p.k_rs = ga.k_rs; p.v_rs = ga.v_rs; p.ks_rs = ga.ks_rs;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
@@ -1004,7 +1005,7 @@ static int attn_16_impl(const char* who, const void* q, int64_t q_stride_h, int6
   AttnParams p;
   p.q = q; p.q_s = nullptr; p.k = k; p.k_s = nullptr; p.vt = (const uint16_t*)vt; p.lut = lut;
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
-  p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_ld = (int64_t)H * 128;
+  p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_heads = ga.q_heads > 0 ? ga.q_heads : H; p.q_ld = (int64_t)p.q_heads * 128;
   p.q_stride_h = q_stride_h; p.q_stride_l = q_stride_l; p.q_rstd = q_rstd; p.q_w = q_w; p.v_scale = nullptr;
   p.kbp = ga.kbp; p.k_rs = ga.k_rs; p.v_rs = ga.v_rs; p.ks_rs = ga.ks_rs;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
@@ -1055,11 +1056,12 @@ extern "C" int td_attn_i8_sp(const int8_t* q_i8, const float* q_s, const int8_t*
                              const void* vt, const int32_t* lut, int nsel, void* o, int out_dtype,
                              int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int H,
                              int kb_per_rank, int64_t k_rank_stride, int64_t ks_rank_stride, int64_t vt_rank_stride,
-                             const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream) {
+                             const void* add_t, int8_t* q_out, float* q_scale, int q_heads_total, td_stream_t stream) {
   TD_REQUIRE(kb_per_rank > 0 && k_rank_stride > 0 && ks_rank_stride > 0 && vt_rank_stride > 0, TD_ERR_INVALID,
              "td_attn_i8_sp: gathered layout kb_per_rank=%d", kb_per_rank);
   TD_REQUIRE(k_rank_stride % 16 == 0 && vt_rank_stride % 16 == 0, TD_ERR_UNSUPPORTED, "td_attn_i8_sp: rank strides must be 16-byte multiples");
-  const AttnGather ga = {kb_per_rank, k_rank_stride, vt_rank_stride, ks_rank_stride};
+  TD_REQUIRE(q_heads_total == 0 || q_heads_total >= H, TD_ERR_INVALID, "td_attn_i8_sp: q_heads_total=%d < H=%d", q_heads_total, H);
+  const AttnGather ga = {kb_per_rank, k_rank_stride, vt_rank_stride, ks_rank_stride, q_heads_total};
   return attn_i8_impl(q_i8, q_s, k_i8, k_s, vt, nullptr, lut, nsel, o, out_dtype, o_stride_h, o_stride_l, sm_scale, L, Lk,
                       0, H, add_t, q_out, q_scale, stream, ga);
 }
@@ -1067,11 +1069,12 @@ extern "C" int td_attn_i8_sp(const int8_t* q_i8, const float* q_s, const int8_t*
 extern "C" int td_attn_16_sp(const void* q, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
                              int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
                              int H, int kb_per_rank, int64_t k_rank_stride, int64_t vt_rank_stride, const void* add_t,
-                             int8_t* q_out, float* q_scale, td_stream_t stream) {
+                             int8_t* q_out, float* q_scale, int q_heads_total, td_stream_t stream) {
   TD_REQUIRE(kb_per_rank > 0 && k_rank_stride > 0 && vt_rank_stride > 0, TD_ERR_INVALID,
              "td_attn_16_sp: gathered layout kb_per_rank=%d", kb_per_rank);
   TD_REQUIRE(k_rank_stride % 16 == 0 && vt_rank_stride % 16 == 0, TD_ERR_UNSUPPORTED, "td_attn_16_sp: rank strides must be 16-byte multiples");
-  const AttnGather ga = {kb_per_rank, k_rank_stride, vt_rank_stride, 0};
+  TD_REQUIRE(q_heads_total == 0 || q_heads_total >= H, TD_ERR_INVALID, "td_attn_16_sp: q_heads_total=%d < H=%d", q_heads_total, H);
+  const AttnGather ga = {kb_per_rank, k_rank_stride, vt_rank_stride, 0, q_heads_total};
   return attn_16_impl("td_attn_16_sp", q, 0, 0, nullptr, nullptr, k, vt, lut, nsel, o, dtype, o_stride_h, o_stride_l,
                       sm_scale, L, Lk, 0, H, add_t, q_out, q_scale, stream, ga);
 }

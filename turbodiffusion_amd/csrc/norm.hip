@@ -307,15 +307,19 @@ extern "C" int td_rms_stats(const void* src, int64_t ld_src, int dtype, float* r
 // q/k: RMSNorm over the full model dim -> cast -> interleaved RoPE (fp32) -> cast -> [H,L,D]
 // ---------------------------------------------------------------------------------------
 template <int NV, int DT>
-__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __restrict__ src,
-                                                           int64_t ld_src, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* src,
+                                                           int64_t ld_src, const float* w,
                                                            const float* __restrict__ cosv,
                                                            const float* __restrict__ sinv,
-                                                           uint16_t* __restrict__ dst, float eps,
-                                                           int64_t L, int H, int D) {
+                                                           uint16_t* dst, float eps,
+                                                           int64_t L, int H, int D,
+                                                           const uint16_t* __restrict__ src2 = nullptr,
+                                                           const float* __restrict__ w2 = nullptr,
+                                                           uint16_t* __restrict__ dst2 = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= L) return;
+  if (blockIdx.y == 1) { src = src2; w = w2; dst = dst2; }   // td_qk_norm_rope_pair: q and k of a fused projection in ONE launch
   const int n = H * D;
   float f[NV][8];
   float sq = 0.f;
@@ -402,10 +406,12 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const uint16_t* __res
   }
 }
 
-extern "C" int td_qk_norm_rope(const void* src, int64_t ld_src, const float* w, const float* cosv,
-                               const float* sinv, void* dst, int dtype, float eps, int64_t L, int H,
-                               int D, td_stream_t stream) {
+static int qk_norm_rope_impl(const void* src, int64_t ld_src, const float* w, const float* cosv,
+                            const float* sinv, void* dst, const void* src2, const float* w2, void* dst2, int dtype, float eps,
+                            int64_t L, int H, int D, td_stream_t stream) {
   TD_REQUIRE(src && dst, TD_ERR_INVALID, "td_qk_norm_rope: null pointer");
+  TD_REQUIRE((src2 == nullptr) == (dst2 == nullptr) && (src2 != nullptr || w2 == nullptr) && (src2 == nullptr || (w == nullptr) == (w2 == nullptr)),
+             TD_ERR_INVALID, "td_qk_norm_rope_pair: second source / weight / destination mismatch");
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_qk_norm_rope: dtype %d", dtype);
   TD_REQUIRE((cosv == nullptr) == (sinv == nullptr), TD_ERR_INVALID, "td_qk_norm_rope: cos/sin mismatch");
   TD_REQUIRE(H > 0 && D > 0 && D % 8 == 0, TD_ERR_UNSUPPORTED, "td_qk_norm_rope: H=%d D=%d", H, D);
@@ -414,16 +420,18 @@ extern "C" int td_qk_norm_rope(const void* src, int64_t ld_src, const float* w, 
              "td_qk_norm_rope: dim=%lld ld=%lld", (long long)n, (long long)ld_src);
   if (L == 0) return TD_OK;
   const int nv = (int)td_cdiv(n, 512);
-  dim3 grid((unsigned)td_cdiv(L, 4));
+  dim3 grid((unsigned)td_cdiv(L, 4), src2 ? 2u : 1u);
   hipStream_t st = (hipStream_t)stream;
 #define TD_QK_NV(NV_)                                                                               \
   do {                                                                                              \
     if (dtype == TD_BF16)                                                                           \
       qk_norm_rope_kernel<NV_, TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)src, ld_src, w, cosv, \
-                                                               sinv, (uint16_t*)dst, eps, L, H, D);  \
+                                                               sinv, (uint16_t*)dst, eps, L, H, D,   \
+                                                               (const uint16_t*)src2, w2, (uint16_t*)dst2); \
     else                                                                                            \
       qk_norm_rope_kernel<NV_, TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)src, ld_src, w, cosv,  \
-                                                              sinv, (uint16_t*)dst, eps, L, H, D);   \
+                                                              sinv, (uint16_t*)dst, eps, L, H, D,    \
+                                                              (const uint16_t*)src2, w2, (uint16_t*)dst2); \
   } while (0)
   if (nv <= 1) TD_QK_NV(1);
   else if (nv <= 2) TD_QK_NV(2);
@@ -436,4 +444,19 @@ extern "C" int td_qk_norm_rope(const void* src, int64_t ld_src, const float* w, 
 #undef TD_QK_NV
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_qk_norm_rope(const void* src, int64_t ld_src, const float* w, const float* cosv,
+                               const float* sinv, void* dst, int dtype, float eps, int64_t L, int H,
+                               int D, td_stream_t stream) {
+  return qk_norm_rope_impl(src, ld_src, w, cosv, sinv, dst, nullptr, nullptr, nullptr, dtype, eps, L, H, D, stream);
+}
+
+// q AND k of a fused q|k|v projection in one launch (same row stride, same RoPE tables; each with its own RMSNorm weight):
+// == td_qk_norm_rope(src_q, .., w_q, .., dst_q) and td_qk_norm_rope(src_k, .., w_k, .., dst_k), bit for bit
+extern "C" int td_qk_norm_rope_pair(const void* src_q, const void* src_k, int64_t ld_src, const float* w_q, const float* w_k,
+                                    const float* cosv, const float* sinv, void* dst_q, void* dst_k, int dtype, float eps,
+                                    int64_t L, int H, int D, td_stream_t stream) {
+  TD_REQUIRE(src_k && dst_k, TD_ERR_INVALID, "td_qk_norm_rope_pair: null pointer");
+  return qk_norm_rope_impl(src_q, ld_src, w_q, cosv, sinv, dst_q, src_k, w_k, dst_k, dtype, eps, L, H, D, stream);
 }

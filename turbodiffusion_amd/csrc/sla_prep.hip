@@ -144,6 +144,44 @@ __global__ __launch_bounds__(1024) void seq_mean_final_kernel(const float* __res
   }
 }
 
+// The per-head column sums of a rank's K rows as f32 [H, 128] (round 5: the sequence-parallel layer's smooth-K exchange used
+// td_seq_sum_partial + a library reduction + a contiguous copy = three launches in front of a latency-bound all-gather): the
+// partial kernel above and this one, which adds a head's SM_CHUNKS partials IN ORDER — a fixed summation tree, deterministic.
+// (A one-launch form — the last workgroup of a head to finish, by an atomic ticket, adds the partials — was built first and
+// measured 57 us at [12, 4096, 128] against 4.8 + 2.5 us for the pair: every workgroup's device-scope release / acquire fence
+// writes back / invalidates its XCD's whole L2, dirty with the previous kernel's output.  No inter-workgroup hand-off inside a
+// kernel on this part.)
+__global__ __launch_bounds__(128) void seq_sum_final_kernel(const float* __restrict__ ws, float* __restrict__ out) {
+  const int h = blockIdx.x, d = threadIdx.x;
+  const float* p = ws + (int64_t)h * SM_CHUNKS * 128 + d;
+  float v[SM_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < SM_CHUNKS; ++c) v[c] = p[c * 128];     // all loads in flight together
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < SM_CHUNKS; ++c) s += v[c];
+  out[h * 128 + d] = s;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void seq_mean_partial_kernel(const uint16_t* __restrict__ k, float* __restrict__ ws, int64_t L);
+
+extern "C" int td_seq_sum(const void* k, float* ws, float* out, unsigned int* tickets, int dtype, int64_t L, int H, int D,
+                          td_stream_t stream) {
+  (void)tickets;   // (ABI v4 keeps the argument of the one-launch form; unused)
+  TD_REQUIRE(k && ws && out, TD_ERR_INVALID, "td_seq_sum: null pointer");
+  TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_seq_sum: D=%d (need 128)", D);
+  TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_seq_sum: dtype %d", dtype);
+  TD_REQUIRE(L > 0 && H > 0, TD_ERR_INVALID, "td_seq_sum: L=%lld H=%d", (long long)L, H);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(SM_CHUNKS, H);
+  if (dtype == TD_BF16) seq_mean_partial_kernel<TD_BF16><<<grid, 256, 0, st>>>((const uint16_t*)k, ws, L);
+  else seq_mean_partial_kernel<TD_F16><<<grid, 256, 0, st>>>((const uint16_t*)k, ws, L);
+  seq_sum_final_kernel<<<H, 128, 0, st>>>(ws, out);
+  TD_CHECK_LAUNCH();
+  return TD_OK;
+}
+
 extern "C" int td_seq_sum_partial(const void* k, float* ws, int dtype, int64_t L, int H, int D,
                                   td_stream_t stream) {
   TD_REQUIRE(k && ws, TD_ERR_INVALID, "td_seq_sum_partial: null pointer");
@@ -187,7 +225,11 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
                                                               uint16_t* __restrict__ pooled,
                                                               int8_t* __restrict__ xq,
                                                               float* __restrict__ xs, int64_t L, int64_t L_alloc,
-                                                              int nb, int hg, int64_t gs) {
+                                                              int nb, int hg, int64_t gs,
+                                                              const float* __restrict__ km_parts = nullptr, int km_n = 0,
+                                                              int64_t km_stride = 0, float km_rows = 1.f, int phg = -1,
+                                                              int64_t pgs = 0) {
+  if (phg < 0) { phg = hg; pgs = gs; }    // (phg, pgs): the head layout of `pooled` when it differs from that of xq / xs
   // nb = blocks ALLOCATED per head in pooled / xs (>= the blocks of L), L_alloc = rows allocated per head in xq; (hg, gs
   // in bytes): the packed head layout of td_common.h for the three outputs
   __shared__ float red[16][128];
@@ -197,6 +239,19 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
   const int blk = blockIdx.x, h = blockIdx.y;
   float kmf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (km != nullptr) unpack8<DT>(*reinterpret_cast<const uint4*>(km + h * 128 + c8 * 8), kmf);
+  if (km_parts != nullptr) {
+    // the smooth-K mean formed HERE from the km_n per-rank column sums f32 [km_n][H*128] (the gathered output of td_seq_sum):
+    // summed in rank order, divided by the global row count, rounded to the 16-bit dtype — td_seq_mean_final's arithmetic
+    // for up to 8 partials (its 8 slices then hold one partial each, added in order), without its launch
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < km_n; ++r) {
+      const float4 a = *reinterpret_cast<const float4*>(km_parts + r * km_stride + h * 128 + c8 * 8);
+      const float4 b = *reinterpret_cast<const float4*>(km_parts + r * km_stride + h * 128 + c8 * 8 + 4);
+      s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w; s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kmf[j] = half_bits_to_f32<DT>(f32_to_half_bits<DT>(s[j] / km_rows));
+  }
 
   uint4 raw[NIT];
 #pragma unroll
@@ -247,7 +302,7 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
     for (int r = 0; r < 16; ++r) s += red[r][tid];
     const int64_t rem = L - (int64_t)blk * BLK;
     const float cnt = (float)(rem < BLK ? rem : BLK);
-    pooled[td_head_off(h, hg, gs / 2, (int64_t)nb * 128) + (int64_t)blk * 128 + tid] = (uint16_t)f32_to_half_bits<DT>(s / cnt);
+    pooled[td_head_off(h, phg, pgs / 2, (int64_t)nb * 128) + (int64_t)blk * 128 + tid] = (uint16_t)f32_to_half_bits<DT>(s / cnt);
   }
   if (xq == nullptr) return;
   amax = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
@@ -278,10 +333,15 @@ __global__ __launch_bounds__(256) void sage_quant_pool_kernel(const uint16_t* __
   }
 }
 
-extern "C" int td_sage_quant_pool_packed(const void* x, const void* km, int dtype, int pool_blk, void* pooled,
-                                         int8_t* xq, float* xs, int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes,
-                                         int H, int D, td_stream_t stream) {
+static int sage_quant_pool_impl(const void* x, const void* km, const float* km_parts, int km_n, int64_t km_stride, int64_t km_rows,
+                                int dtype, int pool_blk, void* pooled, int8_t* xq, float* xs, int64_t L, int64_t L_alloc, int hg,
+                                int64_t gs_bytes, int H, int D, td_stream_t stream, int pool_hg = -1, int64_t pool_gs_bytes = 0) {
+  TD_REQUIRE(pool_hg < 0 || (pool_gs_bytes >= 0 && pool_gs_bytes % 16 == 0 && (pool_hg == 0 || H % pool_hg == 0)), TD_ERR_INVALID,
+             "td_sage_quant_pool: pooled layout hg=%d gs=%lld", pool_hg, (long long)pool_gs_bytes);
   TD_REQUIRE(x, TD_ERR_INVALID, "td_sage_quant_pool: null input");
+  TD_REQUIRE(km_parts == nullptr || (km == nullptr && km_n >= 1 && km_n <= 8 && km_stride >= (int64_t)H * 128 && km_stride % 4 == 0 && km_rows > 0),
+             TD_ERR_INVALID, "td_sage_quant_pool: smooth-K partials n=%d stride=%lld rows=%lld (need 1..8 partials, no km beside them)",
+             km_n, (long long)km_stride, (long long)km_rows);
   TD_REQUIRE(L_alloc >= L && hg >= 0 && gs_bytes >= 0 && gs_bytes % 16 == 0 && (hg == 0 || H % hg == 0), TD_ERR_INVALID,
              "td_sage_quant_pool: packed layout L_alloc=%lld hg=%d gs=%lld", (long long)L_alloc, hg, (long long)gs_bytes);
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_sage_quant_pool: D=%d (need 128)", D);
@@ -295,12 +355,31 @@ extern "C" int td_sage_quant_pool_packed(const void* x, const void* km, int dtyp
   hipStream_t st = (hipStream_t)stream;
 #define TD_SQP(DT_, B_)                                                                              \
   sage_quant_pool_kernel<DT_, B_><<<grid, 256, 0, st>>>((const uint16_t*)x, (const uint16_t*)km,      \
-                                                        (uint16_t*)pooled, xq, xs, L, L_alloc, nb_alloc, hg, gs_bytes)
+                                                        (uint16_t*)pooled, xq, xs, L, L_alloc, nb_alloc, hg, gs_bytes, \
+                                                        km_parts, km_n, km_stride, (float)km_rows, pool_hg, pool_gs_bytes)
   if (dtype == TD_BF16) { if (pool_blk == 64) TD_SQP(TD_BF16, 64); else TD_SQP(TD_BF16, 128); }
   else { if (pool_blk == 64) TD_SQP(TD_F16, 64); else TD_SQP(TD_F16, 128); }
 #undef TD_SQP
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+extern "C" int td_sage_quant_pool_packed(const void* x, const void* km, int dtype, int pool_blk, void* pooled,
+                                         int8_t* xq, float* xs, int64_t L, int64_t L_alloc, int hg, int64_t gs_bytes,
+                                         int H, int D, td_stream_t stream) {
+  return sage_quant_pool_impl(x, km, nullptr, 0, 0, 0, dtype, pool_blk, pooled, xq, xs, L, L_alloc, hg, gs_bytes, H, D, stream);
+}
+
+// td_sage_quant_pool_packed with (a) the smooth-K mean either given (km) or formed in the kernel from km_n (<= 8) per-rank column
+// sums km_parts f32 [km_n][>= H*128] (km_stride floats apart; the all-gathered td_seq_sum outputs) over km_rows global rows, and (b) a
+// head layout of its own (pool_hg, pool_gs_bytes) for `pooled` (the sequence-parallel pack keeps pooled K of ALL heads in its first piece)
+extern "C" int td_sage_quant_pool_packed_kmsum(const void* x, const void* km, const float* km_parts, int km_n, int64_t km_stride,
+                                               int64_t km_rows, int dtype, int pool_blk, void* pooled, int pool_hg,
+                                               int64_t pool_gs_bytes, int8_t* xq, float* xs, int64_t L, int64_t L_alloc, int hg,
+                                               int64_t gs_bytes, int H, int D, td_stream_t stream) {
+  TD_REQUIRE((km == nullptr) || (km_parts == nullptr), TD_ERR_INVALID, "td_sage_quant_pool_packed_kmsum: km AND partials");
+  return sage_quant_pool_impl(x, km, km_parts, km_n, km_stride, km_rows, dtype, pool_blk, pooled, xq, xs, L, L_alloc, hg,
+                              gs_bytes, H, D, stream, pool_hg, pool_gs_bytes);
 }
 
 extern "C" int td_sage_quant_pool(const void* x, const void* km, int dtype, int pool_blk, void* pooled,

@@ -489,6 +489,34 @@ def qk_norm_rope(src, col0, H, D, w, cos, sin, eps):
     return dst
 
 
+def qk_norm_rope_pair(src, col_q, col_k, H, D, wq, wk, cos, sin, eps):
+    """qk_norm_rope for the q columns [col_q, col_q + H*D) AND the k columns [col_k, ...) of one GEMM output in ONE launch
+    -> (q [H, L, D], k [H, L, D]); bit-identical to the two single calls."""
+    require_gpu(src, wq, wk, cos, sin)
+    assert src.dim() == 2 and src.stride(1) == 1
+    _f32c(wq, "norm weight"), _f32c(wk, "norm weight"), _f32c(cos, "cos"), _f32c(sin, "sin")
+    Lr = src.shape[0]
+    both = torch.empty((2, H, Lr, D), dtype=src.dtype, device=src.device)
+    call("td_qk_norm_rope_pair", ptr(src[:, col_q:col_q + H * D]), ptr(src[:, col_k:col_k + H * D]), src.stride(0), ptr(wq), ptr(wk),
+         ptr(cos), ptr(sin), ptr(both[0]), ptr(both[1]), dt_code(src.dtype), float(eps), Lr, H, D, stream_ptr())
+    return both[0], both[1]
+
+
+def seq_sum(k, tickets, out=None):
+    """k [H, L, D] -> f32 [H, D] column sums over this tensor's rows (td_seq_sum: 64 chunk partials per head + a pass that adds
+    them in order: two launches, no library reduction, no copy).  tickets: unused (None).  out: a contiguous f32 [H, D]
+    destination (e.g. a slice of a send buffer)."""
+    require_gpu(k, out)
+    assert k.is_contiguous()
+    H, L_, D = k.shape
+    ws = torch.empty((H, 64, D), dtype=torch.float32, device=k.device)
+    if out is None:
+        out = torch.empty((H, D), dtype=torch.float32, device=k.device)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (H, D) and out.is_contiguous()
+    call("td_seq_sum", ptr(k), ptr(ws), ptr(out), ptr(tickets), dt_code(k.dtype), L_, H, D, stream_ptr())
+    return out
+
+
 def v_transpose(v, stride_h, stride_l, L_, H, D, out_dtype):
     """v: tensor whose element (h,l,d) is at data_ptr + h*stride_h + l*stride_l + d -> vt tiles."""
     require_gpu(v)
@@ -747,9 +775,21 @@ def sla_topk_sp(pq, pk_g, topk, kb):
     return lut
 
 
-def attn_i8_sp(q_i8, q_s, k_g, ks_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
+def _sp_quant_out(quant_out, H):
+    """quant_out of the *_sp attention wrappers: None, or (oq int8 [L, Ht*128], os f32 [ceil(L/128), Ht], h0, Ht) — the launch's H
+    heads are heads [h0, h0 + H) of a row of Ht heads -> (q_out pointer, q_scale pointer, Ht)."""
+    if quant_out is None:
+        return None, None, 0
+    oq, os_, h0, Ht = quant_out
+    assert oq.dtype == torch.int8 and oq.is_contiguous() and oq.shape[1] == Ht * 128 and os_.dtype == torch.float32
+    assert os_.is_contiguous() and os_.shape[1] == Ht and 0 <= h0 and h0 + H <= Ht
+    return L.ctypes.c_void_p(oq.data_ptr() + h0 * 128), L.ctypes.c_void_p(os_.data_ptr() + 4 * h0), Ht
+
+
+def attn_i8_sp(q_i8, q_s, k_g, ks_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None, quant_out=None):
     """attn_i8 with the K side read from the all-gather's rank-major output: k_g int8 [W, H, per, 128],
-    ks_g f32 [W, H, per/64], vt_g f16 [W, H, per/64, 128, 64] (views; only the rank dim may be strided)."""
+    ks_g f32 [W, H, per/64], vt_g f16 [W, H, per/64, 128, 64] (views; only the rank dim may be strided).
+    quant_out: see _sp_quant_out (``out`` then only supplies the 16-bit dtype: a tensor or a torch.dtype)."""
     require_gpu(q_i8, k_g, ks_g, vt_g, lut, add_t)
     H, L_, D = q_i8.shape
     W, H2, per, _ = k_g.shape
@@ -761,13 +801,15 @@ def attn_i8_sp(q_i8, q_s, k_g, ks_g, vt_g, lut, out, o_stride_h, o_stride_l, lk,
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]
+    oq, os_, ht = _sp_quant_out(quant_out, H)
+    odt = out if isinstance(out, torch.dtype) else out.dtype
     _timed("td_attn_i8", (H, L_, lk, nsel), lambda: call(
-        "td_attn_i8_sp", ptr(q_i8), ptr(q_s), ptr(k_g), ptr(ks_g), ptr(vt_g), ptr(lut), nsel, ptr(out), dt_code(out.dtype),
-        o_stride_h, o_stride_l, float(sm_scale), L_, lk, H, kbp, k_rs, ks_rs, v_rs, ptr(add_t), None, None, stream_ptr()))
+        "td_attn_i8_sp", ptr(q_i8), ptr(q_s), ptr(k_g), ptr(ks_g), ptr(vt_g), ptr(lut), nsel, None if oq is not None else ptr(out),
+        dt_code(odt), o_stride_h, o_stride_l, float(sm_scale), L_, lk, H, kbp, k_rs, ks_rs, v_rs, ptr(add_t), oq, os_, ht, stream_ptr()))
     return out
 
 
-def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None):
+def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None, add_t=None, quant_out=None):
     """attn_16 with rank-major gathered K [W, H, per, 128] / V^T tiles [W, H, per/64, 128, 64] (same 16-bit dtype as q)."""
     require_gpu(q, k_g, vt_g, lut, add_t)
     H, L_, D = q.shape
@@ -779,41 +821,77 @@ def attn_16_sp(q, k_g, vt_g, lut, out, o_stride_h, o_stride_l, lk, sm_scale=None
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]
-    call("td_attn_16_sp", ptr(q), ptr(k_g), ptr(vt_g), ptr(lut), nsel, ptr(out), dt_code(q.dtype), o_stride_h, o_stride_l,
-         float(sm_scale), L_, lk, H, kbp, k_rs, v_rs, ptr(add_t), None, None, stream_ptr())
+    oq, os_, ht = _sp_quant_out(quant_out, H)
+    call("td_attn_16_sp", ptr(q), ptr(k_g), ptr(vt_g), ptr(lut), nsel, None if oq is not None else ptr(out), dt_code(q.dtype), o_stride_h,
+         o_stride_l, float(sm_scale), L_, lk, H, kbp, k_rs, v_rs, ptr(add_t), oq, os_, ht, stream_ptr())
     return out
 
 
-def sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay):
-    """This rank's K-side state written STRAIGHT into the send buffer of the sequence-parallel all-gathers (``lay``: a
-    ``seqpar.PackLayout``; buffer uint8 [groups, group_bytes], group g = heads [g*hg, (g+1)*hg), sections k | vt | ks | pk |
-    kv | kss): the Sage INT8 codes + scales + pooled block means of ``k`` (smooth-K mean ``km``), the V^T MFMA tiles of V
-    (element (h,l,d) at v_src + h*v_strides[0] + l*v_strides[1] + d) and the fp32 linear-branch partials — four launches
-    over all heads (the *_packed entry points), no staging copies."""
-    require_gpu(k, km, v_src)
+def sp_pack_begin(k, v_src, v_strides, L_loc, lay, lin_kv=None, lin_ks=None):
+    """First half of a rank's K-side pack (``lay``: a ``seqpar.PackLayout``; flat uint8 send buffer: the pooled K of all heads,
+    then per head group g = heads [g*hg, (g+1)*hg) the sections k | vt | ks) — everything that does NOT depend on the global
+    smooth-K mean: the V^T MFMA tiles of V (element (h,l,d) at v_src + h*v_strides[0] + l*v_strides[1] + d) straight into the vt
+    sections, and — linear branch — this rank's fp32 partials ck^T v -> lin_kv f32 [H, D, D], sum ck -> lin_ks f32 [H, D] (slices
+    of the EARLY send buffer: they travel with the K column sums, ahead of the pack, so that the branch's reduction and second
+    pass run beside the K quantiser and the exchange instead of behind them).  Returns the pack (k / ks / pk still unwritten)."""
+    require_gpu(k, v_src, lin_kv, lin_ks)
     H, L_, D = k.shape
     assert L_ == L_loc and k.is_contiguous() and H == lay.G * lay.hg and D == lay.D
-    pack = (torch.zeros if L_loc < lay.per else torch.empty)((lay.G, lay.gb), dtype=torch.uint8, device=k.device)
-    base = pack.data_ptr()
-
-    def at(name):
-        return L.ctypes.c_void_p(base + lay.offs[name])
-
-    call("td_v_transpose_packed", ptr(v_src), dt_code(v_src.dtype), v_strides[0], v_strides[1], at("vt"), dt_code(lay.pdt),
+    pack = (torch.zeros if L_loc < lay.per else torch.empty)((lay.total,), dtype=torch.uint8, device=k.device)
+    vt0 = L.ctypes.c_void_p(pack.data_ptr() + lay.ab + lay.offs["vt"])
+    call("td_v_transpose_packed", ptr(v_src), dt_code(v_src.dtype), v_strides[0], v_strides[1], vt0, dt_code(lay.pdt),
          L_loc, lay.per, lay.hg, lay.gb, H, D, stream_ptr())
-    if lay.sage or not lay.dense:
-        call("td_sage_quant_pool_packed", ptr(k), ptr(km), dt_code(k.dtype), 64, at("pk") if not lay.dense else None,
-             at("k") if lay.sage else None, at("ks") if lay.sage else None, L_loc, lay.per, lay.hg, lay.gb, H, D, stream_ptr())
-    if not lay.sage:   # 16-bit K travels as it is: one strided copy into the k section
-        lay.section(pack, "k")[:, :, :L_loc].copy_(k.view(lay.G, lay.hg, L_loc, D))
     if lay.linear:
+        assert lin_kv.dtype == torch.float32 and tuple(lin_kv.shape) == (H, D, D) and lin_kv.is_contiguous()
+        assert lin_ks.dtype == torch.float32 and tuple(lin_ks.shape) == (H, D) and lin_ks.is_contiguous()
         ws_kv = torch.empty((H, SLA_NCH, D, D), dtype=torch.float32, device=k.device)
         ws_ks = torch.empty((H, SLA_NCH, D), dtype=torch.float32, device=k.device)
-        call("td_sla_linear_kv_partial_packed", ptr(k), dt_code(k.dtype), at("vt"), dt_code(lay.pdt), ptr(ws_kv), ptr(ws_ks),
+        call("td_sla_linear_kv_partial_packed", ptr(k), dt_code(k.dtype), vt0, dt_code(lay.pdt), ptr(ws_kv), ptr(ws_ks),
              L_loc, lay.per, lay.hg, lay.gb, H, D, stream_ptr())
         call("td_sla_linear_kv_final_packed", ptr(ws_kv), ptr(ws_ks), SLA_NCH, SLA_NCH * D * D, D * D, SLA_NCH * D, D,
-             at("kv"), at("kss"), L.TD_F32, lay.hg, lay.gb, H, D, stream_ptr())
+             ptr(lin_kv), ptr(lin_ks), L.TD_F32, 0, 0, H, D, stream_ptr())
     return pack
+
+
+def sp_pack_finish(pack, k, km, L_loc, lay):
+    """Second half: what needs the smooth-K mean — ONE launch: the Sage INT8 codes + scales of ``k`` into the group sections
+    and the pooled block means (of ALL heads) into the flat all-head section (16-bit K: pooled K only + one strided copy of K).
+    km: the mean [H, D] in k's dtype, or (parts f32 [W, H, D], L_total): the gathered per-rank column sums of ``seq_sum`` — the
+    mean is then formed inside the kernel (no td_seq_mean_final launch)."""
+    require_gpu(pack, k)
+    H, L_, D = k.shape
+    base = pack.data_ptr()
+
+    def grp(name):     # group section of group 0 (the kernels step lay.gb per group)
+        return L.ctypes.c_void_p(base + lay.ab + lay.offs[name])
+
+    if lay.sage or not lay.dense:
+        kmp = allp = None
+        n_parts = stride = rows = 0
+        if isinstance(km, tuple):
+            allp, rows = km
+            require_gpu(allp)
+            assert allp.dtype == torch.float32 and allp.dim() == 3 and tuple(allp.shape[1:]) == (H, D) and allp[0].is_contiguous()
+            assert allp.shape[0] <= 8, "the in-kernel smooth-K mean sums at most 8 per-rank partials"
+            n_parts, stride = allp.shape[0], allp.stride(0)
+        else:
+            require_gpu(km)
+            kmp = km
+        call("td_sage_quant_pool_packed_kmsum", ptr(k), ptr(kmp), ptr(allp), n_parts, stride, int(rows), dt_code(k.dtype), 64,
+             L.ctypes.c_void_p(base + lay.aoffs["pk"]) if not lay.dense else None, 0, 0, grp("k") if lay.sage else None,
+             grp("ks") if lay.sage else None, L_loc, lay.per, lay.hg, lay.gb, H, D, stream_ptr())
+    if not lay.sage:   # 16-bit K travels as it is: one strided copy into the k section
+        lay.group_section(pack, "k")[:, :, :L_loc].copy_(k.view(lay.G, lay.hg, L_loc, D))
+    return pack
+
+
+def sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay, lin_kv=None, lin_ks=None):
+    """sp_pack_begin + sp_pack_finish (tests; the layer itself issues the early exchange between the two)."""
+    H, _, D = k.shape
+    if lay.linear and lin_kv is None:
+        lin_kv = torch.empty((H, D, D), dtype=torch.float32, device=k.device)
+        lin_ks = torch.empty((H, D), dtype=torch.float32, device=k.device)
+    return sp_pack_finish(sp_pack_begin(k, v_src, v_strides, L_loc, lay, lin_kv, lin_ks), k, km, L_loc, lay)
 
 
 # ----------------------------------------------------------------------------- f4: VAE decoder convolutions (vae_conv.hip)

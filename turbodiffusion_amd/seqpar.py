@@ -9,8 +9,8 @@ self-attention, which needs the K side of every rank.  Per self-attention layer:
   2. an all-gather (issued as ``head_groups`` consecutive asynchronous pieces, one per group of heads, so that
      attention on the first heads runs while the later heads' bytes are still on the links) of a packed per-rank
      buffer holding the rank's *quantised* K-side state:
-         K int8 [H, per, 128] | V^T fp16 MFMA tiles [H, per/64, 128, 64] | K scales | pooled K blocks |
-         fp32 linear-branch partials (ck^T v [H,128,128], sum ck [H,128])
+         pooled K blocks and fp32 linear-branch partials (ck^T v [H,128,128], sum ck [H,128]) of ALL heads (first piece) |
+         per head group: K int8 [hg, per, 128] | V^T fp16 MFMA tiles [hg, per/64, 128, 64] | K scales
      (3 B per token-channel instead of the reference Ulysses path's 4 all-to-alls of bf16 q,k,v,o:
      rcm/utils/a2a_cp.py:146-182 — and no head-count divisibility constraint: 12 heads shard 8 ways);
   3. every rank builds the LUT for ITS Q blocks against the global pooled K, runs the block-sparse
@@ -102,11 +102,21 @@ class _Gather:
 
 
 class PackLayout:
-    """Byte layout of the K-side send buffer of one self-attention layer: uint8 [G, gb]; group g = heads [g*hg, (g+1)*hg),
-    inside a group the sections  k (int8 codes, or the 16-bit K when not Sage) | vt (V^T MFMA tiles) | ks (K scales) |
-    pk (pooled K blocks) | kv, kss (fp32 linear-branch partials), each [hg, ...] at the rank-padded extents (``per`` rows,
-    ``per/64`` blocks) and 256-byte aligned.  G = the largest divisor of H not above ``head_groups`` (equal groups: the
-    producer kernels address head h as group h // hg, member h % hg — td_common.h ``td_head_off``)."""
+    """Byte layout of the K-side send buffer of one self-attention layer: ONE flat uint8 buffer of ``total`` bytes,
+
+        [ all-head block (ab bytes): pk | kv | kss for ALL H heads ]  [ group 0 (gb bytes): k | vt | ks ]  [ group 1 ] ...
+
+    sent as G pieces (one asynchronous all-gather each): piece 0 = the all-head block + group 0, piece g > 0 = group g.
+    Group g = heads [g*hg, (g+1)*hg); inside a group block the sections  k (int8 codes, or the 16-bit K when not Sage) | vt (V^T
+    MFMA tiles) | ks (K scales), each [hg, ...] at the rank-padded extents (``per`` rows, ``per/64`` blocks) and 256-byte
+    aligned.  The all-head block holds the pooled K blocks of ALL heads: the block map is ONE launch over all heads right behind
+    the first piece instead of one per head group.  The fp32 linear-branch partials (ck^T v [H,128,128], sum ck [H,128]) do not
+    depend on the smooth-K mean and are small: round 5 sends them AHEAD of the pack (``early_lin``: a second tiny exchange next
+    to the K column sums), so that the branch's reduction over the ranks and its second pass (-> o_l) run on a side stream
+    beside the K quantiser and the pack's exchange; the attention kernel then takes o_l in its epilogue and quantises for the o
+    projection, as on one GPU (no read-modify-write pass, no separate quantiser behind attention).
+    G = the largest divisor of H not above ``head_groups`` (equal groups: the producer kernels address head h as group
+    h // hg, member h % hg — td_common.h ``td_head_off``; the all-head sections use its flat form)."""
 
     def __init__(self, H, per, D, head_groups, sage, dense, dt):
         self.H, self.per, self.D, self.sage, self.dense, self.linear, self.dt = H, per, D, sage, dense, not dense, dt
@@ -114,29 +124,63 @@ class PackLayout:
         self.hg = hg = H // self.G
         self.kbp = kbp = per // 64
         self.pdt = torch.float16 if sage else dt
-        self.spec = {   # name -> (dtype, per-group shape)
+        self.spec = {   # group sections: name -> (dtype, per-group shape)
             "k": (torch.int8 if sage else dt, (hg, per, D)),
             "vt": (self.pdt, (hg, kbp, D, 64)),
             "ks": (torch.float32, (hg, kbp)) if sage else None,
-            "pk": (dt, (hg, kbp, D)) if not dense else None,
-            "kv": (torch.float32, (hg, D, D)) if self.linear else None,
-            "kss": (torch.float32, (hg, D)) if self.linear else None,
         }
-        self.offs, self.sizes, o = {}, {}, 0
-        for name, sp in self.spec.items():
-            n = 0
-            if sp is not None:
-                n = torch.empty((), dtype=sp[0]).element_size()
-                for d in sp[1]:
-                    n *= d
-            self.offs[name], self.sizes[name] = o, n
-            o += _cdiv(n, 256) * 256
-        self.gb = o
+        self.aspec = {  # all-head sections: name -> (dtype, shape over ALL heads)
+            "pk": (dt, (H, kbp, D)) if not dense else None,
+        }
+        # the EARLY send buffer (f32, one tiny exchange ahead of the pack): the rank's K column sums [H, D] (-> the global
+        # smooth-K mean), then — linear branch — its partials sum ck [H, D] | ck^T v [H, D, D]
+        self.early_sum = H * D
+        self.early_lin = (H * D + H * D * D) if self.linear else 0
 
-    def section(self, buf, name):
-        """buf uint8 [N, gb] (the pack: N = G; one group's all-gather output: N = world) -> [N, *per-group shape] VIEW."""
+        def lay(spec):
+            offs, sizes, o = {}, {}, 0
+            for name, sp in spec.items():
+                n = 0
+                if sp is not None:
+                    n = torch.empty((), dtype=sp[0]).element_size()
+                    for d in sp[1]:
+                        n *= d
+                offs[name], sizes[name] = o, n
+                o += _cdiv(n, 256) * 256
+            return offs, sizes, o
+        self.offs, self.sizes, self.gb = lay(self.spec)
+        self.aoffs, self.asizes, self.ab = lay(self.aspec)
+        self.total = self.ab + self.G * self.gb
+        self.pieces = [(0, self.ab + self.gb)] + [(self.ab + g * self.gb, self.gb) for g in range(1, self.G)]   # (offset, bytes)
+
+    def piece(self, pack, g):
+        """pack uint8 [total] -> the bytes of piece g (a view)."""
+        o, n = self.pieces[g]
+        return pack[o:o + n]
+
+    def group_section(self, pack, name):
+        """pack uint8 [total] (the LOCAL send buffer) -> [G, *per-group shape] VIEW of a group section."""
         dtype, shape = self.spec[name]
         off, n = self.offs[name], self.sizes[name]
+        return pack[self.ab:].view(self.G, self.gb)[:, off:off + n].view(dtype).view((self.G,) + shape)
+
+    def all_section(self, pack, name):
+        """pack uint8 [total] (the LOCAL send buffer) -> [*all-head shape] VIEW of an all-head section."""
+        dtype, shape = self.aspec[name]
+        off, n = self.aoffs[name], self.asizes[name]
+        return pack[off:off + n].view(dtype).view(shape)
+
+    def gathered(self, outs, g, name):
+        """outs: the all-gather outputs of the pieces (uint8 [W, piece bytes] each) -> rank-major VIEW [W, *shape] of group g's
+        section ``name`` (g = None: an all-head section, which travels in piece 0)."""
+        if g is None:
+            dtype, shape = self.aspec[name]
+            off, n = self.aoffs[name], self.asizes[name]
+            buf = outs[0]
+        else:
+            dtype, shape = self.spec[name]
+            off, n = self.offs[name] + (self.ab if g == 0 else 0), self.sizes[name]
+            buf = outs[g]
         return buf[:, off:off + n].view(dtype).view((buf.shape[0],) + shape)
 
 
@@ -288,13 +332,14 @@ class SeqParallel:
 
     # ------------------------------------------------------------------ self attention
     def self_attention(self, q, k, v_src, v_strides, out, o_stride_h, o_stride_l, attention_type, topk_ratio,
-                       proj_w=None, proj_b=None):
+                       proj_w=None, proj_b=None, quant_out=False):
         """q, k: [H, L_loc, D] (after RoPE); V element (h,l,d) at v_src + h*v_strides[0] + l*v_strides[1] + d;
-        out: element (h,l,d) at out + h*o_stride_h + l*o_stride_l + d (this rank's rows)."""
+        out: element (h,l,d) at out + h*o_stride_h + l*o_stride_l + d (this rank's rows).
+        quant_out: return the [L_loc, H*D] result block-quantised for the o projection instead — (int8 [L_loc, H*D], f32
+        [ceil(L_loc/128), H]); ``out`` then only supplies the 16-bit dtype (a tensor or a torch.dtype)."""
         ops, W = self.ops, self.world
         H, L_loc, D = q.shape
         L, per = self.L, self.per
-        kbp = per // 64
         kb_tot = _cdiv(L, 64)
         sage = attention_type in ("sage", "sagesla")
         dense = attention_type in ("original", "sage")
@@ -305,12 +350,42 @@ class SeqParallel:
             # same condition on every rank, raised BEFORE any collective (sla.py mirrors SLA/utils.py:61-62 the same way)
             raise ValueError(f"block-sparse attention with topk ratio {topk_ratio} selects no block of {kb_tot} (L = {L} tokens)")
 
-        # ---- (1) global smooth-K mean: a tiny all-gather (latency-bound); the Q side of this rank — independent of it —
-        # is prepared while it is in flight ----
-        km = allp = km_work = None
+        from . import graph as _graph
+        on_streams = q.is_cuda and _graph._ACTIVE is None     # side streams need real streams and no segmented capture in progress
+        lay = PackLayout(H, per, D, self.groups_for(H, per), sage, dense, dt)
+        # ---- (1) the EARLY exchange: this rank's per-head K column sums (-> the global smooth-K mean: chunk
+        # partials + one in-order pass) and, for the linear branch, its fp32 partials — neither needs anything global, both are
+        # small, latency-bound all-gathers.  The column sums go first (the K quantiser waits for them); the Q side of this
+        # rank is prepared while they are in flight.  The mean itself is formed inside the K quantiser from the gathered sums.
+        early = torch.empty((lay.early_sum + lay.early_lin,), dtype=torch.float32, device=dev)
+        allp = km_work = alll = lin_work = None
         if sage or not dense:
-            part = ops.seq_sum_partial(k).sum(dim=1)           # [H, D] f32, this rank's column sums
-            allp, km_work = self.all_gather(part, async_op=True)   # [W, H, D]
+            part = ops.seq_sum(k, None, out=early[:lay.early_sum].view(H, D))
+            allp, km_work = self.all_gather(part, async_op=True)                # [W, H, D]
+        lin_ks = early[lay.early_sum:lay.early_sum + H * D].view(H, D) if linear else None
+        lin_kv = early[lay.early_sum + H * D:].view(H, D, D) if linear else None
+        pack = ops.sp_pack_begin(k, v_src, v_strides, L_loc, lay, lin_kv, lin_ks)      # V^T tiles; linear partials -> early
+        # ---- the linear branch's reduction over the ranks and its second pass (-> o_l [all heads], which the attention
+        # epilogue adds): on a
+        # side stream beside the Q / K quantisers and the pack's exchange below (a graph branch under capture), joined before attention
+        o_l = e_ol = None
+        if linear:
+            alll, lin_work = self.all_gather(early[lay.early_sum:], async_op=True)      # [W, H*D + H*D*D]
+            main = torch.cuda.current_stream() if on_streams else None
+            st_l = self._stream(100) if on_streams else None
+            if st_l is not None:
+                e_f = torch.cuda.Event()
+                e_f.record(main)
+                st_l.wait_event(e_f)
+            with (torch.cuda.stream(st_l) if st_l is not None else _NullCtx()):
+                lin_work.wait()
+                ks_parts = alll[:, :H * D].view(W, H, D)                       # [W, H, D] rank-major views of the early gather
+                kv_parts = alll[:, H * D:].view(W, H, D, D)
+                kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D, ks_parts.stride(0), H, D, dt)
+                o_l = ops.sla_linear_out_t(q, kv_t, ksum, proj_w, proj_b)
+                if st_l is not None:
+                    e_ol = torch.cuda.Event()
+                    e_ol.record(st_l)
         pq = q_q = q_s = None
         if sage:
             pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
@@ -318,49 +393,55 @@ class SeqParallel:
             pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
         if allp is not None:
             km_work.wait()
-            km = ops.seq_mean_final(allp, W, D, H * D, L, H, D, dt)
 
-        # ---- (2) local K-side state, written by the producer kernels straight into the send buffer: ONE buffer
-        # [groups][k | vt | ks | pk | kv | kss][heads of the group][...] (PackLayout), one all-gather per head group ----
-        lay = PackLayout(H, per, D, self.groups_for(H, per), sage, dense, dt)
-        pack = ops.sp_pack_k_side(k, km, v_src, v_strides, L_loc, lay)          # uint8 [G, group_bytes]
+        # ---- (2) the part of the K-side state that needs the mean, written straight into the send buffer: ONE launch ----
+        ops.sp_pack_finish(pack, k, None if allp is None else (allp, L), L_loc, lay)
 
-        # ---- (2) + (3), pipelined over head groups: the groups' all-gathers are issued back to back (asynchronously,
-        # RCCL's own stream executes them in order); then, group by group, the gather is awaited and that group's block
-        # map / attention / linear branch run while the later groups' bytes are still on the links.  The bytes on the wire
-        # are the same as with one gather; what changes is that attention — about a third of a layer's compute — overlaps
-        # most of the exchange instead of waiting for all of it.
-        handles = [_Gather(self.group, torch.empty((W, lay.gb), dtype=torch.uint8, device=dev), pack[g], True)
+        # ---- (2) + (3), pipelined over head groups: the pieces' all-gathers are issued back to back (asynchronously,
+        # RCCL's own stream executes them in order); behind the first one the block map (ONE launch over all heads); then,
+        # group by group, the gather is awaited and that group's attention runs while the later groups' bytes are still on
+        # the links.  The bytes on the wire are the same as with one gather; what changes is that attention — about a third
+        # of a layer's compute — overlaps most of the exchange instead of waiting for all of it.
+        handles = [_Gather(self.group, torch.empty((W, lay.pieces[g][1]), dtype=torch.uint8, device=dev), lay.piece(pack, g), True)
                    for g in range(lay.G)]
 
-        def issue_all():   # ONE eager point (graph.py): all groups' gathers, and the wait for the first
+        def issue_all():   # ONE eager point (graph.py): all pieces' gathers
             for h in handles:
                 h.issue()
-            handles[0]._wait()
         eager_point(issue_all)
-        inflight = [(g * lay.hg, (g + 1) * lay.hg, handles[g].out, handles[g]) for g in range(lay.G)]
-        # The attention / block-map kernels read the K side STRAIGHT from the all-gather's rank-major output (the *_sp
-        # entry points: block j = block j % kbp of rank j // kbp): no re-layout of the gathered K / V^T / scales / pooled K.
+        outs = [h.out for h in handles]
 
+        handles[0].wait()
+        # The attention / block-map kernels read the K side STRAIGHT from the all-gathers' rank-major outputs (the *_sp
+        # entry points: block j = block j % kbp of rank j // kbp): no re-layout of the gathered K / V^T / scales / pooled K.
         topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
-        from . import graph as _graph
-        # parallel branches need real streams and no segmented capture in progress (a segment cannot end with forked streams)
-        par = q.is_cuda and _graph._ACTIVE is None and self.branches_in_parallel(H, per, lay.G)
+        lut = None
+        if not dense:
+            lut = ops.sla_topk_sp(pq, lay.gathered(outs, None, "pk"), topk, kb_tot)                       # all heads
+        if e_ol is not None:
+            torch.cuda.current_stream().wait_event(e_ol)
+        qo = None
+        if quant_out:
+            odt = out if isinstance(out, torch.dtype) else out.dtype
+            qo = (torch.empty((L_loc, H * D), dtype=torch.int8, device=dev),
+                  torch.empty((_cdiv(L_loc, 128), H), dtype=torch.float32, device=dev))
+            out = odt
+        par = on_streams and self.branches_in_parallel(H, per, lay.G)   # (a segment cannot end with forked streams)
         main = torch.cuda.current_stream() if par else None
         joins = []
         if par:
             e_fork = torch.cuda.Event()
             e_fork.record(main)
-        for gi, (h0, h1, allb, work) in enumerate(inflight):
+        for g in range(lay.G):
+            h0, h1 = g * lay.hg, (g + 1) * lay.hg
             st = None
-            if par and gi > 0:
-                st = self._stream(gi)
+            if par and g > 0:
+                st = self._stream(g)
                 st.wait_event(e_fork)
             with (torch.cuda.stream(st) if st is not None else _NullCtx()):
-                if h0 > 0:
-                    work.wait()      # (RCCL: the CURRENT stream waits for that group's gather)
-                self._group(ops, lay, q, q_q, q_s, pq, h0, h1, allb, out, o_stride_h, o_stride_l, L, topk, kb_tot, sage, dense,
-                            linear, W, D, dt, proj_w, proj_b)
+                if g > 0:
+                    handles[g].wait()      # (RCCL: the CURRENT stream waits for that group's gather)
+                self._group(ops, lay, outs, g, q, q_q, q_s, lut, o_l, h0, h1, out, qo, o_stride_h, o_stride_l, L, sage, H)
                 if st is not None:
                     e = torch.cuda.Event()
                     e.record(st)
@@ -368,9 +449,9 @@ class SeqParallel:
         for e in joins:
             main.wait_event(e)
         # allocation safety without record_stream: tensors made inside a branch live on that branch's stream and are reused
-        # there only; what the branches READ (q side, the gathered buffers) belongs to the main stream and is released by
-        # Python after the join above has been enqueued
-        return out
+        # there only; what the branches READ (q side, LUT, o_l, the gathered buffers) and WRITE (out / the quantised output)
+        # belongs to the main stream and is released by Python after the join above has been enqueued
+        return qo if quant_out else out
 
     def _stream(self, gi):
         key = (torch.cuda.current_device(), gi)
@@ -379,30 +460,20 @@ class SeqParallel:
             st = self._group_streams[key] = torch.cuda.Stream()
         return st
 
-    def _group(self, ops, lay, q, q_q, q_s, pq, h0, h1, allb, out, o_stride_h, o_stride_l, L, topk, kb_tot, sage, dense, linear,
-               W, D, dt, proj_w, proj_b):
-        """Block map, attention and linear branch of the heads [h0, h1) against one head group's gathered K side."""
-        Hg = h1 - h0
-
-        def gathered(name):  # [W, hg, ...] strided VIEW of one section of the group's gather (no copy)
-            return lay.section(allb, name)
-
-        vt_g = gathered("vt")                                                   # [W, Hg, kbp, D, 64] view
-        out_g = out.view(-1)[h0 * o_stride_h:]   # same buffer, origin moved to the group's first head
-        lut = None
-        if not dense:
-            lut = ops.sla_topk_sp(pq[h0:h1], gathered("pk"), topk, kb_tot)
+    def _group(self, ops, lay, outs, g, q, q_q, q_s, lut, o_l, h0, h1, out, qo, o_stride_h, o_stride_l, L, sage, H):
+        """Attention of the heads [h0, h1) against head group g's gathered K side (block map rows, o_l: slices of the all-head
+        results made behind the first piece)."""
+        vt_g = lay.gathered(outs, g, "vt")                                      # [W, hg, kbp, D, 64] view
+        lut_g = None if lut is None else lut[h0:h1]
+        add_g = None if o_l is None else o_l[h0:h1]
+        quant = None if qo is None else (qo[0], qo[1], h0, H)
+        out_g = out if qo is not None else out.view(-1)[h0 * o_stride_h:]   # same buffer, origin moved to the group's first head
         if sage:
-            ops.attn_i8_sp(q_q[h0:h1], q_s[h0:h1], gathered("k"), gathered("ks"), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
+            ops.attn_i8_sp(q_q[h0:h1], q_s[h0:h1], lay.gathered(outs, g, "k"), lay.gathered(outs, g, "ks"), vt_g, lut_g, out_g,
+                           o_stride_h, o_stride_l, L, add_t=add_g, quant_out=quant)
         else:
-            ops.attn_16_sp(q[h0:h1], gathered("k"), vt_g, lut, out_g, o_stride_h, o_stride_l, L)
-        if linear:
-            kv_parts = gathered("kv")   # [W, Hg, D, D]
-            ks_parts = gathered("kss")     # [W, Hg, D]
-            kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D,
-                                                 ks_parts.stride(0), Hg, D, dt)
-            ops.sla_linear_out_(q[h0:h1], kv_t, ksum, proj_w, proj_b, out_g, o_stride_h, o_stride_l)
-        return out
+            ops.attn_16_sp(q[h0:h1], lay.gathered(outs, g, "k"), vt_g, lut_g, out_g, o_stride_h, o_stride_l, L, add_t=add_g,
+                           quant_out=quant)
 
 
 class _ModelAdapter:
@@ -428,10 +499,10 @@ class _ModelAdapter:
         """This rank's token range [start, stop) of L tokens (the fused patch-embedding kernel reads only those)."""
         return self.sp.plan(L)
 
-    def self_attention(self, model, fused, q, k, qkv, out):
+    def self_attention(self, model, fused, q, k, qkv, out, quant_out=False):
         dim, D = model.dim, 128
         return self.sp.self_attention(q, k, qkv[:, 2 * dim:], (D, 3 * dim), out, D, dim, model.attention_type,
-                                      model.sla_topk, fused.get("proj_w"), fused.get("proj_b"))
+                                      model.sla_topk, fused.get("proj_w"), fused.get("proj_b"), quant_out=quant_out)
 
 
 def enable(model, group=None, ops=None, broadcast_inputs=False):

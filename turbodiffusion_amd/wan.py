@@ -455,16 +455,17 @@ class WanModel(nn.Module):
 
         def q_fn():
             return K.qk_norm_rope(qkv, 0, H, D, sa.norm_q.weight, cos, sin, self.eps)
-        q = None if two else q_fn()
-        k = K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
         if self.seq_parallel is not None:
             if sage and self.sage_pv != "fp16":
                 raise NotImplementedError("sage_pv='fp8' is not built for the sequence-parallel path (the packed K-side exchange "
                                           "carries fp16 V^T tiles); use sage_pv='fp16' with seqpar.enable")
-            quant_out = False
+            # q and k in ONE launch (a rank's shard is small: every launch in front of the K-side exchange counts)
+            q, k = K.qk_norm_rope_pair(qkv, 0, dim, H, D, sa.norm_q.weight, sa.norm_k.weight, cos, sin, self.eps)
+            out = dtype if quant_out else torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
+            return self.seq_parallel.self_attention(self, f, q, k, qkv, out, quant_out=quant_out)
+        q = None if two else q_fn()
+        k = K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
         out = dtype if quant_out else torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
-        if self.seq_parallel is not None:
-            return self.seq_parallel.self_attention(self, f, q, k, qkv, out)
         dense = at in ("original", "sage")
         # W8A8: the attention kernel's epilogue hands the o projection its INT8 activation directly
         res, _, _ = sparse_linear_attention_hld(q, k, qkv[:, 2 * dim:], f.get("proj_w") if not dense else None,
@@ -684,7 +685,7 @@ class WanModel(nn.Module):
         else:
             h = K.layernorm(x2, None, None, self.eps, scale=ec[1], shift=ec[0], rows_per_batch=L_loc, pad_cols=pad)
             hs_ = [h[r] for r in rows]
-        qo = self.quant_linear and B == 1 and self.seq_parallel is None  # attention epilogue quantises for the o proj
+        qo = self.quant_linear and B == 1   # attention epilogue quantises for the o proj (one GPU and sequence-parallel alike)
         ys = [self._self_attention(i, blk, hb, cos, sin, L_loc, dt, quant_out=qo) for hb in hs_]
         y = ys[0] if B == 1 else torch.cat(ys, 0)
         ms = self._split_rows(L_loc) if (fstats and qo and isinstance(blk.norm3, FastLayerNorm) and isinstance(y, tuple)
