@@ -441,6 +441,54 @@ def test_gemm_vt_epilogue_is_gemm_plus_v_transpose(K, m, dim, k, dt, vt_dt):
     assert torch.equal(vt.view(torch.int16), vt_ref.view(torch.int16))
 
 
+# ---------------------------------------------------------------- round 5: the 128-row form of the LDS-DMA kernel (NI = 4)
+@pytest.mark.parametrize("m,n,k", [(4096, 1536, 1536), (4000, 1544, 384), (2100, 512, 256), (4096, 1536, 8960), (1100, 4608, 1536),
+                                   (4096, 8960, 1536)])
+def test_gemm_128_row_tile_form_is_bit_identical(K, m, n, k):
+    """TD_TUNE_GEMM_VARIANT = 6 forces the 128 x 256 tile (csrc/gemm_w8a8_fi.hip, NI = 4: the eight waves on 64 x 64 each) — the
+    form the per-rank GEMMs of a sequence shard take automatically: every epilogue (plain + GELU, gated / plain residual,
+    row-statistics partials with and without residual, fused quantiser with the GELU as a table and inline, V^T tiles) gives
+    the bits of the 256 x 256 tile (variant 4), ragged M / N tails included — partials too: a wave's 64-column piece is summed
+    in the same order in both forms."""
+    g = torch.Generator().manual_seed(m + n + k)
+    a = act_like(m, k, torch.bfloat16, seed=m + k)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(torch.bfloat16)
+    b = (torch.randn(n, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    gate = (torch.randn(1, n, generator=g) * 0.5).to(DEV)
+    x0 = (torch.randn(m, n, generator=g) * 2 + 0.3).to(torch.bfloat16).to(DEV)
+    aq, as_ = K.quant_i8_block128(a.to(DEV))
+    wq, ws = K.quant_i8_block128(w.to(DEV))
+    outs = {}
+    for variant in (4, 6):
+        K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
+        try:
+            r = {"plain": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b), "gelu": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True),
+                 "nobias": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16),
+                 "res": K.gemm_w8a8_residual_(x0.clone(), aq, as_, wq, ws, bias=b, gate=gate),
+                 "res_nogate": K.gemm_w8a8_residual_(x0.clone(), aq, as_, wq, ws, bias=b, gate=None)}
+            if n % 64 == 0:
+                r["stats_x"], r["part_x"] = K.gemm_w8a8_stats(aq, as_, wq, ws, b, x=x0.clone(), gate=gate)
+                r["stats_y"], r["part_y"] = K.gemm_w8a8_stats(aq, as_, wq, ws, b)
+            if n % 16 == 0:
+                r["q"], r["qs"] = K.gemm_w8a8_quant(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True)
+                r["q0"], r["qs0"] = K.gemm_w8a8_quant(aq, as_, wq, ws, torch.bfloat16, bias=b)
+                K.set_tuning(K.TUNE_GELU_TABLE, 1)
+                r["qi"], r["qsi"] = K.gemm_w8a8_quant(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True)
+                K.set_tuning(K.TUNE_GELU_TABLE, 0)
+            if n % 768 == 0:      # q | k | v of n / 3 columns each, heads of 128: V leaves as the attention kernel's tiles
+                r["vt_d"], r["vt"] = K.gemm_w8a8_vt(aq, as_, wq, ws, b, 2 * n // 3, torch.float16)
+                r["vt_d"] = r["vt_d"][:, :2 * n // 3].clone()
+        finally:
+            K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
+            K.set_tuning(K.TUNE_GELU_TABLE, 0)
+        outs[variant] = r
+    for key in outs[4]:
+        assert torch.equal(outs[4][key].view(torch.uint8) if outs[4][key].dtype == torch.float16 else outs[4][key],
+                           outs[6][key].view(torch.uint8) if outs[6][key].dtype == torch.float16 else outs[6][key]), key
+    if "q" in outs[6]:
+        assert torch.equal(outs[6]["q"], outs[6]["qi"]) and torch.equal(outs[6]["qs"], outs[6]["qsi"])
+
+
 # ---------------------------------------------------------------- small problems: the fused epilogues on the 128x128 kernel
 @pytest.mark.parametrize("m,n,k", [(4096, 1536, 1536), (4000, 1536, 384), (2100, 512, 256), (4096, 1536, 8960)])
 def test_small_problem_gemm_epilogues_match_the_256_tile_kernel(K, m, n, k):
@@ -457,7 +505,7 @@ def test_small_problem_gemm_epilogues_match_the_256_tile_kernel(K, m, n, k):
     aq, as_ = K.quant_i8_block128(a.to(DEV))
     wq, ws = K.quant_i8_block128(w.to(DEV))
     outs = {}
-    for variant in (4, 0):          # 4: the 256x256 kernel; 0: automatic (-> 128x128 for these shapes)
+    for variant in (4, 1):          # 4: the 256x256 kernel; 1: the 128x128 kernel (the automatic choice for these shapes until round 5)
         K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
         try:
             r = {"plain": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True),
@@ -472,7 +520,7 @@ def test_small_problem_gemm_epilogues_match_the_256_tile_kernel(K, m, n, k):
         finally:
             K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
         outs[variant] = r
-    big, small = outs[4], outs[0]
+    big, small = outs[4], outs[1]
     for key in ("plain", "res", "res_nogate", "stats_x", "stats_y") + (("q", "qs") if n % 128 == 0 else ()):
         assert torch.equal(big[key], small[key]), key
     torch.testing.assert_close(small["stats"], big["stats"], rtol=2e-5, atol=1e-6)

@@ -6,7 +6,7 @@
   two     two blocks at L = 32 760 (the real C1 length, top-k 0.1): tokens after the second block vs the oracle — the hand-off
           (row statistics carried from the FFN GEMM's epilogue into the next norm1, token-half split, V^T epilogue) at full size
 Block-map near-ties and INT8 rounding differences compound with depth (round 3: 0.7 % after 4 blocks, 1.1 % after 12); the
-figures are printed, the bound is 4e-2 with cosine >= 0.999."""
+figures are printed, the bound is 2.5e-2 (round 5; 4e-2 before) with cosine >= 0.999."""
 import os
 
 import pytest
@@ -43,8 +43,9 @@ def _check(which, net, x, t, ctx, g, capsys):
         print(f"\n[{which}: {net.num_layers} layers at dim {net.dim}, L = 4096] rel-L2 vs the oracle: tokens after the last block "
               f"{r_tok:.4f} (cosine {cosine(tok, g['tok_rows']):.5f}), velocity {r_v:.4f}")
     assert torch.isfinite(v).all()
-    assert r_tok < 4e-2 and cosine(tok, g["tok_rows"]) > 0.999, r_tok
-    assert r_v < 4e-2 and cosine(v, g["v"].float()) > 0.999, r_v
+    # measured 1.2e-2 ... 1.6e-2 (profiles/r04_pytest_gpu.txt, r05_pytest_gpu.txt); SURVEY §8d's one-block bar is 2e-2
+    assert r_tok < 2.5e-2 and cosine(tok, g["tok_rows"]) > 0.999, r_tok
+    assert r_v < 2.5e-2 and cosine(v, g["v"].float()) > 0.999, r_v
 
 
 def test_thirty_layers_at_1p3b_width_against_the_oracle(capsys):

@@ -147,3 +147,109 @@ def test_sla_core_refuses_what_it_does_not_handle(K):
     kv_t, ksum = K.sla_linear_kv(k, vt, feature_map="elu")
     K.sla_linear_out_(q, kv_t, ksum, wp, bp, b16, 128, H * 128, feature_map="elu")
     assert torch.equal(a, b16)
+
+
+# ---------------------------------------------------------------- parity at the REAL size, full depth (VERDICT r04 "next" 2)
+def _gold(name):
+    path = os.path.join(GOLD, f"r05_{name}.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (oracle/make_golden_r05.py {name}: hours of CPU)")
+    return torch.load(path, weights_only=False)
+
+
+def _c1_net():
+    from oracle import make_golden_r05 as R5
+    from oracle import wan_ref as W
+    from turbodiffusion_amd.wan import WanModel
+    with torch.device(DEV):
+        net = WanModel(attention_type="sagesla", sla_topk=R5.C1["topk"], quant_linear=True, **R5.C1["cfg"])
+    sd = W.make_state_dict(R5.C1["cfg"], seed=R5.C1["sd_seed"])
+    net.load_from_float_state_dict({k_: v_.to(DEV) for k_, v_ in sd.items()})
+    return net.eval()
+
+
+def test_headline_configuration_full_depth_at_the_real_length_against_the_oracle(capsys):
+    """C1 as the bench runs it — Wan2.1-1.3B, 30 layers, L = 32 760 tokens, W8A8 + Fast norms + SageSLA top-k 0.1, the production
+    schedule (hipGraph-able path: fused epilogues, two streams, token-half split) — ONE forward at step 2's t against the CPU
+    oracle's forward of the same weights / inputs (tests/golden/r05_c1full.pt, 55 min of oracle time): tokens after the last
+    block (every 32nd row + the 120-row tail block), the velocity, and the drift over depth (after blocks 1, 2, 4, 8, 16, 24).
+    Bound: SURVEY §8d's 2e-2 / cosine 0.999 on the velocity would be the one-block figure; through 30 blocks of block-map
+    near-ties and INT8 rounding the measured figures are printed and bounded at 2.5e-2."""
+    from oracle import make_golden_r05 as R5
+    g = _gold("c1full")
+    net = _c1_net()
+    assert net.split_tokens and net.fuse_row_stats and net.fuse_vt and net.two_streams
+    x, ctx = R5.c1_inputs()
+    xd, td, cd = x.to(DEV).bfloat16(), R5.c1_t(1).to(DEV), ctx.to(DEV)
+    net._tap_tokens = []
+    v = net(xd, td, cd)
+    taps, net._tap_tokens = net._tap_tokens, None
+    assert len(taps) == 30 and taps[-1].shape == (1, 32760, 1536)
+    rows = g["rows"].to(DEV)
+    tok = taps[-1][0][rows]
+    r_tok, r_tail, r_v = rel_l2(tok, g["tok_rows"].float()), rel_l2(taps[-1][0][-120:], g["tok_rows"][-120:].float()), rel_l2(v, g["v"].float())
+    depth = {i: rel_l2(taps[i][0][::g["depth_every"]], d.float()) for i, d in sorted(g["depth"].items())}
+    with capsys.disabled():
+        print(f"\n[C1 at full size: 30 layers x 32 760 tokens] rel-L2 vs the oracle: tokens after the last block {r_tok:.4f} (tail block "
+              f"{r_tail:.4f}, cosine {cosine(tok, g['tok_rows'].float()):.5f}), velocity {r_v:.4f} (cosine {cosine(v, g['v'].float()):.5f}); "
+              f"after blocks " + ", ".join(f"{i + 1}: {e:.4f}" for i, e in depth.items()))
+    assert torch.isfinite(v).all()
+    assert r_tok < 2.5e-2 and cosine(tok, g["tok_rows"].float()) > 0.999, r_tok
+    assert r_v < 2.5e-2 and cosine(v, g["v"].float()) > 0.999, r_v
+    assert r_tail < 3.5e-2 and max(depth.values()) < 2.5e-2, (r_tail, depth)
+
+
+def test_four_sampler_steps_at_the_real_size_against_the_oracle(capsys):
+    """"full 4-step latent vs the eager CPU reference at identical noise: rel-L2 per step" — at the headline size: the
+    same 30-layer model through the rCM loop (sampler.rcm_sample, hipGraph replay) against the oracle's loop at identical
+    noise: the velocity at every step's input and the latent after every step (tests/golden/r05_c1steps.pt, ~3.6 h of
+    oracle time; a partially generated fixture checks the steps it holds)."""
+    from oracle import make_golden_r05 as R5
+    from turbodiffusion_amd.graph import GraphedModel
+    from turbodiffusion_amd.sampler import rcm_sample_iter
+    g = _gold("c1steps")
+    net = GraphedModel(_c1_net())
+    x0, ctx = R5.c1_inputs()
+    noises = [n.to(DEV) for n in R5.c1_noises()]
+    vs = []
+
+    def model(**kw):          # the sampler's network call, with the velocity of every step kept
+        v = net(**kw)
+        vs.append(v.float().clone())
+        return v
+    lines = []
+    for i, x_i in rcm_sample_iter(model, x0.to(DEV), ctx.to(DEV), num_steps=4, noises=noises, sigma_max=80.0):
+        if i >= len(g["x"]):
+            break
+        rv, rx = rel_l2(R5._sub(vs[i]), g["v"][i].float().to(DEV)), rel_l2(R5._sub(x_i.float()), g["x"][i].float().to(DEV))
+        lines.append(f"step {i + 1}: velocity {rv:.4f}, latent {rx:.4f}")
+        assert rv < 3e-2 and rx < 3e-2, (i, rv, rx)
+    with capsys.disabled():
+        print("\n[4 rCM steps at full size, identical noise] rel-L2 vs the oracle per step: " + "; ".join(lines)
+              + (" (fixture partial)" if g.get("partial") else ""))
+    assert lines
+
+
+def test_two_blocks_at_c4_size_all_heads_against_the_oracle(capsys):
+    """C4 / C5's size: dim 5120, 40 heads, ffn 13 824 at L = 75 600 tokens (720p), two blocks, all heads, top-k 0.1: tokens after the
+    second block (every 32nd row + the 80-row tail block) vs the oracle (tests/golden/r05_c4two.pt)."""
+    from oracle import make_golden_r04 as R4
+    from oracle import make_golden_r05 as R5
+    from turbodiffusion_amd.wan import WanModel
+    g = _gold("c4two")
+    cfg = R5.C4["cfg"]
+    with torch.device(DEV):
+        net = WanModel(attention_type="sagesla", sla_topk=R5.C4["topk"], quant_linear=True, **cfg)
+    sd = R4.hash_globals(cfg, device=DEV)
+    for i in range(cfg["num_layers"]):
+        sd.update(R4.hash_layer(cfg, i, device=DEV))
+    net.load_from_float_state_dict(sd)
+    del sd
+    x, t, ctx = R5.c4_inputs()
+    tok = net.eval()(x.to(DEV).bfloat16(), t.to(DEV), ctx.to(DEV), _return_tokens=True)[0]
+    assert tok.shape == (75600, 5120)
+    rows = g["rows"].to(DEV)
+    r, tail = rel_l2(tok[rows], g["tok_rows"].float()), rel_l2(tok[-80:], g["tok_rows"][-80:].float())
+    with capsys.disabled():
+        print(f"\n[two blocks at C4's size: dim 5120 x 75 600 tokens, 40 heads] rel-L2 vs the oracle: sampled rows {r:.4f}, tail block {tail:.4f}")
+    assert r < 2e-2 and tail < 3e-2 and cosine(tok[rows], g["tok_rows"].float()) > 0.999

@@ -1,6 +1,6 @@
 """The W8A8 GEMMs of one DiT block at the per-rank row counts of a sequence split (M = L / N ranks), fused epilogues included:
-the 256x256-tile kernel (TD_TUNE_GEMM_VARIANT = 4) against the automatic choice, which sends problems of <= 128 such tiles to
-the 128x128 kernel (csrc/gemm_w8a8.hip: G_RES / G_STATS / G_QOUT).  DESIGN §6's table comes from here.
+the 256x256-tile kernel (TD_TUNE_GEMM_VARIANT = 4), its 128-row form (6, round 5), the 128x128 kernel (1; csrc/gemm_w8a8.hip:
+G_RES / G_STATS / G_QOUT) and the automatic choice (0).  DESIGN §6's table comes from here.
 
     python tools/gemm_small_m.py [--M 4096,8192,16384]
 """
@@ -18,8 +18,13 @@ from turbodiffusion_amd import kernels as K  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--M", default="4096,8192,16384,32760")
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--dim", type=int, default=1536)
+ap.add_argument("--ffn", type=int, default=8960)
 args = ap.parse_args()
-dev, dim, ffn = "cuda", 1536, 8960
+ap2 = None
+dev, dim, ffn = "cuda", args.dim, args.ffn
+# 4 = 256x256 tiles only, 6 = the 128-row form of the same kernel (round 5), 1 = the 128x128 kernel, 0 = the shipped choice
+VARIANTS = ((4, "tile256"), (6, "tile128x256"), (1, "tile128"), (0, "auto"))
 
 
 def timeit(fn, iters, warm=3):
@@ -58,13 +63,13 @@ for M in [int(v) for v in args.M.split(",")]:
     best = {}
     for rnd in range(2):                 # the two kernels interleaved per operator, best of two rounds (clock ramps)
         for name, fn in ops.items():
-            for variant, tag in ((4, "tile256"), (0, "auto")):
+            for variant, tag in VARIANTS:
                 K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
                 t = timeit(fn, args.iters)
                 key = f"{name} {tag} us"
                 best[key] = min(best.get(key, 1e9), t)
     K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
-    for tag in ("tile256", "auto"):
+    for _, tag in VARIANTS:
         for name in ops:
             row[f"{name} {tag} us"] = round(best[f"{name} {tag} us"], 1)
         row[f"sum {tag} us"] = round(sum(best[f"{name} {tag} us"] for name in ops), 1)

@@ -304,13 +304,15 @@ static int launch_gemm(const int8_t* a, const float* a_s, const int8_t* b, const
   return TD_OK;
 }
 
-// Problems that leave more than half of the 256 CUs without a 256x256 tile go to the 128x128 kernel (two workgroups per CU):
-// the per-rank GEMMs of a wide sequence split (M = 4096, N = 1536: 96 tiles).  TD_TUNE_GEMM_VARIANT overrides (1 / 4 / 5).
+// Problems with fewer than 64 tiles of 128 x 256 go to the 128x128 kernel (two workgroups per CU).  Until round 5 this was "at
+// most 128 tiles of 256 x 256" — the per-rank GEMMs of a wide sequence split (M = 4096, N = 1536: 96 such tiles); those now
+// run on the LDS-DMA kernel's 128-row form (gemm_w8a8_fi.hip, NI = 4), which measured 0.72-0.81 of the 128x128 kernel's time on
+// them (tools/gemm_small_m.py).  TD_TUNE_GEMM_VARIANT overrides (1 / 4 / 5 / 6).
 static bool td_gemm_small(int64_t m, int64_t n) {
   const int v = td_tuning(TD_TUNE_GEMM_VARIANT);
   if (v == 1) return true;
-  if (v != 0) return false;
-  return td_cdiv(m, 256) * td_cdiv(n, 256) <= 128;
+  if (v != 0) return false;    // (4 / 5 / 6: a 256-column LDS-DMA kernel is forced)
+  return td_cdiv(m, 128) * td_cdiv(n, 256) < 64;
 }
 
 // The 256x256 LDS-DMA kernels address the int8 operands through 32-bit buffer offsets (gemm_w8a8_fi.hip: ga / gb, the

@@ -38,12 +38,11 @@
 //   * epilogue identical to v3 (permlane32 swap -> 16-byte row-contiguous stores).
 #include "td_common.h"
 
-#define F_BM 256
 #define F_BN 256
-#define F_TILE (256 * 128)        // one operand tile per K block, bytes
-#define F_STAGE (2 * F_TILE)      // activations + weights
-#define F_LDS (2 * F_STAGE)       // two stages = 128 KB
 #define F_DUMP 4096               // 2 KB landing area of the L2-prefetch dwords + 2 KB epilogue constants (bias, gate)
+// per instantiation (NI = 8 | 4 sixteen-row sub-tiles per wave): tile rows F_BM = 32 NI = 256 | 128; one stage = an activation tile
+// of F_BM x 128 B + a weight tile of 256 x 128 B; two stages = 128 | 96 KB (F_EPI = where the epilogue's scratch behind them
+// starts: 128 KB in both forms, so that the GELU table fits)
 #define F_MAGIC_I 0x4B400000
 #define F_MAGIC_F 12582912.0f
 
@@ -132,7 +131,13 @@ static const uint16_t* td_gelu_table_bf16(hipStream_t st) {
 // (VT = 2), into QS (reinterpreted as 16-bit): bit-identical to td_gemm_w8a8 followed by td_v_transpose, minus a 2-byte
 // write, a 2-byte read and a launch.  Each wave transposes its 128 keys x 64 d through a private LDS region (the stage
 // buffers are free after the main loop) in two 64-key halves: 2-byte scatter writes, 16-byte row reads, full-line stores.
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0>
+// NI = 4 (round 5): a 128(M) x 256(N) tile for the row counts of a sequence shard (M = 4096 per rank of 8: 16 x 18 = 288 tiles of
+// 256 x 256 are 1.1 rounds of the 256 CUs, paid as 2; the 96 tiles at N = 1536 leave 160 CUs idle): the SAME eight waves, two
+// per SIMD, each on 64 x 64 instead of 128 x 64 — a K block is four groups instead of eight, everything else (slot structure,
+// one barrier per K block, fragment ring, epilogues) is the same code with NI for 8.  (A four-wave form with the unchanged
+// 128 x 64 wave tile — one wave per SIMD — measured 0.75 of the per-FLOP rate: tools/gemm_small_m.py, profiles/r05_gemm_small_m.txt.)
+// Bit-identical: the arithmetic per output element does not depend on the tile it is computed in.
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0, int NI = 8>
 __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
@@ -145,6 +150,13 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
   const int wm = wave >> 2, wn = wave & 3;
+  constexpr int WROWS = 16 * NI;                 // rows of a wave tile (128 | 64)
+  constexpr int F_BM = 2 * WROWS;                // tile rows
+  constexpr int F_TILE = F_BM * 128;             // activation tile bytes per K block
+  constexpr int F_STAGE = F_TILE + 256 * 128;    // + weight tile
+  constexpr int F_LDS = 2 * F_STAGE;
+  constexpr int F_EPI = 131072;                  // epilogue scratch (bias / gate constants, amax exchange) behind 128 KB in both forms
+  constexpr int NA = NI / 2;                     // activation chunks (8 rows x 128 B) a wave moves per stage (weights: 4)
   unsigned long long dbg_t[40];
   int dbg_n = 0;
   unsigned long long c_t0 = 0, c_t1 = 0, c_t2 = 0;
@@ -167,13 +179,13 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   const int nk = (int)(K / 128);
 
   // ---- LDS-DMA pieces: wave w moves chunks c = w + 8t (8 rows x 128 B) of both operand tiles ----
-  uint32_t ga[4], gb[4];
+  uint32_t ga[4], gb[4];     // (NI = 4: ga[0..1] used — the activation tile has 16 chunks, two per wave)
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int c = wave + 8 * t;
     const int row = 8 * c + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (LDS image is lane-linear)
-    int64_t am = m0 + row; if (am > M - 1) am = M - 1;   // tail rows: clamp (never stored)
+    int64_t am = m0 + (t < NA ? row : 0); if (am > M - 1) am = M - 1;   // tail rows: clamp (never stored)
     int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
     ga[t] = (uint32_t)(am * lda + chunk * 16);
     gb[t] = (uint32_t)(bn * ldb + chunk * 16);
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // waves 0-3: activation rows 64*(wave&3)+lane, waves 4-7: weight rows.  The loaded dword is never used.
   uint32_t pf_off;
   {
-    const int row = 64 * (wave & 3) + lane;
+    const int row = (64 * (wave & 3) + lane) % F_BM;
     int64_t am = m0 + row; if (am > M - 1) am = M - 1;
     int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
     pf_off = wave < 4 ? (uint32_t)(am * lda) : (uint32_t)(bn * ldb);
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // (LDS-DMA form with a 4-byte element: no destination VGPR; the dwords land in a 2 KB dump area behind the stages)
 #define F_PREFETCH(kb_)                                                                           \
   if constexpr ((SCHED & 2) != 0) {                                                               \
-    char* dump_ = smem + F_LDS + wave * 256;                                                      \
+    char* dump_ = smem + F_EPI + wave * 256;                                                      \
     if (wave < 4)                                                                                 \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)dump_, 4, pf_off, (kb_) * 128, 0, 0); \
     else                                                                                          \
@@ -216,18 +228,18 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   uint32_t xoff[2], woff[2];
 #pragma unroll
   for (int kc = 0; kc < 2; ++kc) {
-    xoff[kc] = f_swz(wm * 128 + l16, 4 * kc + lq);
+    xoff[kc] = f_swz(wm * WROWS + l16, 4 * kc + lq);
     woff[kc] = F_TILE + f_swz(wn * 64 + pr, 4 * kc + lq);
   }
 
-  v4f accf[8][4];
+  v4f accf[NI][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) accf[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
   // scale rows of this wave's 128x64 sub-tile (clamped for tail tiles)
-  int64_t mb = (m0 + wm * 128) >> 7, nb = (n0 + wn * 64) >> 7;
+  int64_t mb = (m0 + wm * WROWS) >> 7, nb = (n0 + wn * 64) >> 7;
   const int64_t mb_max = td_cdiv(M, 128) - 1, nb_max = td_cdiv(N, 128) - 1;
   if (mb > mb_max) mb = mb_max;
   if (nb > nb_max) nb = nb_max;
@@ -264,11 +276,12 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 
   // ---- prologue: stage 0 and stage 1 in flight; wait for stage 0; fragments of group (0,0) ----
 #pragma unroll
-  for (int p = 0; p < 8; ++p) F_PIECE(0, p)
+  for (int p = 0; p < 8; ++p) { if ((p & 3) < NA || p >= 4) F_PIECE(0, p) }
   if (nk > 1) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) F_PIECE(1, p)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int p = 0; p < 8; ++p) { if ((p & 3) < NA || p >= 4) F_PIECE(1, p) }
+    if constexpr (NI == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -311,14 +324,14 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const bool dma_head = kb + 2 < nk;         // first pieces of stage kb+2, after this block's barrier
     float sa_n = 0.f, sb_n = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NI; ++i) {
       const int cur = i & 1, prv = cur ^ 1;
-      const int pi = (i + 7) & 7;  // m sub-tile of the group being dequantised
+      const int pi = (i + NI - 1) % NI;  // m sub-tile of the group being dequantised
       const float scl = (i == 0) ? sc_old : sc_new;
       F_STAMP()
       // -- fragment prefetch for the next group into the other ring slot (its last readers, the MFMAs of
       //    the previous group, have all been issued)
-      if (i < 7) { F_LOAD_X(st, i + 1, prv) }
+      if (i < NI - 1) { F_LOAD_X(st, i + 1, prv) }
       else if (more) { F_LOAD_X(stn, 0, prv) }
       F_FENCE()
       // -- slots 0-3
@@ -329,10 +342,15 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         else if (recentre) { F_ADDC4(accf[pi][j], c_neg) }
       }
       F_FENCE()
-      if (i == 7 && more) { F_LOAD_W(stn, 0) }
+      if (i == NI - 1 && more) { F_LOAD_W(stn, 0) }
       // -- LDS-DMA issue (VMEM issue slots of this wave only)
-      if (i == 7) { F_PREFETCH(kb + 4) }
-      if constexpr (SCHED & 1) {
+      if (i == NI - 1) { F_PREFETCH(kb + 4) }
+      if constexpr (NI == 4) {
+        // six pieces per wave and stage (2 activation + 4 weight chunks), all of stage kb+2 right behind this block's barrier:
+        // three in the last group, three in the next block's first — ~3 groups ahead of the barrier that needs them
+        if (i == 3) { if (dma_head) { F_PIECE(kb + 2, 0) F_PIECE(kb + 2, 4) F_PIECE(kb + 2, 1) } }
+        else if (i == 0) { if (dma_tail) { F_PIECE(kb + 1, 5) F_PIECE(kb + 1, 6) F_PIECE(kb + 1, 7) } }
+      } else if constexpr (SCHED & 1) {
         if (i == 7) { if (dma_head) { F_PIECE(kb + 2, 0) F_PIECE(kb + 2, 4) F_PIECE(kb + 2, 1) F_PIECE(kb + 2, 5) } }
         else if (i == 0) { if (dma_tail) { F_PIECE(kb + 1, 2) F_PIECE(kb + 1, 6) F_PIECE(kb + 1, 3) F_PIECE(kb + 1, 7) } }
       } else {
@@ -343,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         else if (i == 3) { if (dma_tail) { F_PIECE(kb + 1, 3) } }
         else if (i == 4) { if (dma_tail) { F_PIECE(kb + 1, 7) } }
       }
-      if (i == 5) { if (more) { sa_n = as_row[kb + 1]; sb_n = bs_row[kb + 1]; } }  // scalar loads
+      if (i == NI - 3) { if (more) { sa_n = as_row[kb + 1]; sb_n = bs_row[kb + 1]; } }  // scalar loads
       F_FENCE()
       F_STAMP()
       // -- slots 4-7
@@ -353,8 +371,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         F_FMAC4(accf[pi][j], t[prv][j], scl)
       }
       F_FENCE()
-      if (i == 7 && more) { F_LOAD_W(stn, 1) }
-      if (i == 6) {
+      if (i == NI - 1 && more) { F_LOAD_W(stn, 1) }
+      if (i == NI - 2) {
         // every LDS read of stage kb has returned (group 7's fragment was read at the top of this group),
         // this wave's pieces of stage kb+1 have landed; after the barrier: everyone's
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -380,7 +398,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     for (int j = 0; j < 4; ++j) { F_ADD4(t[1][j]) }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { F_FMAC4(accf[7][j], t[1][j], sc_old) }
+  for (int j = 0; j < 4; ++j) { F_FMAC4(accf[NI - 1][j], t[1][j], sc_old) }
   if constexpr (FAST > 0) {
     // whatever M*s_k has not been taken out yet (the last, partial group + the fp64 -> fp32 remainders)
     const float c_hi = (float)c_sum;
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const float c_last = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -c_hi)));
     const float c_last2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, -c_lo)));
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) { F_ADDC4(accf[i][j], c_last) F_ADDC4(accf[i][j], c_last2) }
   }
@@ -422,11 +440,11 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       }
     }
     // (1) the 16-bit results exactly as the plain epilogue would store them, kept in 64 VGPRs
-    uint32_t pk[8][4][2];
+    uint32_t pk[NI][4][2];
     const bool tail = (m0 + F_BM > M) || (n0 + F_BN > N);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const bool m_ok = (m0 + wm * 128 + i * 16 + l16) < M;
+    for (int i = 0; i < NI; ++i) {
+      const bool m_ok = (m0 + wm * WROWS + i * 16 + l16) < M;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         int64_t n = n0 + wn * 64 + j * 16 + 8 * (lq & 1) + 4 * hi;
@@ -477,7 +495,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
               pk[i][j][e] = glo[j][e] | ghi[j][e];                                                  \
             }                                                                                       \
         }
-        F_GELU_LOOKUP(0) F_GELU_LOOKUP(4)
+        F_GELU_LOOKUP(0)
+        if constexpr (NI == 8) { F_GELU_LOOKUP(4) }
 #undef F_GELU_LOOKUP
       }
     }
@@ -486,7 +505,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     //     formats are monotone in their magnitude bits), two per v_pk_max_u16
     uint32_t mx = 0u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -500,16 +519,17 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     F_MARK("qout_exchange")
     // (3) the other half belongs to wave ^ 1: exchange through LDS (free: every wave is past the last barrier
     //     of the main loop, nothing reads or lands in the stages any more)
-    uint32_t* red = reinterpret_cast<uint32_t*>(smem + F_LDS + 2048);   // (behind the stages: those may hold the GELU table)
+    uint32_t* red = reinterpret_cast<uint32_t*>(smem + F_EPI + 2048);   // (behind 128 KB: the stage area may hold the GELU table)
     if (lane == 0) red[wave] = m16;
     __syncthreads();
     m16 = max(red[wave], red[wave ^ 1]);
+    if constexpr (NI == 4) m16 = max(m16, max(red[wave ^ 4], red[wave ^ 5]));   // 64-row wave tiles: the quant block spans both wm
     float amax = half_bits_to_f32<ODT>(m16);
     amax = fmaxf(amax, 1e-8f);
     const float mult = 128.0f / amax;  // IEEE division, as quant.hip
     {
-      const int64_t mb_q = (m0 + wm * 128) >> 7, nb_q = (n0 + wn * 64) >> 7;
-      if (lane == 0 && (wn & 1) == 0 && (m0 + wm * 128) < M && (n0 + wn * 64) < N) QS[mb_q * ldqs + nb_q] = amax / 128.0f;
+      const int64_t mb_q = (m0 + wm * WROWS) >> 7, nb_q = (n0 + wn * 64) >> 7;
+      if (lane == 0 && (wn & 1) == 0 && (NI == 8 || wm == 0) && (m0 + wm * WROWS) < M && (n0 + wn * 64) < N) QS[mb_q * ldqs + nb_q] = amax / 128.0f;
     }
     // (4) quantise: q = sat_s8(rne(x * mult)).  rne via the 1.5*2^23 add (exact for |v| < 2^22, same result as
     //     rintf of the rounded product); its low byte IS the two's-complement code.  |x*mult| <= 128(1+eps), so only
@@ -517,8 +537,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     int8_t* Dq = reinterpret_cast<int8_t*>(D);
     F_MARK("qout_quantise_store")
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int64_t m = m0 + wm * 128 + i * 16 + l16;
+    for (int i = 0; i < NI; ++i) {
+      const int64_t m = m0 + wm * WROWS + i * 16 + l16;
       uint32_t qd[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -555,13 +575,13 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // RES: the residual tile is fetched up front — 16 independent 16-byte loads per lane in flight, at the addresses
   // this lane will store to (row i*16 + l16, the 8 consecutive n it owns after the lane swap) — so their latency
   // overlaps the conversion of the accumulators instead of serialising load -> add -> store per row
-  uint4 xres[RES ? 8 : 1][2];
+  uint4 xres[RES ? NI : 1][2];
   if constexpr (RES) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
-        const int64_t m = m0 + wm * 128 + i * 16 + l16;
+        const int64_t m = m0 + wm * WROWS + i * 16 + l16;
         const int64_t n = n0 + wn * 64 + (hi ? 2 * jp + 1 : 2 * jp) * 16 + 8 * (lq & 1);
         xres[i][jp] = make_uint4(0, 0, 0, 0);
         if (m < M && n < N) xres[i][jp] = *reinterpret_cast<const uint4*>(D + m * ldd + n);
@@ -577,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   // group with ds_read (lgkmcnt).  As global loads inside the row-group loop (the compiler does not hoist them) each one
   // carried an s_waitcnt vmcnt(0), and on gfx9 vmcnt counts STORES too: every row group waited for the previous group's
   // statistics store / the previous half's tile stores to complete.
-  float* ep_bias = reinterpret_cast<float*>(smem + F_LDS + 2048);
+  float* ep_bias = reinterpret_cast<float*>(smem + F_EPI + 2048);
   float* ep_gate = ep_bias + 256;
   if (tid < 256) {
     const int64_t n = n0 + tid;
@@ -595,8 +615,8 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   uint16_t* vt_lds = stg_lds;         // the wave's transposition buffer [64 d][64 positions (+8 pad)] 16-bit
   if constexpr (VT != 0) vtile = n0 >= ldqs;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int64_t m = m0 + wm * 128 + i * 16 + l16;
+  for (int i = 0; i < NI; ++i) {
+    const int64_t m = m0 + wm * WROWS + i * 16 + l16;
     float st_s = 0.f, st_q = 0.f, st_c = 0.f;   // STATS: this lane's share of the row's 64-column piece (shifted by st_c)
     uint32_t pk[4][2];
 #pragma unroll
@@ -680,7 +700,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
           const int row = it * 8 + (lane >> 3), chunk = lane & 7;
-          const int64_t mm = m0 + wm * 128 + (i >> 2) * 64 + row, nn = n0 + wn * 64 + chunk * 8;
+          const int64_t mm = m0 + wm * WROWS + (i >> 2) * 64 + row, nn = n0 + wn * 64 + chunk * 8;
           const uint4 r = *reinterpret_cast<const uint4*>(stg_lds + row * 72 + chunk * 8);
           if (mm < M && nn < N) *reinterpret_cast<uint4*>(D + mm * ldd + nn) = r;
         }
@@ -691,7 +711,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
       if (vtile && (i & 3) == 3) {   // a 64-key half is complete in LDS: 8 d rows x 128 B per store instruction
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int64_t Kb = (M + 63) >> 6;
-        const int64_t kb = ((m0 + wm * 128) >> 6) + (i >> 2);
+        const int64_t kb = ((m0 + wm * WROWS) >> 6) + (i >> 2);
         const int64_t head = ((n0 - ldqs) >> 7) + (wn >> 1);
         uint16_t* dst = reinterpret_cast<uint16_t*>(QS) + (head * Kb + kb) * (128 * 64) + (int64_t)((wn & 1) * 64) * 64;
         if (kb < Kb) {
@@ -735,11 +755,30 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   }
 }
 
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0>
+// 128-row tiles (NI = 4) when they finish sooner by the round count: rounds of the 256 CUs x the relative cost of a half-height
+// tile — 0.5 in matrix work; measured (tools/gemm_small_m.py, profiles/r05_gemm_small_m.txt: shapes where both forms run whole
+// rounds) 0.59-0.60 with the fused epilogues (quantiser, residual, row statistics) and 0.79 with the plain 16-bit store.
+// TD_TUNE_GEMM_VARIANT = 6 forces them, 4 forbids them.
+static bool td_gemm_half_tiles(int64_t m, int64_t n, bool plain_store) {
+  const int v = td_tuning(TD_TUNE_GEMM_VARIANT);
+  if (v == 6) return true;
+  if (v == 4) return false;
+  const int64_t tn = td_cdiv(n, 256);
+  const double cost = plain_store ? 0.80 : 0.60;
+  const double full = (double)td_cdiv(td_cdiv(m, 256) * tn, 256), half = cost * (double)td_cdiv(td_cdiv(m, 128) * tn, 256);
+  return half < full;
+}
+
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0, int NI = 8>
 static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
-  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT>;
+  if constexpr (NI == 8 && DBG == 0 && SCHED == 0 && FAST == 0) {
+    if (td_gemm_half_tiles(m, n, !QOUT && !RES && !STATS))   // a sequence shard's row count: 128-row tiles (see the kernel's NI note)
+      return launch_gemm_fi<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 0, STATS, VT, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate);
+  }
+  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT, NI>;
+  constexpr int F_BM = 32 * NI, F_LDS = 131072;    // (both forms allocate 128 KB + scratch: one workgroup per CU either way)
   const uint16_t* gelu_tab = nullptr;
   if constexpr (QOUT && EPI == TD_EPI_GELU_TANH && ODT == TD_BF16) {
     if (td_tuning(TD_TUNE_GELU_TABLE) != 1) gelu_tab = td_gelu_table_bf16(st);   // 1 = the inline form (cross-check / A-B)

@@ -57,6 +57,19 @@ class EmulatedGroup:
         self.rank, self.world = rank, world
 
 
+import os as _os
+EMU_WIRE_STREAM = _os.environ.get("TD_EMU_WIRE_STREAM", "1") != "0"   # EmulatedGroup: transfers on their own stream (0: on the issuing stream, round 4's form)
+_EMU_STREAMS = {}
+
+
+def _emu_stream():
+    dev = torch.cuda.current_device()
+    st = _EMU_STREAMS.get(dev)
+    if st is None:
+        st = _EMU_STREAMS[dev] = torch.cuda.Stream()
+    return st
+
+
 WAIT_PROBE = None   # bench.py (N > 1): a list that receives (event before, event after, bytes gathered) of every stream-side wait
 #                     for an asynchronous gather — the time the compute stream sat waiting for the wire, per collective
 
@@ -75,6 +88,20 @@ class _Gather:
 
     def issue(self):
         if self.emulated:
+            # the emulated transfer runs where a real one does: on a stream of its own (RCCL's communicator stream), forked
+            # off the issuing stream here and joined at ``wait`` — kernels enqueued in between overlap it, as they overlap
+            # the wire.  (Still CU / HBM work of THIS GPU where the fabric's DMA would do the writes: pessimistic, not free.)
+            if self.out.is_cuda and self.async_op and EMU_WIRE_STREAM:
+                main = torch.cuda.current_stream()
+                st = _emu_stream()
+                e = torch.cuda.Event()
+                e.record(main)
+                st.wait_event(e)
+                with torch.cuda.stream(st):
+                    self.out.view(self.group.world, -1).copy_(self.src.view(1, -1).expand(self.group.world, -1))
+                    self.done = torch.cuda.Event()
+                    self.done.record(st)
+                return
             self.out.view(self.group.world, -1).copy_(self.src.view(1, -1).expand(self.group.world, -1))
         elif self.via_host:
             host = torch.empty(self.out.shape, dtype=self.out.dtype)
@@ -97,7 +124,13 @@ class _Gather:
             self.work = None
 
     def wait(self):
-        if self.async_op and not self.via_host and not self.emulated:
+        if self.emulated:
+            d = getattr(self, "done", None)
+            if d is not None:
+                torch.cuda.current_stream().wait_event(d)
+                self.done = None
+            return
+        if self.async_op and not self.via_host:
             eager_point(self._wait)
 
 
