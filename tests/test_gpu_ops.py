@@ -459,7 +459,7 @@ def test_gemm_128_row_tile_form_is_bit_identical(K, m, n, k):
     aq, as_ = K.quant_i8_block128(a.to(DEV))
     wq, ws = K.quant_i8_block128(w.to(DEV))
     outs = {}
-    for variant in (4, 6):
+    for variant in (4, 6, 0):      # 0: the automatic plan — for (4096, 8960, 1536) the MIXED one (two rounds of 256-row tiles + 128-row tiles)
         K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
         try:
             r = {"plain": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b), "gelu": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True),
@@ -482,9 +482,12 @@ def test_gemm_128_row_tile_form_is_bit_identical(K, m, n, k):
             K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
             K.set_tuning(K.TUNE_GELU_TABLE, 0)
         outs[variant] = r
-    for key in outs[4]:
-        assert torch.equal(outs[4][key].view(torch.uint8) if outs[4][key].dtype == torch.float16 else outs[4][key],
-                           outs[6][key].view(torch.uint8) if outs[6][key].dtype == torch.float16 else outs[6][key]), key
+    for other in (6, 0):
+        for key in outs[4]:
+            if other == 0 and key.startswith("part_"):
+                continue      # (a problem this small goes to the 128x128 kernel automatically: its partials agree to rounding, not bit for bit)
+            assert torch.equal(outs[4][key].view(torch.uint8) if outs[4][key].dtype == torch.float16 else outs[4][key],
+                               outs[other][key].view(torch.uint8) if outs[other][key].dtype == torch.float16 else outs[other][key]), (other, key)
     if "q" in outs[6]:
         assert torch.equal(outs[6]["q"], outs[6]["qi"]) and torch.equal(outs[6]["qs"], outs[6]["qsi"])
 

@@ -143,7 +143,9 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int tiles_m, int tiles_n, int group_m,
     unsigned long long* __restrict__ dbg, float* __restrict__ QS, int64_t ldqs, const float* __restrict__ gate,
-    const uint16_t* __restrict__ gelu_tab = nullptr) {
+    const uint16_t* __restrict__ gelu_tab = nullptr, int tm0 = 0) {
+  // tm0: index of this launch's first row tile (in tiles of F_BM rows) — a launch may cover a row range [tm0 F_BM, ...) of the
+  // problem (launch_gemm_fi: whole rounds on 256-row tiles, the remainder on 128-row tiles); M stays the problem's row count
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   const int first_m = gid * group_m;
   const int gsz = min(group_m, tiles_m - first_m);
   const int in_g = vid % per_group;
-  const int tm = first_m + in_g % gsz;
+  const int tm = first_m + in_g % gsz + tm0;
   const int tn = in_g / gsz;
   const int64_t m0 = (int64_t)tm * F_BM, n0 = (int64_t)tn * F_BN;
   const int nk = (int)(K / 128);
@@ -755,45 +757,70 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   }
 }
 
-// 128-row tiles (NI = 4) when they finish sooner by the round count: rounds of the 256 CUs x the relative cost of a half-height
-// tile — 0.5 in matrix work; measured (tools/gemm_small_m.py, profiles/r05_gemm_small_m.txt: shapes where both forms run whole
-// rounds) 0.59-0.60 with the fused epilogues (quantiser, residual, row statistics) and 0.79 with the plain 16-bit store.
-// TD_TUNE_GEMM_VARIANT = 6 forces them, 4 forbids them.
-static bool td_gemm_half_tiles(int64_t m, int64_t n, bool plain_store) {
-  const int v = td_tuning(TD_TUNE_GEMM_VARIANT);
-  if (v == 6) return true;
-  if (v == 4) return false;
-  const int64_t tn = td_cdiv(n, 256);
-  const double cost = plain_store ? 0.80 : 0.60;
-  const double full = (double)td_cdiv(td_cdiv(m, 256) * tn, 256), half = cost * (double)td_cdiv(td_cdiv(m, 128) * tn, 256);
-  return half < full;
-}
-
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0, int NI = 8>
-static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
-                          const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
-                          hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
-  if constexpr (NI == 8 && DBG == 0 && SCHED == 0 && FAST == 0) {
-    if (td_gemm_half_tiles(m, n, !QOUT && !RES && !STATS))   // a sequence shard's row count: 128-row tiles (see the kernel's NI note)
-      return launch_gemm_fi<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 0, STATS, VT, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate);
-  }
+// one launch over the row tiles [tm0, tm0 + tiles_m) (tiles of 32 NI rows)
+template <int ODT, int EPI, bool HAS_BIAS, int DBG, int SCHED, bool QOUT, bool RES, int FAST, bool STATS, int VT, int NI>
+static int launch_gemm_fi_range(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                                const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
+                                hipStream_t st, float* qs, int64_t ldqs, const float* gate, int tm0, int tiles_m) {
   auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT, NI>;
-  constexpr int F_BM = 32 * NI, F_LDS = 131072;    // (both forms allocate 128 KB + scratch: one workgroup per CU either way)
+  constexpr int F_LDS = 131072;    // (both forms allocate 128 KB + scratch: one workgroup per CU either way)
   const uint16_t* gelu_tab = nullptr;
   if constexpr (QOUT && EPI == TD_EPI_GELU_TANH && ODT == TD_BF16) {
     if (td_tuning(TD_TUNE_GELU_TABLE) != 1) gelu_tab = td_gelu_table_bf16(st);   // 1 = the inline form (cross-check / A-B)
   }
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), F_LDS + F_DUMP, attr_mask);
-  const int tiles_m = (int)td_cdiv(m, F_BM), tiles_n = (int)td_cdiv(n, F_BN);
+  const int tiles_n = (int)td_cdiv(n, F_BN);
   const int group_m = td_tuning(TD_TUNE_GEMM_GROUP_M) > 0 ? td_tuning(TD_TUNE_GEMM_GROUP_M) : 4;
   const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;
   // profiling only: row stride of both int8 operands = k + pad (the caller's buffers must be that large)
   const int64_t ldab = k + td_tuning(TD_TUNE_GEMM_LDPAD);
   kern<<<nwg, 512, F_LDS + F_DUMP, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldab, ldab, ldd,
-                                tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr, qs, ldqs, gate, gelu_tab);
+                                tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr, qs, ldqs, gate, gelu_tab, tm0);
   TD_CHECK_LAUNCH();
   return TD_OK;
+}
+
+// Tile form(s) of a problem.  Time ~ rounds of the 256 CUs x relative tile cost (a 128-row tile: 0.5 of a 256 x 256 one in
+// matrix work; measured — tools/gemm_small_m.py, profiles/r05_gemm_small_m.txt, shapes where both forms run whole rounds —
+// 0.59-0.60 with the fused epilogues (quantiser, residual, row statistics), 0.79 with the plain 16-bit store).  Three plans:
+//   (a) 256-row tiles only                                   ceil(T / 256)
+//   (b) 128-row tiles only                                   c x ceil(2T' / 256)
+//   (c) MIXED: as many whole rounds of 256-row tiles as fit, the remaining rows on 128-row tiles in a second launch
+//       (ffn.0 of a rank of 8: 560 tiles = 2.19 rounds -> 2 rounds + 140 half tiles = 2.6 instead of 3)
+// the cheapest wins; (c) must beat the better of (a) / (b) by 5 % to pay for its second launch.  Bit-identical whatever the
+// plan.  TD_TUNE_GEMM_VARIANT = 4 forces (a), 6 forces (b), 7 allows only (a) / (b).
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0, int NI = 8>
+static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
+                          const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
+                          hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
+  const int tm8 = (int)td_cdiv(m, 256), tm4 = (int)td_cdiv(m, 128), tn = (int)td_cdiv(n, F_BN);
+  if constexpr (DBG == 0 && SCHED == 0 && FAST == 0) {
+    const int v = td_tuning(TD_TUNE_GEMM_VARIANT);
+    const double c = (!QOUT && !RES && !STATS) ? 0.80 : 0.60;
+    auto rounds = [](int64_t tiles) { return (double)td_cdiv(tiles, 256); };
+    const double pa = rounds((int64_t)tm8 * tn), pb = c * rounds((int64_t)tm4 * tn);
+    // (c): the largest row-tile count whose tiles fill whole rounds
+    const int whole = (int)(((int64_t)tm8 * tn) / 256);            // full rounds available
+    int m1 = 0;
+    double pc = 1e30;
+    if (whole >= 1 && v != 4 && v != 6 && v != 7) {
+      m1 = (int)(((int64_t)whole * 256) / tn);                    // row tiles (of 256) in the first launch
+      if (m1 >= tm8) m1 = tm8 - 1;
+      if (m1 >= 1) {
+        const int64_t rest4 = (int64_t)(tm4 - 2 * m1) * tn;        // 128-row tiles of the remaining rows
+        pc = rounds((int64_t)m1 * tn) + c * rounds(rest4);
+      }
+    }
+    if (v == 6 || (v != 4 && pb < pa && pb <= pc * 1.05))
+      return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 0, STATS, VT, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, tm4);
+    if (v != 4 && v != 6 && pc * 1.05 < pa && pc * 1.05 < pb) {
+      int rc = launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 0, STATS, VT, 8>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, m1);
+      if (rc != TD_OK) return rc;
+      return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 0, STATS, VT, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 2 * m1, tm4 - 2 * m1);
+    }
+  }
+  return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT, NI>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, tm8);
 }
 
 // called by td_gemm_w8a8 (gemm_w8a8.hip) after argument validation; needs ldd % 8 == 0
