@@ -70,7 +70,7 @@ const char* td_last_error(void);
 #define TD_TUNE_GEMM_FAST 6     /* W8A8 GEMM dequant: 0 = build default, 1 = exact (bit-identical to the reference arithmetic),
                                   G in {2,4,8} = one-VALU dequant re-centred every G K blocks (|diff| <= 0.75 (G+1) sum_k s_k) */
 #define TD_TUNE_LIN_QB 7       /* linear branch, pass 2: Q blocks one workgroup walks (0 = default) */
-#define TD_TUNE_ATTN_OCC 8     /* INT8/FP16-PV attention builds kept for comparison: 2 = two workgroups per CU with explicit fragment prefetch, 3 = Q64 (waves as 2 Q halves x 2 key halves; equal to rounding, not bit-identical), 4 = build 2 with the softmax denominator accumulated on the matrix pipe (round-4 experiment; equal to rounding) */
+#define TD_TUNE_ATTN_OCC 8     /* INT8/FP16-PV attention builds kept for comparison: 2 = two workgroups per CU with explicit fragment prefetch, 3 = Q64 (waves as 2 Q halves x 2 key halves; equal to rounding, not bit-identical), 4 = build 2 with the softmax denominator accumulated on the matrix pipe (round-4 experiment; equal to rounding), 5 = the production build with the denominator from the fp16-ROUNDED probabilities, two per v_dot2_f32_f16 (round-5 experiment: 16 instead of 32 VALU per lane and tile; measured equal, profiles/r05_attn_dot2.txt) */
 #define TD_TUNE_VAE_CONV 9     /* td_vae_conv.  0 = default: the 2-D-tile kernel staged by LDS-DMA (csrc/vae_conv3.hip, frames-first tile order; 256-position tiles with two workgroups per CU, 512-position tiles for the 384-channel x 27-tap reductions) for the 3x3 spatial kernels with C_out % 96 == 0 or <= 32, the row-tile kernel (csrc/vae_conv.hip) for everything else; 8 / 9 = always 512 / 256 positions; 7 = 512 with the tiles of a frame first; 2 = the row-tile kernel everywhere (the default until round 4; cross-check); 1 = the first kernel (one gather per tap, flat position tiles), cross-check; 3 = row tiles of 512 columns, one workgroup per CU (experiment, slower), 4 = row tiles with 32-channel chunks in two LDS stages, 5 = row tiles, frames-first order, 6 = 4 with the chunk multiply unrolled (experiments: equal within 1 %) */
 #define TD_TUNE_GEMM16 10      /* td_gemm_bf16, 16-bit outputs: 2 = the four-wave kernel (128x128 wave tiles, accumulators in AGPRs: round-4 experiment, measured equal to the default eight-wave kernel; bit-identical results) */
 #define TD_TUNE_GELU_TABLE 11  /* td_gemm_w8a8_quant, bf16 + GELU-tanh (the FFN's first GEMM): 0 = the GELU of the fused epilogue as a lookup in the

@@ -1,0 +1,41 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
+python - <<'PY'
+import torch, statistics, sys
+sys.path.insert(0, ".")
+from turbodiffusion_amd import kernels as K
+dev = "cuda"
+H, L = 12, 32760
+g = torch.Generator(device=dev).manual_seed(0)
+q = torch.randn(H, L, 128, device=dev, generator=g).bfloat16()
+k = torch.randn(H, L, 128, device=dev, generator=g).bfloat16()
+v = torch.randn(L, H, 128, device=dev, generator=g).bfloat16()
+km = K.seq_mean(k)
+pq, q8, qs = K.sage_quant_pool(q, None, 128)
+pk, k8, ks = K.sage_quant_pool(k, km, 64)
+lut = K.sla_topk(pq, pk, 51)
+vt = K.v_transpose(v, 128, H * 128, L, H, 128, torch.float16)
+out = torch.empty((L, H * 128), dtype=torch.bfloat16, device=dev)
+res = {}
+ts = {0: [], 5: []}
+for rep in range(5):
+    for mode in (0, 5):
+        K.set_tuning(K.TUNE_ATTN_OCC, mode)
+        for _ in range(2):
+            K.attn_i8(q8, qs, k8, ks, vt, lut, out, 128, H * 128)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            K.attn_i8(q8, qs, k8, ks, vt, lut, out, 128, H * 128)
+        e1.record(); e1.synchronize()
+        ts[mode].append(e0.elapsed_time(e1) / 10 * 1e3)
+        res[mode] = out.clone()
+K.set_tuning(K.TUNE_ATTN_OCC, 0)
+d = (res[0].float() - res[5].float())
+print("attention [12, 32760, 128] top-k 51: production %.1f us, dot2 row sum %.1f us; rel-L2 between them %.2e" % (
+    statistics.median(ts[0]), statistics.median(ts[5]), (d.norm() / res[0].float().norm()).item()))
+PY
+for i in 1 2; do for mode in 0 5; do
+timeout 600 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-box-calibration --tune 8=$mode 2>/dev/null | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.readline()); print('attn mode $mode:', round(r['dit_step_ms'],2), 'ms per DiT step; attention launch', round(r['roofline_attention']['avg_launch_ms']*1e3,1), 'us; gemm', round(r['roofline']['avg_launch_ms']*1e3,1))"
+done; done

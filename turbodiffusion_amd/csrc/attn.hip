@@ -118,7 +118,7 @@ template <> struct Mma16<TD_BF16> {
 // tile against an all-ones A operand accumulate sum_k P[k][q] into one more accumulator block (every row of it is the row
 // sum, complete over both half-waves), and the 32 v_add per lane and tile of `psum` leave the VALU stream.  The denominator
 // is then the sum of the ROUNDED probabilities (what the numerator uses); results equal to rounding, not bit-identical.
-template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false, bool ROWSUM = false>
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false, bool ROWSUM = false, bool DOT2 = false>
 // lut_all / ks_all / qs_all repeat p.lut / p.k_s / p.q_s as __restrict__ kernel arguments: only then are the per-iteration
 // LUT entry and K scale SCALAR loads (s_load, lgkmcnt).  As vector loads they drag an s_waitcnt vmcnt(0) into the loop,
 // which waits for every K/V tile in flight and undoes the fetch-ahead.
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         s[g][r] = __builtin_amdgcn_exp2f(fmaf(s[g][r], mult, cc));
-        if constexpr (!ROWSUM) psum += s[g][r];
+        if constexpr (!ROWSUM && !DOT2) psum += s[g][r];
       }
     if constexpr (ROWSUM) lacc[0] *= alpha;     // (only row 0 of the ones-product is ever read: every row holds the same sum)
     else l_part = l_part * alpha + psum;
@@ -406,6 +406,19 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
     for (int ks = 0; ks < 4; ++ks) {
       const int g = ks >> 1, t = ks & 1;
       pf[ks] = pack8<PDT>(&s[g][8 * t]);
+    }
+    if constexpr (DOT2) {
+      // round-5 experiment (TD_TUNE_ATTN_OCC = 5): the row sum from the ROUNDED probabilities — the values the PV product uses —
+      // two per instruction: v_dot2_f32_f16 against (1, 1), fp32 accumulate; 16 instead of 32 VALU per lane and tile
+      typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+      const h2v ones2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint32_t w4[4] = {pf[ks].x, pf[ks].y, pf[ks].z, pf[ks].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) psum = __builtin_amdgcn_fdot2(__builtin_bit_cast(h2v, w4[e]), ones2, psum, false);
+      }
+      l_part += psum;     // (l_part was scaled by alpha above with psum = 0)
     }
     // ---- O^T += V^T . P^T ----
     if constexpr (OCC2) {
@@ -886,21 +899,22 @@ static int launch_attn_q64(const AttnParams& p_in, hipStream_t st) {
   return TD_OK;
 }
 
-template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false, bool ROWSUM = false>
+template <bool QK_I8, int PDT, int ODT, bool PV8 = false, bool OCC2 = false, bool STAMP = false, bool ROWSUM = false, bool DOT2 = false>
 static int launch_attn(const AttnParams& p_in, hipStream_t st) {
   AttnParams p = p_in;
   p.dbg = nullptr;
-  if constexpr (QK_I8 && !PV8 && !OCC2 && !STAMP) {
+  if constexpr (QK_I8 && !PV8 && !OCC2 && !STAMP && !DOT2) {
     if (td_tuning(TD_TUNE_ATTN_OCC) == 2) return launch_attn<QK_I8, PDT, ODT, PV8, true>(p, st);
     if (td_tuning(TD_TUNE_ATTN_OCC) == 3) return launch_attn_q64<ODT>(p, st);
     if (td_tuning(TD_TUNE_ATTN_OCC) == 4) return launch_attn<QK_I8, PDT, ODT, PV8, true, false, true>(p, st);
+    if constexpr (PDT == TD_F16) { if (td_tuning(TD_TUNE_ATTN_OCC) == 5) return launch_attn<QK_I8, PDT, ODT, PV8, false, false, false, true>(p, st); }
   }
-  if constexpr (!PV8 && !OCC2 && !STAMP && ODT == TD_BF16 && (QK_I8 || PDT == TD_BF16)) {
+  if constexpr (!PV8 && !OCC2 && !STAMP && !DOT2 && ODT == TD_BF16 && (QK_I8 || PDT == TD_BF16)) {
     // profiling instantiations of the two kernels the model runs (bf16 outputs)
     if (td_tuning(TD_TUNE_ATTN_OCC) == 9) return launch_attn<QK_I8, PDT, ODT, PV8, false, true>(p, st);
   }
   if constexpr (STAMP) p.dbg = td_dbg_buffer();
-  auto kern = attn_kernel<QK_I8, PDT, ODT, PV8, OCC2, STAMP, ROWSUM>;
+  auto kern = attn_kernel<QK_I8, PDT, ODT, PV8, OCC2, STAMP, ROWSUM, DOT2>;
   // two (three: OCC2) tile buffers, and at least the 128 x 272-byte staging area of the epilogue's transpose
   constexpr int lds_tiles = (OCC2 ? 3 : 2) * (KTile<QK_I8>::BYTES + (PV8 ? VT8_BYTES : VT_BYTES));
   constexpr int lds = lds_tiles > 128 * 272 ? lds_tiles : 128 * 272;
