@@ -75,7 +75,11 @@ const char* td_last_error(void);
 #define TD_TUNE_GEMM16 10      /* td_gemm_bf16, 16-bit outputs: 2 = the four-wave kernel (128x128 wave tiles, accumulators in AGPRs: round-4 experiment, measured equal to the default eight-wave kernel; bit-identical results) */
 #define TD_TUNE_GELU_TABLE 11  /* td_gemm_w8a8_quant, bf16 + GELU-tanh (the FFN's first GEMM): 0 = the GELU of the fused epilogue as a lookup in the
                                   device-built 65 536-entry table of td_gelu_tanh (bit-identical), 1 = evaluated inline (cross-check, A/B) */
-#define TD_TUNE_COUNT 12
+#define TD_TUNE_GEMM_COTENANT 12 /* 1 = the W8A8 GEMMs launched while this is set run BESIDE another GEMM on a second stream (the token-half
+                                   split of a block's tail, wan.py): 256-row tiles only — the 128-row / mixed plans of gemm_w8a8_fi.hip price a
+                                   launch as if it owned the 256 CUs, and half-height tiles cost 1.2x the matrix work per output (measured at
+                                   N = 1 with the plans left on: -3.8 %, profiles/r05_gemm_plan_n1_ab.txt) */
+#define TD_TUNE_COUNT 13
 int td_set_tuning(int key, int value);
 /* profiling: copy the n (<= 256) 64-bit s_memtime stamps of the last TD_TUNE_GEMM_ABLATE == 9 launch to host */
 int td_debug_read(unsigned long long* host_dst, int n);

@@ -796,7 +796,8 @@ static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, co
                           hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
   const int tm8 = (int)td_cdiv(m, 256), tm4 = (int)td_cdiv(m, 128), tn = (int)td_cdiv(n, F_BN);
   if constexpr (DBG == 0 && SCHED == 0 && FAST == 0) {
-    const int v = td_tuning(TD_TUNE_GEMM_VARIANT);
+    int v = td_tuning(TD_TUNE_GEMM_VARIANT);
+    if (v == 0 && td_tuning(TD_TUNE_GEMM_COTENANT)) v = 4;   // beside another GEMM: a launch does not own the chip, whole tiles only
     const double c = (!QOUT && !RES && !STATS) ? 0.80 : 0.60;
     auto rounds = [](int64_t tiles) { return (double)td_cdiv(tiles, 256); };
     const double pa = rounds((int64_t)tm8 * tn), pb = c * rounds((int64_t)tm4 * tn);

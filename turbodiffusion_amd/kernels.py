@@ -73,6 +73,7 @@ TUNE_LIN_QB = 7      # linear branch pass 2: Q blocks per workgroup (0 = library
 TUNE_ATTN_OCC = 8    # 2 = INT8/FP16-PV attention built for two workgroups per CU with explicit fragment prefetch, 3 = the Q64 build, 4 = 2 + row sum on the matrix pipe
 TUNE_VAE_CONV = 9    # 1 = the first td_vae_conv kernel (cross-check of the default)
 TUNE_GELU_TABLE = 11  # 1 = the fused FFN GEMM's GELU evaluated inline instead of looked up in the device-built table (bit-identical; A/B)
+TUNE_GEMM_COTENANT = 12  # 1 while W8A8 GEMMs are launched beside another GEMM on a second stream (256-row tiles only)
 TUNE_GEMM16 = 10     # td_gemm_bf16: 2 = the four-wave 128x128 experiment (bit-identical, measured equal); default eight waves of 128x64
 
 
