@@ -74,7 +74,7 @@ const char* td_last_error(void);
 #define TD_TUNE_VAE_CONV 9     /* td_vae_conv.  0 = default: the 2-D-tile kernel staged by LDS-DMA (csrc/vae_conv3.hip, frames-first tile order; 256-position tiles with two workgroups per CU, 512-position tiles for the 384-channel x 27-tap reductions) for the 3x3 spatial kernels with C_out % 96 == 0 or <= 32, the row-tile kernel (csrc/vae_conv.hip) for everything else; 8 / 9 = always 512 / 256 positions; 7 = 512 with the tiles of a frame first; 2 = the row-tile kernel everywhere (the default until round 4; cross-check); 1 = the first kernel (one gather per tap, flat position tiles), cross-check; 3 = row tiles of 512 columns, one workgroup per CU (experiment, slower), 4 = row tiles with 32-channel chunks in two LDS stages, 5 = row tiles, frames-first order, 6 = 4 with the chunk multiply unrolled (experiments: equal within 1 %) */
 #define TD_TUNE_GEMM16 10      /* td_gemm_bf16, 16-bit outputs: 2 = the four-wave kernel (128x128 wave tiles, accumulators in AGPRs: round-4 experiment, measured equal to the default eight-wave kernel; bit-identical results) */
 #define TD_TUNE_GELU_TABLE 11  /* td_gemm_w8a8_quant, bf16 + GELU-tanh (the FFN's first GEMM): 0 = the GELU of the fused epilogue as a lookup in the
-                                  device-built 65 536-entry table of td_gelu_tanh (bit-identical), 1 = evaluated inline (cross-check, A/B) */
+                                  device-built 65 536-entry table of the GELU function of csrc/td_common.h: bit-identical, 1 = evaluated inline (cross-check, A/B) */
 #define TD_TUNE_GEMM_COTENANT 12 /* 1 = the W8A8 GEMMs launched while this is set run BESIDE another GEMM on a second stream (the token-half
                                    split of a block's tail, wan.py): 256-row tiles only — the 128-row / mixed plans of gemm_w8a8_fi.hip price a
                                    launch as if it owned the 256 CUs, and half-height tiles cost 1.2x the matrix work per output (measured at

@@ -74,7 +74,7 @@ def _general_sla_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, out, o_stride_h, 
 
 def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, out, o_stride_h, o_stride_l,
                                 v_strides, blkq=128, blkk=64, dense=False, quant_out=False, km=None, pv="fp16", vt=None,
-                                side=None, q_fn=None, feature_map="softmax", side2=None, k_fn=None):
+                                side=None, q_fn=None, feature_map="softmax"):
     """Core of both modules on head-major tensors.
 
     q, k: [H, L, D] 16-bit (after RoPE); vt_src: tensor holding V with element (h,l,d) at
@@ -96,15 +96,6 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
     The linear branch (needs only q, k, v) runs FIRST and leaves o_l in a lane-private layout; the attention kernel adds
     it in its epilogue (o = o_s + o_l, the 16-bit add of SLA/core.py:253) — no read-modify-write pass over the output.
     """
-    if k is None:
-        # three-branch schedule (round 5): ``k_fn()`` produces k on the current stream AFTER the fork, so that the Q side's
-        # norm + RoPE (on ``side``) no longer queues behind it; the linear branch's pass over K runs on ``side2``
-        assert k_fn is not None and side is not None and side2 is not None and q_fn is not None and q is None
-        if (sage and not dense and proj_w is not None and pv == "fp16" and vt is not None and km is None and blkq == 128
-                and feature_map == "softmax"):
-            return _sagesla_three_branches(q_fn, k_fn, vt, proj_w, proj_b, topk_ratio, out, o_stride_h, o_stride_l, blkq, blkk,
-                                           quant_out, side, side2)
-        k = k_fn()
     H, L_, D = k.shape
     _check_geometry(D, blkq, blkk)
     if blkq != 128 or feature_map != "softmax":
@@ -137,12 +128,15 @@ def sparse_linear_attention_hld(q, k, vt_src, proj_w, proj_b, topk_ratio, sage, 
         assert vt.dtype == pdt and tuple(vt.shape) == (H, kb, D, 64) and not (sage and pv == "fp8")
     o_l = None
     if proj_w is not None:
-        # (until round 5 the linear branch's pass over K also accumulated the smooth-K mean — td_sla_linear_kv's ws_km / km —
-        # which chained the K quantiser behind that pass; the mean now comes from its own 20-us pass in EVERY schedule, so
-        # that the schedules stay bit-identical to one another)
-        if km is None and (sage or not dense):
-            km = K.seq_mean(k)
-        kv_t, ksum = K.sla_linear_kv(k, vt)
+        # the linear branch's pass over K also accumulates the smooth-K mean (k.mean(dim=-2), SLA/core.py:197): +6 us on a 68-us
+        # pass, where a pass of its own costs 20 (td_seq_mean) and column sums riding on k's norm + RoPE pass cost 23 — and the K
+        # quantiser that waits for it is not on the critical path (norm + RoPE of k -> this pass -> pass 2 -> attention is);
+        # round 5 tried both and a three-branch schedule around them: measured, no gain over this form
+        # (profiles/r05_vs_r04_same_box_*.txt, profiles/NOTES_r05.md)
+        if km is None:
+            kv_t, ksum, km = K.sla_linear_kv(k, vt, want_kmean=True)
+        else:
+            kv_t, ksum = K.sla_linear_kv(k, vt)
         o_l = K.sla_linear_out_t(q, kv_t, ksum, proj_w, proj_b)
     elif km is None and (sage or not dense):
         km = K.seq_mean(k)
@@ -200,8 +194,7 @@ def _sagesla_two_streams(q_fn, k, vt, proj_w, proj_b, topk, kb, out, o_stride_h,
         pq, q_i8, q_s = K.sage_quant_pool(q, None, blkq, want_pool=True)
         e_pq = torch.cuda.Event()
         e_pq.record(side)
-    km = K.seq_mean(k)
-    kv_t, ksum = K.sla_linear_kv(k, vt)
+    kv_t, ksum, km = K.sla_linear_kv(k, vt, want_kmean=True)
     e_kv = torch.cuda.Event()
     e_kv.record(main)
     with torch.cuda.stream(side):
@@ -209,58 +202,6 @@ def _sagesla_two_streams(q_fn, k, vt, proj_w, proj_b, topk, kb, out, o_stride_h,
         o_l = K.sla_linear_out_t(q, kv_t, ksum, proj_w, proj_b)
         e_ol = torch.cuda.Event()
         e_ol.record(side)
-    pk, k_i8, k_s = K.sage_quant_pool(k, km, blkk, want_pool=True)
-    main.wait_event(e_pq)
-    lut = K.sla_topk(pq, pk, topk)
-    main.wait_event(e_ol)
-    res = K.attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out)
-    return res, topk, kb
-
-
-def _sagesla_three_branches(q_fn, k_fn, vt, proj_w, proj_b, topk_ratio, out, o_stride_h, o_stride_l, blkq, blkk, quant_out,
-                            side, side2):
-    """The SageSLA kernel sequence as THREE graph branches (round 5).  What stood between the q|k|v GEMM and the attention
-    kernel on one GPU was a chain of 295 us per layer (10 % of it: profiles/r05_timeline_n1.txt): norm + RoPE of k, then of q
-    (queued behind it), the linear branch's pass over K — which also produced the smooth-K mean, so the K quantiser waited
-    for it — its finaliser, the K quantiser, the block map beside the linear branch's second pass, and only then attention.
-    The dependencies allow:
-
-        current stream   k = k_fn()  ->  km = seq_mean(k)  ->  Sage quant / pool of k  ->  block map  ->  attention
-        side             q = q_fn()  ->  Sage quant / pool of q  (-> block map)  ...  pass 2 of the linear branch (-> o_l -> attention)
-        side2                            pass 1 of the linear branch over k, V^T   (-> pass 2)
-
-    Same kernels, same arguments as the one- and two-stream forms: bit-identical.  Allocation safety without record_stream as
-    in ``_sagesla_two_streams``: a side stream's tensors are consumed before this function's last kernel on the current
-    stream, and the side streams start their next work only behind an event of the current stream recorded after it."""
-    main = torch.cuda.current_stream()
-    e_fork = torch.cuda.Event()
-    e_fork.record(main)                      # the q|k|v projection (and its V^T tiles) is complete
-    side.wait_event(e_fork)
-    with torch.cuda.stream(side):
-        q = q_fn()
-        pq, q_i8, q_s = K.sage_quant_pool(q, None, blkq, want_pool=True)
-        e_pq = torch.cuda.Event()
-        e_pq.record(side)
-    k = k_fn()
-    H, L_, D = k.shape
-    kb = K.cdiv(L_, blkk)
-    topk = min(kb, int(topk_ratio * kb))
-    if topk < 1:
-        raise ValueError(f"block-sparse attention with topk ratio {topk_ratio} selects no block of {kb} "
-                         f"(L = {L_} tokens): use a longer sequence or a larger ratio")
-    e_k = torch.cuda.Event()
-    e_k.record(main)
-    side2.wait_event(e_k)
-    with torch.cuda.stream(side2):
-        kv_t, ksum = K.sla_linear_kv(k, vt)
-        e_kv = torch.cuda.Event()
-        e_kv.record(side2)
-    with torch.cuda.stream(side):
-        side.wait_event(e_kv)
-        o_l = K.sla_linear_out_t(q, kv_t, ksum, proj_w, proj_b)
-        e_ol = torch.cuda.Event()
-        e_ol.record(side)
-    km = K.seq_mean(k)
     pk, k_i8, k_s = K.sage_quant_pool(k, km, blkk, want_pool=True)
     main.wait_event(e_pq)
     lut = K.sla_topk(pq, pk, topk)

@@ -186,7 +186,6 @@ class WanModel(nn.Module):
         self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
         self.fuse_vt = True         # self-attention V leaves the q|k|v GEMM as the attention kernel's V^T tiles (K.gemm_w8a8_vt)
         self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
-        self.three_branches = True  # ... and the linear branch's pass over K on a third (round 5: sla._sagesla_three_branches)
         self.split_tokens = True    # everything after self-attention is token-local: two token halves on two streams (_block)
         self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
@@ -464,11 +463,8 @@ class WanModel(nn.Module):
             q, k = K.qk_norm_rope_pair(qkv, 0, dim, H, D, sa.norm_q.weight, sa.norm_k.weight, cos, sin, self.eps)
             out = dtype if quant_out else torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
             return self.seq_parallel.self_attention(self, f, q, k, qkv, out, quant_out=quant_out)
-        def k_fn():
-            return K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
-        three = two and self.three_branches
         q = None if two else q_fn()
-        k = None if three else k_fn()
+        k = K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps)
         out = dtype if quant_out else torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
         dense = at in ("original", "sage")
         # W8A8: the attention kernel's epilogue hands the o projection its INT8 activation directly
@@ -476,15 +472,14 @@ class WanModel(nn.Module):
                                                 f.get("proj_b") if not dense else None, self.sla_topk, sage, out, D, dim,
                                                 (D, 3 * dim), dense=dense, quant_out=quant_out,
                                                 pv=self.sage_pv if sage else "fp16", vt=vt,
-                                                side=self._side() if two else None, q_fn=q_fn if two else None,
-                                                side2=self._side(1) if three else None, k_fn=k_fn if three else None)
+                                                side=self._side() if two else None, q_fn=q_fn if two else None)
         return res
 
-    def _side(self, idx=0):
-        """The second (idx 0) / third (idx 1) HIP stream of the self-attention schedules: one per (device, calling stream, idx),
-        so that two host threads driving this model on two streams never share one (the allocation-safety argument of
-        sla._sagesla_two_streams / _sagesla_three_branches is per set of streams)."""
-        key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, idx)
+    def _side(self):
+        """The second HIP stream of the two-stream self-attention schedule: one per (device, calling stream), so that two
+        host threads driving this model on two streams never share one (the allocation-safety argument of
+        sla._sagesla_two_streams is per pair of streams)."""
+        key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
         st = self._side_streams.get(key)
         if st is None:
             if len(self._side_streams) >= 16:
