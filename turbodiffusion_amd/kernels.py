@@ -396,19 +396,25 @@ def gemm_w8a8_stats(a_q, a_s, b_q, b_s, bias, x=None, gate=None, out_dtype=torch
     return tgt, ws
 
 
-def gemm_w8a8_vt(a_q, a_s, b_q, b_s, bias, v_col0, vt_dtype, out_dtype=torch.bfloat16):
+def gemm_w8a8_vt(a_q, a_s, b_q, b_s, bias, v_col0, vt_dtype, out_dtype=torch.bfloat16, out=None):
     """Fused q|k|v projection: -> (d [m, n] whose columns >= v_col0 are NOT written, vt [heads, ceil(m/64), 128, 64] = the
-    V^T tiles ``v_transpose`` would make of those columns)."""
+    V^T tiles ``v_transpose`` would make of those columns).  ``out``: d as a column range of a wider row-major buffer."""
     require_gpu(a_q, a_s, b_q, b_s, bias)
     m, k = a_q.shape
     n = b_q.shape[0]
     assert b_q.shape[1] == k and a_q.is_contiguous() and b_q.is_contiguous() and bias.dtype == out_dtype
+    assert bias.shape == (n,) and bias.is_contiguous() and a_s.is_contiguous() and b_s.is_contiguous()
+    assert a_s.shape == (cdiv(m, 128), k // 128) and b_s.shape == (cdiv(n, 128), k // 128), "scale shapes"
     a_s, b_s = _f32c(a_s, "a_s"), _f32c(b_s, "b_s")
-    d = torch.empty((m, n), dtype=out_dtype, device=a_q.device)
+    if out is None:
+        d = torch.empty((m, n), dtype=out_dtype, device=a_q.device)
+    else:
+        d = out
+        assert d.shape == (m, n) and d.stride(1) == 1 and d.dtype == out_dtype and d.stride(0) % 8 == 0 and d.data_ptr() % 16 == 0
     vt = torch.empty(((n - v_col0) // 128, cdiv(m, 64), 128, 64), dtype=vt_dtype, device=a_q.device)
     _timed("td_gemm_w8a8", (m, n, k), lambda: call(
-        "td_gemm_w8a8_vt", ptr(a_q), ptr(a_s), ptr(b_q), ptr(b_s), ptr(bias), ptr(d), dt_code(out_dtype), m, n, k, n, v_col0,
-        ptr(vt), dt_code(vt_dtype), stream_ptr()))
+        "td_gemm_w8a8_vt", ptr(a_q), ptr(a_s), ptr(b_q), ptr(b_s), ptr(bias), ptr(d), dt_code(out_dtype), m, n, k, d.stride(0),
+        v_col0, ptr(vt), dt_code(vt_dtype), stream_ptr()))
     return d, vt
 
 

@@ -210,6 +210,57 @@ def _sagesla_two_streams(q_fn, k, vt, proj_w, proj_b, topk, kb, out, o_stride_h,
     return res, topk, kb
 
 
+def sagesla_split_projection(kv_proj, k_fn, q_proj, q_fn, proj_w, proj_b, L_, topk_ratio, out, o_stride_h, o_stride_l, quant_out,
+                             side, blkq=128, blkk=64):
+    """SageSLA self-attention of a block whose q|k|v projection is launched as TWO GEMMs — K|V first, Q second — so that the
+    K-side chain (norm + RoPE of k, the linear branch's pass over K and V^T with the smooth-K mean, the K quantiser) runs on
+    ``side`` UNDER the Q projection instead of after the whole projection (round 5; the chain norm(k) -> linear pass 1 ->
+    linear pass 2 in front of the attention kernel was ~270 us of a 2.9-ms block at C1 with nothing beside it but other
+    bandwidth-bound passes).  Same kernels on the same data as ``_sagesla_two_streams``: bit-identical.  Measured gain is
+    small — +0.7 % on a quiet box, nothing on a noisy one (profiles/r05_split_qkv_ab.txt, r05_split_variants.txt): the Q GEMM
+    beside the chain takes 183 us instead of 96 (it is issue-bound; the chain's waves take issue slots on the same SIMDs) and
+    the chain 190 instead of 110 (profiles/r05_timeline_n1_split.txt).  Two other orders (Q first with the Q-side chain under
+    K|V; only norm / mean / quantiser under the Q GEMM) measured the same to the noise.
+
+    kv_proj() -> vt (and k's source columns written), on the calling stream;  k_fn() -> k [H, L, D] (side);
+    q_proj() writes q's source columns (calling stream);  q_fn() -> q [H, L, D] (calling stream).
+
+    Allocation safety without record_stream, as in ``_sagesla_two_streams``: every tensor made on ``side`` is last read by a
+    kernel of the calling stream that is enqueued before this function returns (the attention kernel, behind e_kv / e_lut), and
+    ``side`` starts its next work only behind the NEXT call's fork event, recorded on the calling stream after that kernel;
+    tensors of the calling stream read on ``side`` (vt, q, the projection buffer) are read before e_kv / e_lut are recorded."""
+    kb = K.cdiv(L_, blkk)
+    topk = min(kb, int(topk_ratio * kb))
+    if topk < 1:
+        raise ValueError(f"topk ratio {topk_ratio} keeps no key block out of {kb}")
+    main = torch.cuda.current_stream()
+    vt = kv_proj()
+    e_fork = torch.cuda.Event()
+    e_fork.record(main)
+    side.wait_event(e_fork)
+    with torch.cuda.stream(side):
+        k = k_fn()
+        kv_t, ksum, km = K.sla_linear_kv(k, vt, want_kmean=True)
+        e_kv = torch.cuda.Event()
+        e_kv.record(side)
+        pk, k_i8, k_s = K.sage_quant_pool(k, km, blkk, want_pool=True)
+    q_proj()
+    q = q_fn()
+    e_q = torch.cuda.Event()
+    e_q.record(main)
+    with torch.cuda.stream(side):
+        side.wait_event(e_q)
+        pq, q_i8, q_s = K.sage_quant_pool(q, None, blkq, want_pool=True)
+        lut = K.sla_topk(pq, pk, topk)
+        e_lut = torch.cuda.Event()
+        e_lut.record(side)
+    main.wait_event(e_kv)
+    o_l = K.sla_linear_out_t(q, kv_t, ksum, proj_w, proj_b)
+    main.wait_event(e_lut)
+    res = K.attn_i8(q_i8, q_s, k_i8, k_s, vt, lut, out, o_stride_h, o_stride_l, add_t=o_l, quant_out=quant_out)
+    return res, topk, kb
+
+
 class _SLABase(nn.Module):
     def __init__(self, head_dim, topk, feature_map, use_bf16, tie_feature_map_qk):
         super().__init__()

@@ -30,7 +30,7 @@ import torch.nn as nn
 
 from . import kernels as K
 from .ops import FastLayerNorm, FastRMSNorm, Int8Linear
-from .sla import SageSparseLinearAttention, SparseLinearAttention, sparse_linear_attention_hld
+from .sla import SageSparseLinearAttention, SparseLinearAttention, sagesla_split_projection, sparse_linear_attention_hld
 
 ATTENTION_TYPES = ("original", "sage", "sla", "sagesla")
 
@@ -186,6 +186,7 @@ class WanModel(nn.Module):
         self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
         self.fuse_vt = True         # self-attention V leaves the q|k|v GEMM as the attention kernel's V^T tiles (K.gemm_w8a8_vt)
         self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
+        self.split_qkv = True       # ... and the q|k|v projection as K|V then Q, the K-side chain under the Q GEMM (round 5)
         self.split_tokens = True    # everything after self-attention is token-local: two token halves on two streams (_block)
         self._side_streams = {}
         self.sage_pv = "fp16"      # "fp8": SageAttention's FP8-PV variant for self-attention (the reference's sm89+ branch)
@@ -440,8 +441,27 @@ class WanModel(nn.Module):
         at = self.attention_type
         sage = at in ("sage", "sagesla")
         vt = None
-        if (isinstance(h, tuple) and self.fuse_vt and self.seq_parallel is None and dim % 256 == 0 and f["qkv_b"] is not None
-                and not (sage and self.sage_pv == "fp8")):
+        fuse_vt = (isinstance(h, tuple) and self.fuse_vt and self.seq_parallel is None and dim % 256 == 0
+                   and f["qkv_b"] is not None and not (sage and self.sage_pv == "fp8"))
+        if (fuse_vt and self.split_qkv and self.two_streams and at == "sagesla" and self.sage_pv == "fp16"
+                and f.get("proj_w") is not None and H * D == dim):
+            # the projection as two launches, K|V then Q, with the K-side chain of the attention glue under the second
+            qkv = torch.empty((L_loc, 3 * dim), dtype=dtype, device=h[0].device)
+            nb = dim // 128
+
+            def kv_proj():
+                return K.gemm_w8a8_vt(h[0], h[1], f["qkv_w"][dim:], f["qkv_s"][nb:], f["qkv_b"][dim:], dim, torch.float16,
+                                      out_dtype=dtype, out=qkv[:, dim:])[1]
+
+            def q_proj():
+                K.gemm_w8a8(h[0], h[1], f["qkv_w"][:dim], f["qkv_s"][:nb], dtype, bias=f["qkv_b"][:dim], out=qkv[:, :dim])
+            out = dtype if quant_out else torch.empty((L_loc, dim), dtype=dtype, device=qkv.device)
+            res, _, _ = sagesla_split_projection(
+                kv_proj, lambda: K.qk_norm_rope(qkv, dim, H, D, sa.norm_k.weight, cos, sin, self.eps), q_proj,
+                lambda: K.qk_norm_rope(qkv, 0, H, D, sa.norm_q.weight, cos, sin, self.eps), f["proj_w"], f["proj_b"], L_loc,
+                self.sla_topk, out, D, dim, quant_out, self._side())
+            return res
+        if fuse_vt:
             # the V third of the projection leaves the GEMM as the attention kernel's V^T tiles (no v_transpose pass;
             # qkv's V columns are not written)
             qkv, vt = K.gemm_w8a8_vt(h[0], h[1], f["qkv_w"], f["qkv_s"], f["qkv_b"], 2 * dim,
