@@ -58,3 +58,10 @@ done
 timeout 600 python bench.py --config C5 --steps 2 --warmup 1 --no-cpu-baseline --no-box-calibration 2>/dev/null | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.readline()); print('C5 N=1 on this box: %.1f ms per DiT step' % r['dit_step_ms'])" | tee -a $OUT
 timeout 600 python bench.py --emulate-rank 0/8 --config C5 --steps 2 --warmup 1 --no-cpu-baseline --no-box-calibration > gpurun_out/emu_c5_0_8_$T.log 2>&1
 grep '^{' gpurun_out/emu_c5_0_8_$T.log | python -c "import sys,json; r=json.loads(sys.stdin.readline()); e=r['emulated_rank']; w=e['modelled_wire_ms_per_dit_step']; print('C5 N=8 groups %d parallel %s: compute %.1f ms (emulated transfers alone: %.1f), wire exposed %.1f (model), sum %.1f' % (e['head_groups'], e['branches_in_parallel'], r['dit_step_ms'], e['of_which_emulation_gather_copies_ms'], w['first_head_group_exposed'], r['dit_step_ms'] + w['first_head_group_exposed']))" | tee -a $OUT
+# the block's six GEMMs at the row counts of a sequence shard: 256-row tiles / 128-row tiles / the 128x128 kernel / the shipped plan
+timeout 300 python tools/gemm_small_m.py --M 4096,8192,16384 > gpurun_out/gemm_small_m_$T.jsonl 2> gpurun_out/gemm_small_m_$T.err; tail -3 gpurun_out/gemm_small_m_$T.jsonl | cut -c1-200
+# N = 1 beside the round-4 tree (a git worktree of the round-4 commit with its own build, when present) on THIS box
+if [ -d .r04tree ]; then
+  one() { d=$1; shift; (cd $d && timeout 600 python bench.py "$@" --no-cpu-baseline --no-box-calibration 2>/dev/null | grep '^{' | python -c "import sys,json; r=json.loads(sys.stdin.readline()); print(round(r['value'],4), 'videos/s', round(r['dit_step_ms'],2), 'ms per DiT step')"); }
+  for i in 1 2 3; do echo "N=1 round 5: $(one $R --steps 6 --warmup 1)"; echo "N=1 round 4: $(one $R/.r04tree --steps 6 --warmup 1)"; done | tee gpurun_out/vs_r04_$T.txt
+fi
