@@ -228,7 +228,7 @@ def collect_traffic(argv_model):
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "b", "--output-format", "csv", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--num-steps", "1", "--no-graph", "--no-cpu-baseline",
                    "--no-box-calibration"] + argv_model
-            env = dict(os.environ, TD_BENCH_MODEL_FLAGS="split_tokens=0", TMPDIR="/tmp")
+            env = dict(os.environ, TD_BENCH_MODEL_FLAGS="split_tokens=0,split_qkv=0", TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
             csvs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
             if r.returncode != 0 or not csvs:
@@ -643,9 +643,12 @@ def main():
         # video of the SAME workload enqueued eagerly right after the timed region (same kernels, same stream)
         # ... with the token-half split of the block tails OFF for that video: with it two GEMMs share the chip most of the
         # time and a launch's event-to-event duration would be that of two kernels; the roofline wants one kernel's own time
-        saved_split = [(m_, m_.split_tokens) for m_ in filter(None, (net, net_low))]
-        for m_, _v in saved_split:
+        # (round 5: the same for the two-launch q|k|v projection, whose Q GEMM runs beside the K-side glue chain on purpose:
+        # for this video the projection is ONE launch with nothing beside it)
+        saved_split = [(m_, m_.split_tokens, m_.split_qkv) for m_ in filter(None, (net, net_low))]
+        for m_, _v, _q in saved_split:
             m_.split_tokens = False
+            m_.split_qkv = False
         K.set_timer(timer)
         sync()
         t1 = time.perf_counter()
@@ -653,8 +656,9 @@ def main():
         sync()
         eager_elapsed = time.perf_counter() - t1
         K.set_timer(None)
-        for m_, v_ in saved_split:
+        for m_, v_, q_ in saved_split:
             m_.split_tokens = v_
+            m_.split_qkv = q_
         phase(f"eager video with per-kernel events done ({eager_elapsed:.2f} s)")
     # ---- serving-style extra (N = 1): two independent videos in flight (two graph replays on two streams); the GPU
     #      fills one video's bubbles (GEMM prologues / store phases, barrier waits) with the other's kernels
@@ -959,7 +963,7 @@ def main():
             "roofline": roof, "roofline_attention": roof_attn, **({"roofline_gemm16": roof16} if roof16 is not None else {}),
             "launch_mode": (("hipGraph replay, one graph per DiT forward" if sp == 1 else
                              "hipGraph replay in segments, the all-gathers issued eagerly between them") +
-                            "; kernel events from one eager video (full-size launches, token-half split off) after the timed region"
+                            "; kernel events from one eager video (full-size launches: token-half split off, q|k|v projection as one launch) after the timed region"
                             if use_graph else "eager enqueue; kernel events inside the timed region"),
         }
         if use_graph and getattr(run_net, "sp_graph_mode", None):

@@ -26,7 +26,7 @@ for pass in "sq1:SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_A
 done
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   name=${pass%%:*}; ctrs=${pass#*:}
-  (cd /tmp && TD_BENCH_MODEL_FLAGS=split_tokens=0 timeout 900 rocprofv3 --pmc $ctrs --kernel-trace -d $R/gpurun_out/pmcb_${T}_$name -o b --output-format csv -- $B > $R/gpurun_out/pmcb_${T}_$name.log 2>&1)
+  (cd /tmp && TD_BENCH_MODEL_FLAGS=split_tokens=0,split_qkv=0 timeout 900 rocprofv3 --pmc $ctrs --kernel-trace -d $R/gpurun_out/pmcb_${T}_$name -o b --output-format csv -- $B > $R/gpurun_out/pmcb_${T}_$name.log 2>&1)
   echo "pmc $name exit $?"
 done
 python tools/pmc_sq.py gpurun_out/pmc_sq_$T.json $csvs | tail -14 | cut -c1-200
