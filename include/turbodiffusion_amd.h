@@ -412,14 +412,14 @@ int td_attn_16_sp(const void* q, const void* k, const void* vt, const int32_t* l
  *  td_seq_sum            per-head column sums of k [H, L, 128] -> out f32 [H, 128]: td_seq_sum_partial's 64 row chunks per head + a
  *                        128-thread pass per head that adds the chunk partials in order (two launches; a one-launch form with an
  *                        atomic ticket cost 10x more: a device-scope fence per workgroup flushes the XCD's L2 — csrc/sla_prep.hip).
- *                        ws f32 [H, 64, 128] scratch; `tickets` is unused (kept in the v4 signature).
+ *                        ws f32 [H, 64, 128] scratch.
  *  td_qk_norm_rope_pair  td_qk_norm_rope for the q AND the k columns of a fused projection in one launch (bit-identical).
  *  td_sage_quant_pool_packed_kmsum
  *                        td_sage_quant_pool_packed with the smooth-K mean either given (km) or formed in the kernel from km_n (<= 8)
  *                        per-rank column sums (km_parts: the gathered td_seq_sum outputs, km_stride floats apart) over km_rows
  *                        global rows — the arithmetic of td_seq_mean_final, without its launch — and a head layout of its own
  *                        (pool_hg, pool_gs_bytes; hg = 0: flat) for `pooled`. */
-int td_seq_sum(const void* k, float* ws, float* out, unsigned int* tickets, int dtype, int64_t L, int H, int D, td_stream_t stream);
+int td_seq_sum(const void* k, float* ws, float* out, int dtype, int64_t L, int H, int D, td_stream_t stream);
 int td_qk_norm_rope_pair(const void* src_q, const void* src_k, int64_t ld_src, const float* w_q, const float* w_k,
                          const float* cosv, const float* sinv, void* dst_q, void* dst_k, int dtype, float eps, int64_t L, int H,
                          int D, td_stream_t stream);

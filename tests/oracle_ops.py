@@ -27,7 +27,7 @@ def seq_sum_partial(k, out=None):
     return ws
 
 
-def seq_sum(k, tickets=None, out=None):
+def seq_sum(k, out=None):
     """kernels.seq_sum: this rank's per-head column sums f32 [H, D] (chunk partials added in order)."""
     ws = seq_sum_partial(k)
     s = torch.zeros(k.shape[0], k.shape[2])

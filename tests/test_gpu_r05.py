@@ -33,9 +33,9 @@ def test_seq_sum_is_the_partials_summed_in_order(K, H, L):
     want = torch.zeros(H, 128, device=DEV)
     for c in range(64):
         want = want + ws[:, c]
-    assert torch.equal(K.seq_sum(k, None), want)
+    assert torch.equal(K.seq_sum(k), want)
     buf = torch.full((H * 128 + 77,), -1.0, device=DEV)
-    got = K.seq_sum(k, None, out=buf[:H * 128].view(H, 128))
+    got = K.seq_sum(k, out=buf[:H * 128].view(H, 128))
     assert torch.equal(got, want) and bool((buf[H * 128:] == -1.0).all())
 
 
@@ -65,7 +65,7 @@ def test_pack_with_in_kernel_smooth_k_mean_is_the_finalised_mean(K, W, H, per, L
     v = torch.randn(Lloc, H, 128, generator=g).bfloat16().to(DEV)
     L_tot = (W - 1) * per + Lloc
     allp = (torch.randn(W, H, 128, generator=g) * 30).to(DEV)
-    allp[W - 1] = K.seq_sum(k, None)
+    allp[W - 1] = K.seq_sum(k)
     km = K.seq_mean_final(allp, W, 128, H * 128, L_tot, H, 128, torch.bfloat16)
     lay = PackLayout(H, per, 128, 2, sage, dense, torch.bfloat16)
     lins = [(torch.empty((H, 128, 128), device=DEV), torch.empty((H, 128), device=DEV)) for _ in range(2)]

@@ -69,7 +69,7 @@ SIGNATURES = {
                       _vp, _vp, _vp, _i32, _vp],
     "td_attn_16_sp": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i32, _i32, _i64, _i64, _vp, _vp, _vp,
                       _i32, _vp],
-    "td_seq_sum": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
+    "td_seq_sum": [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp],
     "td_qk_norm_rope_pair": [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _i64, _i32, _i32, _vp],
     "td_sage_quant_pool_packed_kmsum": [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _vp, _i32, _i64, _vp, _vp, _i64, _i64, _i32, _i64,
                                         _i32, _i32, _vp],

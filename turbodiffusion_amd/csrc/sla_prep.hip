@@ -166,9 +166,7 @@ __global__ __launch_bounds__(128) void seq_sum_final_kernel(const float* __restr
 template <int DT>
 __global__ __launch_bounds__(256) void seq_mean_partial_kernel(const uint16_t* __restrict__ k, float* __restrict__ ws, int64_t L);
 
-extern "C" int td_seq_sum(const void* k, float* ws, float* out, unsigned int* tickets, int dtype, int64_t L, int H, int D,
-                          td_stream_t stream) {
-  (void)tickets;   // (ABI v4 keeps the argument of the one-launch form; unused)
+extern "C" int td_seq_sum(const void* k, float* ws, float* out, int dtype, int64_t L, int H, int D, td_stream_t stream) {
   TD_REQUIRE(k && ws && out, TD_ERR_INVALID, "td_seq_sum: null pointer");
   TD_REQUIRE(D == 128, TD_ERR_UNSUPPORTED, "td_seq_sum: D=%d (need 128)", D);
   TD_REQUIRE(dtype == TD_F16 || dtype == TD_BF16, TD_ERR_UNSUPPORTED, "td_seq_sum: dtype %d", dtype);

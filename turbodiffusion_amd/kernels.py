@@ -509,9 +509,9 @@ def qk_norm_rope_pair(src, col_q, col_k, H, D, wq, wk, cos, sin, eps):
     return both[0], both[1]
 
 
-def seq_sum(k, tickets, out=None):
+def seq_sum(k, out=None):
     """k [H, L, D] -> f32 [H, D] column sums over this tensor's rows (td_seq_sum: 64 chunk partials per head + a pass that adds
-    them in order: two launches, no library reduction, no copy).  tickets: unused (None).  out: a contiguous f32 [H, D]
+    them in order: two launches, no library reduction, no copy).  out: a contiguous f32 [H, D]
     destination (e.g. a slice of a send buffer)."""
     require_gpu(k, out)
     assert k.is_contiguous()
@@ -520,7 +520,7 @@ def seq_sum(k, tickets, out=None):
     if out is None:
         out = torch.empty((H, D), dtype=torch.float32, device=k.device)
     assert out.dtype == torch.float32 and tuple(out.shape) == (H, D) and out.is_contiguous()
-    call("td_seq_sum", ptr(k), ptr(ws), ptr(out), ptr(tickets), dt_code(k.dtype), L_, H, D, stream_ptr())
+    call("td_seq_sum", ptr(k), ptr(ws), ptr(out), dt_code(k.dtype), L_, H, D, stream_ptr())
     return out
 
 

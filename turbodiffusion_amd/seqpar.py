@@ -393,7 +393,7 @@ class SeqParallel:
         early = torch.empty((lay.early_sum + lay.early_lin,), dtype=torch.float32, device=dev)
         allp = km_work = alll = lin_work = None
         if sage or not dense:
-            part = ops.seq_sum(k, None, out=early[:lay.early_sum].view(H, D))
+            part = ops.seq_sum(k, out=early[:lay.early_sum].view(H, D))
             allp, km_work = self.all_gather(part, async_op=True)                # [W, H, D]
         lin_ks = early[lay.early_sum:lay.early_sum + H * D].view(H, D) if linear else None
         lin_kv = early[lay.early_sum + H * D:].view(H, D, D) if linear else None
