@@ -262,7 +262,7 @@ def test_four_sampler_steps_at_the_real_size_against_the_oracle(capsys):
 
 def test_two_blocks_at_c4_size_all_heads_against_the_oracle(capsys):
     """C4 / C5's size: dim 5120, 40 heads, ffn 13 824 at L = 75 600 tokens (720p), two blocks, all heads, top-k 0.1: tokens after the
-    second block (every 32nd row + the 80-row tail block) vs the oracle (tests/golden/r05_c4two.pt)."""
+    second block (every 128th row + the 80-row tail block) vs the oracle (tests/golden/r05_c4two.pt)."""
     from oracle import make_golden_r04 as R4
     from oracle import make_golden_r05 as R5
     from turbodiffusion_amd.wan import WanModel
