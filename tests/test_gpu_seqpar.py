@@ -63,6 +63,62 @@ def test_seqpar_world2_on_gpu_matches_single_rank(attention):
     assert ret["rel"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
 
 
+def _full_length_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.pop("TD_SP_HEAD_GROUPS", None)     # the shipped group rule
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import make_golden_r04 as R4
+        from oracle import make_golden_r05 as R5
+        from turbodiffusion_amd import seqpar
+        from turbodiffusion_amd.wan import WanModel
+        cfg = dict(R4.CFG13, num_layers=2)
+        with torch.device("cuda"):
+            net = WanModel(attention_type="sagesla", sla_topk=0.1, quant_linear=True, **cfg)
+        sd = R4.hash_globals(cfg, device="cuda")
+        for i in range(cfg["num_layers"]):
+            sd.update(R4.hash_layer(cfg, i, device="cuda"))
+        net.load_from_float_state_dict(sd)
+        del sd
+        net.eval()
+        x, ctx = R5.c1_inputs()                     # [1, 16, 21, 60, 104]: L = 32 760 tokens
+        x, ctx = x.to("cuda").bfloat16(), ctx.to("cuda")
+        t = torch.tensor([[933.781]], device="cuda").bfloat16()
+        ref = net(x, t, ctx, _return_tokens=True)[0].clone() if rank == 0 else None
+        seqpar.enable(net, dist.group.WORLD)
+        out = net(x, t, ctx, _return_tokens=True)[0]
+        sp = net.seq_parallel.sp
+        if rank == world - 1:
+            ret["last_rank_tokens"] = sp.stop - sp.start
+        if rank == 0:
+            ret["per"] = sp.per
+            ret["shape"] = tuple(out.shape)
+            ret["finite"] = bool(torch.isfinite(out.float()).all().item())
+            ret["rel"] = rel_l2(out, ref)
+            ret["cos"] = cosine(out, ref)
+            ret["tail"] = rel_l2(out[-120:], ref[-120:])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_seqpar_world4_at_the_real_length_matches_single_rank(capsys):
+    """The sharded layer at the size it is built for: 1.3B width, two blocks, L = 32 760 tokens over FOUR ranks (shards of 8192
+    tokens, the last one ragged: 8184), the shipped head-group rule, every HIP kernel of the gathered path (rank-major K / V^T /
+    scales / pooled K, one block map over 512 key blocks of four ranks, per-group attention with the fused quantiser) against the
+    single-rank schedule on the same weights.  Four processes share the box's one GPU and talk gloo."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_full_length_worker, args=(4, _free_port(), ret), nprocs=4, join=True)
+    with capsys.disabled():
+        print(f"\n[two blocks at L = 32 760 over 4 ranks] rel-L2 vs the single-rank forward: {ret['rel']:.4f} (tail block {ret['tail']:.4f}, "
+              f"cosine {ret['cos']:.5f}); shards of {ret['per']} tokens, the last rank owns {ret['last_rank_tokens']}")
+    assert ret["finite"] and ret["shape"] == (32760, 1536) and ret["per"] == 8192 and ret["last_rank_tokens"] == 8184, dict(ret)
+    # per-rank quantisation blocks and per-rank partial sums of the global reductions: same arithmetic class, stated tolerance
+    assert ret["rel"] < 2e-2 and ret["tail"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
+
+
 def _graph_worker(rank, world, port, attention, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -20,7 +20,8 @@ def rel_l2(a, b):
 
 
 def cosine(a, b):
-    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    # fp64: an fp32 dot / norm over the 5e7 elements of a full-size token tensor is good to two digits only
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
     return (a @ b / (a.norm() * b.norm()).clamp_min(1e-20)).item()
 
 
