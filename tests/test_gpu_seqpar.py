@@ -63,6 +63,50 @@ def test_seqpar_world2_on_gpu_matches_single_rank(attention):
     assert ret["rel"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
 
 
+def _i2v_worker(rank, world, port, clip, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["TD_SP_HEAD_GROUPS"] = "2"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import wan_ref as W
+        from tests.test_gpu_wan import make_net
+        from turbodiffusion_amd import seqpar
+        gold = torch.load(GOLD, weights_only=False)
+        cfg = dict(gold["cfg"], in_dim=36, model_type="i2v", **({"clip_dim": 1280} if clip else {}))
+        net = make_net(cfg, W.make_state_dict(cfg, 7), "sagesla", True, topk=0.5)
+        g = torch.Generator().manual_seed(23)
+        x = torch.randn(1, 16, 5, 16, 24, generator=g).to("cuda").bfloat16()     # 480 tokens: shards of 256 and 224
+        y = torch.randn(1, 20, 5, 16, 24, generator=g).to("cuda").bfloat16()     # conditioning channels (mask + latent)
+        kw = dict(y_B_C_T_H_W=y)
+        if clip:
+            kw["frame_cond_crossattn_emb_B_L_D"] = (torch.randn(1, 257, 1280, generator=g) * 0.5).to("cuda").bfloat16()
+        ctx = gold["ctx"].to("cuda").bfloat16()
+        t = gold["t"].to("cuda").bfloat16()
+        ref = net(x, t, ctx, **kw) if rank == 0 else None
+        seqpar.enable(net, dist.group.WORLD)
+        out = net(x, t, ctx, **kw)
+        if rank == 0:
+            ret["rel"], ret["cos"] = rel_l2(out, ref), cosine(out, ref)
+            ret["finite"] = bool(torch.isfinite(out).all().item())
+            ret["shape_ok"] = tuple(out.shape) == tuple(ref.shape)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("clip", [False, True])
+def test_seqpar_world2_i2v_inputs_match_single_rank(clip):
+    """Image-to-video inputs through the sharded forward: the conditioning channels ``y`` (Wan2.2-A14B I2V: 16 + 20 input
+    channels; every rank's patch-embedding launch reads only its token range of x AND y) and, for Wan2.1 I2V, the CLIP image
+    tokens of the second cross-attention (token-local: nothing to exchange)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_i2v_worker, args=(2, _free_port(), clip, ret), nprocs=2, join=True)
+    assert ret["finite"] and ret["shape_ok"], dict(ret)
+    assert ret["rel"] < 2e-2 and ret["cos"] > 0.999, dict(ret)
+
+
 def _full_length_worker(rank, world, port, width, layers, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
