@@ -60,7 +60,9 @@ const char* td_last_error(void);
 /* Kernel-selection knobs for benchmarking (results never depend on them: every variant of an
  * operator is bit-identical).  value 0 = automatic. */
 #define TD_TUNE_GEMM_VARIANT 0 /* 1 = 128x128-tile kernel (default for m < 1024), 4 = 256x256 fine-interleaved on 16x16x64 MFMA (default),
-                                  5 = the same pipeline on 32x32x32 MFMA (carries the opt-in fast dequant / schedules); all exact variants are bit-identical */
+                                  5 = the same pipeline on 32x32x32 MFMA (carries the opt-in fast dequant / schedules); 6 = variant 4 on 128 x 256 tiles
+                                  (eight waves of 64 x 64), 7 = 4 or 6 by the launch planner, never mixed; 8 = the FOUR-wave form of variant 4
+                                  (round 6: 128 x 256 tile, one wave per SIMD, two independent workgroups per CU); all exact variants are bit-identical */
 #define TD_TUNE_GEMM_ABLATE 1  /* profiling instantiations only (s_memtime traces / phase stamps: 6, 9, 16, 19; tools/gemm_*.py) */
 #define TD_TUNE_GEMM_LDPAD 2   /* profiling only: int8 operand row stride = k + value (buffers must be that large) */
 #define TD_TUNE_GEMM_GROUP_M 3 /* m-tiles per raster group of the 256x256 kernels (0 = default 4) */

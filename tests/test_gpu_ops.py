@@ -459,8 +459,10 @@ def test_gemm_128_row_tile_form_is_bit_identical(K, m, n, k):
     aq, as_ = K.quant_i8_block128(a.to(DEV))
     wq, ws = K.quant_i8_block128(w.to(DEV))
     outs = {}
-    for variant in (4, 6, 0):      # 0: the automatic plan — for (4096, 8960, 1536) the MIXED one (two rounds of 256-row tiles + 128-row tiles)
-        K.set_tuning(K.TUNE_GEMM_VARIANT, variant)
+    for variant in (4, 6, 8, 0, 104, 108):      # 0: the automatic plan — for (4096, 8960, 1536) the MIXED one (two rounds of 256-row tiles + 128-row tiles)
+        # 8 (round 6): the FOUR-wave form (128 x 256 tile, two workgroups per CU); 104 / 108: forms 4 / 8 with the one-VALU dequant
+        K.set_tuning(K.TUNE_GEMM_VARIANT, variant % 100)
+        K.set_tuning(K.TUNE_GEMM_FAST, 4 if variant >= 100 else 1)
         try:
             r = {"plain": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b), "gelu": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True),
                  "nobias": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16),
@@ -481,15 +483,20 @@ def test_gemm_128_row_tile_form_is_bit_identical(K, m, n, k):
         finally:
             K.set_tuning(K.TUNE_GEMM_VARIANT, 0)
             K.set_tuning(K.TUNE_GELU_TABLE, 0)
+            K.set_tuning(K.TUNE_GEMM_FAST, 0)
         outs[variant] = r
-    for other in (6, 0):
-        for key in outs[4]:
+    for base, other in ((4, 6), (4, 8), (4, 0), (104, 108)):
+        for key in outs[base]:
             if other == 0 and key.startswith("part_"):
                 continue      # (a problem this small goes to the 128x128 kernel automatically: its partials agree to rounding, not bit for bit)
-            assert torch.equal(outs[4][key].view(torch.uint8) if outs[4][key].dtype == torch.float16 else outs[4][key],
+            assert torch.equal(outs[base][key].view(torch.uint8) if outs[base][key].dtype == torch.float16 else outs[base][key],
                                outs[other][key].view(torch.uint8) if outs[other][key].dtype == torch.float16 else outs[other][key]), (other, key)
     if "q" in outs[6]:
         assert torch.equal(outs[6]["q"], outs[6]["qi"]) and torch.equal(outs[6]["qs"], outs[6]["qsi"])
+    # the one-VALU dequant of EVERY epilogue (round 6) stays within a bf16 rounding step of the exact form
+    for key in ("plain", "gelu", "res", "res_nogate"):
+        e, f = outs[4][key].float(), outs[104][key].float()
+        assert ((e - f).norm() / e.norm()).item() < 2e-3, key
 
 
 # ---------------------------------------------------------------- small problems: the fused epilogues on the 128x128 kernel

@@ -297,6 +297,41 @@ def test_seqpar_over_rccl_one_rank(attention):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("whole", ["0", "1"])
+def test_emulated_group_replays_bit_identically_as_segments_and_as_one_graph(whole):
+    """seqpar.EmulatedGroup (bench.py --emulate-rank) under BOTH capture forms: ``TD_SP_WHOLE_GRAPH = 0`` replays hipGraph
+    segments around the eager re-issue of every emulated gather — there the copy must stay on the issuing stream (the wire
+    stream's join would be captured once, against the capture pass's event: ADVICE r05) — and ``1`` captures the wire stream's
+    fork / join as graph edges.  Replay == eager, for the captured inputs, new inputs, and the first again."""
+    from oracle import wan_ref as W
+    from tests.test_gpu_wan import make_net
+    from turbodiffusion_amd import seqpar
+    from turbodiffusion_amd.graph import GraphedModel
+    gold = torch.load(GOLD, weights_only=False)
+    cfg = gold["cfg"]
+    sd = W.make_state_dict(cfg, gold["sd_seed"])
+    net = make_net(cfg, sd, "sagesla", True, topk=0.5)
+    g = torch.Generator().manual_seed(23)
+    xs = [torch.randn(1, 16, 5, 16, 24, generator=g).to("cuda").bfloat16() for _ in range(2)]
+    ctx = gold["ctx"].to("cuda").bfloat16()
+    ts = [gold["t"].to("cuda").bfloat16(), (gold["t"] * 0.5).to("cuda").bfloat16()]
+    seqpar.enable(net, seqpar.EmulatedGroup(0, 2))
+    try:
+        eager = [net(x, t, ctx).clone() for x, t in zip(xs, ts)]
+        gm = GraphedModel(net)
+        gm._whole_graph_env = whole
+        outs = [gm(x, t, ctx).clone() for x, t in zip(xs, ts)]
+        outs.append(gm(xs[0], ts[0], ctx).clone())
+        torch.cuda.synchronize()
+        first = next(iter(gm._graphs.values()))[0]
+        assert isinstance(first, torch.cuda.CUDAGraph) == (whole == "1"), (type(first), gm.sp_capture_error, gm.sp_whole_graph_error)
+        assert torch.equal(outs[0], eager[0]) and torch.equal(outs[1], eager[1]) and torch.equal(outs[2], eager[0])
+        assert not torch.equal(eager[0], eager[1])
+    finally:
+        seqpar.disable(net)
+
+
+@pytest.mark.gpu
 def test_capture_after_eager_collectives_survives_the_rccl_watchdog():
     """graph.quiesce_collective_watchdog: an eager RCCL collective that completed just before a capture with collectives
     inside stays on ProcessGroupNCCL's watchdog list; the capture pulls the communicator stream into capture mode and the

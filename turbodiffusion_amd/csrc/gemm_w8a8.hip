@@ -307,7 +307,7 @@ static int launch_gemm(const int8_t* a, const float* a_s, const int8_t* b, const
 // Problems with fewer than 64 tiles of 128 x 256 go to the 128x128 kernel (two workgroups per CU).  Until round 5 this was "at
 // most 128 tiles of 256 x 256" — the per-rank GEMMs of a wide sequence split (M = 4096, N = 1536: 96 such tiles); those now
 // run on the LDS-DMA kernel's 128-row form (gemm_w8a8_fi.hip, NI = 4), which measured 0.72-0.81 of the 128x128 kernel's time on
-// them (tools/gemm_small_m.py).  TD_TUNE_GEMM_VARIANT overrides (1 / 4 / 5 / 6).
+// them (tools/gemm_small_m.py).  TD_TUNE_GEMM_VARIANT overrides (1 / 4 / 5 / 6 / 7 / 8).
 static bool td_gemm_small(int64_t m, int64_t n) {
   const int v = td_tuning(TD_TUNE_GEMM_VARIANT);
   if (v == 1) return true;
@@ -343,8 +343,8 @@ extern "C" int td_gemm_w8a8(const int8_t* a, const float* a_s, const int8_t* b, 
   hipStream_t st = (hipStream_t)stream;
   const int variant = td_tuning(TD_TUNE_GEMM_VARIANT);
   // large problems: the fine-interleaved 256x256 LDS-DMA kernel (gemm_w8a8_fi.hip); every variant is bit-identical
-  if (variant == 4 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0 && !td_gemm_small(m, n))) {
-    TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variant 4 needs ldd %% 8 == 0");
+  if (variant == 4 || variant == 6 || variant == 7 || variant == 8 || (variant == 0 && m >= 1024 && n >= 256 && ldd % 8 == 0 && !td_gemm_small(m, n))) {
+    TD_REQUIRE(ldd % 8 == 0, TD_ERR_UNSUPPORTED, "td_gemm_w8a8: variants 4 / 6 / 7 / 8 need ldd %% 8 == 0");
     return td_gemm_w8a8_fi(a, a_s, b, b_s, bias, d, out_dtype, epilogue, m, n, k, ldd, st);
   }
   if (variant == 5) {  // 32x32x32-MFMA twin of variant 4 (gemm_w8a8_m32.hip)

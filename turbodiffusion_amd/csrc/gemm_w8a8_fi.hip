@@ -137,8 +137,19 @@ static const uint16_t* td_gelu_table_bf16(hipStream_t st) {
 // one barrier per K block, fragment ring, epilogues) is the same code with NI for 8.  (A four-wave form with the unchanged
 // 128 x 64 wave tile — one wave per SIMD — measured 0.75 of the per-FLOP rate: tools/gemm_small_m.py, profiles/r05_gemm_small_m.txt.)
 // Bit-identical: the arithmetic per output element does not depend on the tile it is computed in.
-template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0, int NI = 8>
-__global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
+// NW = 4 (round 6): the FOUR-wave form — one wave per SIMD, the unchanged 128 x 64 wave tile, waves side by side in N: a
+// 128(M) x 256(N) tile per 256-thread workgroup and TWO independent workgroups per CU (68 KB of LDS and 256 VGPRs each).  What
+// the eight-wave workgroup pays once per K block with nothing beside it — the barrier, the weight-fragment refill burst behind
+// it, the prologue until the first stage has landed and the epilogue's store tail — one workgroup now pays while the other
+// workgroup of the CU keeps both waves' worth of issue slots and the matrix pipe busy (the arrangement that bought the VAE
+// convolution its short reductions, csrc/vae_conv3.hip).  LDS: the activation tile (128 rows x 128 B = 16 KB, read by all four
+// waves) in two stages; the weight tile is NOT shared in this arrangement — wave w alone reads rows 64 w .. 64 w + 63 — so each
+// wave stages its own 8 KB by its own eight LDS-DMA pieces into a PRIVATE region, single-buffered: the K block's weight fragments
+// live in registers, the region is dead as soon as they are read (group 7 of the previous block) and the next block's pieces
+// are issued right behind that read with a whole K block to land; no barrier guards it.  2 x 16 + 4 x 8 = 64 KB.
+// Same slots, same fragment ring, same epilogues: bit-identical to the eight-wave form (test_gemm_four_wave_form_is_bit_identical).
+template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0, int NI = 8, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void gemm_w8a8_fi_kernel(
     const int8_t* __restrict__ A, const float* __restrict__ AS, const int8_t* __restrict__ B,
     const float* __restrict__ BS, const uint16_t* __restrict__ bias, uint16_t* __restrict__ D,
     int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldd, int tiles_m, int tiles_n, int group_m,
@@ -151,14 +162,16 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, lq = lane >> 4;
-  const int wm = wave >> 2, wn = wave & 3;
+  constexpr bool W4 = NW == 4;
+  static_assert(NW == 8 || (NW == 4 && NI == 8 && DBG == 0 && SCHED == 0), "four-wave form: 128 x 64 wave tiles, no profiling instantiations");
+  const int wm = W4 ? 0 : wave >> 2, wn = wave & 3;
   constexpr int WROWS = 16 * NI;                 // rows of a wave tile (128 | 64)
-  constexpr int F_BM = 2 * WROWS;                // tile rows
+  constexpr int F_BM = W4 ? WROWS : 2 * WROWS;   // tile rows
   constexpr int F_TILE = F_BM * 128;             // activation tile bytes per K block
-  constexpr int F_STAGE = F_TILE + 256 * 128;    // + weight tile
-  constexpr int F_LDS = 2 * F_STAGE;
-  constexpr int F_EPI = 131072;                  // epilogue scratch (bias / gate constants, amax exchange) behind 128 KB in both forms
-  constexpr int NA = NI / 2;                     // activation chunks (8 rows x 128 B) a wave moves per stage (weights: 4)
+  constexpr int F_STAGE = W4 ? F_TILE : F_TILE + 256 * 128;    // + weight tile (four-wave form: a stage is the activation tile alone)
+  constexpr int F_WBASE = W4 ? 2 * F_TILE : F_TILE;            // weight rows: behind the activation tile of a stage | the waves' private regions behind both stages
+  constexpr int F_EPI = W4 ? 65536 : 131072;     // epilogue scratch (bias / gate constants, amax exchange) behind the stage area
+  constexpr int NA = W4 ? 4 : NI / 2;            // activation chunks (8 rows x 128 B) a wave moves per stage (weights: 4 | 8)
   unsigned long long dbg_t[40];
   int dbg_n = 0;
   unsigned long long c_t0 = 0, c_t1 = 0, c_t2 = 0;
@@ -181,17 +194,27 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   const int nk = (int)(K / 128);
 
   // ---- LDS-DMA pieces: wave w moves chunks c = w + 8t (8 rows x 128 B) of both operand tiles ----
+  // four-wave form: wave w moves activation chunks c = w + 4t and ALL eight chunks of its own 64 weight rows — piece t of those
+  // = rows 8t .. 8t + 7 of the wave's region; the row step rides on the instruction's scalar offset, the source swizzle depends
+  // on t's parity only: two address registers (gb[0] even, gb[1] odd t)
   uint32_t ga[4], gb[4];     // (NI = 4: ga[0..1] used — the activation tile has 16 chunks, two per wave)
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int c = wave + 8 * t;
+    const int c = wave + NW * t;
     const int row = 8 * c + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);  // source-side swizzle (LDS image is lane-linear)
     int64_t am = m0 + (t < NA ? row : 0); if (am > M - 1) am = M - 1;   // tail rows: clamp (never stored)
     int64_t bn = n0 + row; if (bn > N - 1) bn = N - 1;
     ga[t] = (uint32_t)(am * lda + chunk * 16);
     gb[t] = (uint32_t)(bn * ldb + chunk * 16);
+    if constexpr (W4) {
+      // rows >= N (n % 8 == 0: whole pieces) are beyond the descriptor's extent: the buffer unit answers them with zeros, and
+      // nothing computed from them is ever stored
+      const int lrow = 8 * (t & 1) + (lane >> 3);                        // local row of pieces t (mod 2): 8t + (lane >> 3), t < 2
+      gb[t] = (uint32_t)((n0 + wave * 64 + lrow) * ldb + ((lane & 7) ^ ((lrow >> 1) & 7)) * 16);
+    }
   }
+  const uint32_t w4_step = (uint32_t)(8 * ldb);   // row step of a weight piece (scalar)
   const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, (int)(uint32_t)(M * lda), 0x00020000);
   const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, (int)(uint32_t)(N * ldb), 0x00020000);
   // L2 prefetch (SCHED bit 1): one buffer_load_dword per wave touches 64 cache lines (one 128-B line per lane) of a
@@ -225,13 +248,21 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
                                                16, gb[(p_) & 3], (kb_) * 128, 0, 0);              \
   }
 
+  // four-wave form: activation piece t (0..3) of stage kb_, weight piece t (0..7) of K block kb_ into the wave's private region
+#define F_PIECE_A4(kb_, t_)                                                                       \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lptr_t)(smem + ((kb_) & 1) * F_STAGE + wave * 1024 + (t_) * 4096), 16, \
+                                           ga[t_], (kb_) * 128, 0, 0);
+#define F_PIECE_B4(kb_, t_)                                                                       \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lptr_t)(smem + F_WBASE + wave * 8192 + (t_) * 1024), 16, \
+                                           gb[(t_) & 1], (kb_) * 128 + ((t_) >> 1) * 2 * w4_step, 0, 0);
+
   // ---- fragment read offsets (within a stage); weight rows use the bit-2/3-swapped order ----
   const int pr = (l16 & 3) | ((l16 & 4) << 1) | ((l16 & 8) >> 1);
   uint32_t xoff[2], woff[2];
 #pragma unroll
   for (int kc = 0; kc < 2; ++kc) {
     xoff[kc] = f_swz(wm * WROWS + l16, 4 * kc + lq);
-    woff[kc] = F_TILE + f_swz(wn * 64 + pr, 4 * kc + lq);
+    woff[kc] = W4 ? F_WBASE + wave * 8192 + f_swz(pr, 4 * kc + lq) : F_TILE + f_swz(wn * 64 + pr, 4 * kc + lq);
   }
 
   v4f accf[NI][4];
@@ -277,6 +308,29 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     asm volatile("v_add_f32 %0, %1, %0" : "+v"((acc_)[r]) : "s"(c_));
 
   // ---- prologue: stage 0 and stage 1 in flight; wait for stage 0; fragments of group (0,0) ----
+  if constexpr (W4) {
+    // block 0 (4 + 8 pieces) and the activation tile of block 1 in flight; block 1's weights follow the first fragment read
+#pragma unroll
+    for (int t = 0; t < 4; ++t) F_PIECE_A4(0, t)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) F_PIECE_B4(0, t)
+    if (nk > 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) F_PIECE_A4(1, t)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    F_BARRIER()
+    F_LOAD_W(smem, 0)
+    F_LOAD_W(smem, 1)
+    F_LOAD_X(smem, 0, 0)
+    if (nk > 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the private region has been read: block 1's weights may land in it
+#pragma unroll
+      for (int t = 0; t < 8; ++t) F_PIECE_B4(1, t)
+    }
+  } else {
 #pragma unroll
   for (int p = 0; p < 8; ++p) { if ((p & 3) < NA || p >= 4) F_PIECE(0, p) }
   if (nk > 1) {
@@ -294,6 +348,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   F_LOAD_W(smem, 0)
   F_LOAD_W(smem, 1)
   F_LOAD_X(smem, 0, 0)
+  }
 
   // block scales live in SGPRs: sc_old = K block of the group being dequantised at i == 0 (the previous
   // block's last group), sc_new = this block's.  (sa*sb) formed first, kernel.hpp:418.
@@ -321,6 +376,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
     }
     const char* st = smem + (kb & 1) * F_STAGE;
     const char* stn = smem + ((kb + 1) & 1) * F_STAGE;
+    const char* wsn = W4 ? smem : stn;          // where the NEXT block's weight fragments are read (woff carries the private region)
     const bool more = kb + 1 < nk;
     const bool dma_tail = (kb >= 1) && more;   // rest of stage kb+1 (stage 1 was issued by the prologue)
     const bool dma_head = kb + 2 < nk;         // first pieces of stage kb+2, after this block's barrier
@@ -344,10 +400,18 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         else if (recentre) { F_ADDC4(accf[pi][j], c_neg) }
       }
       F_FENCE()
-      if (i == NI - 1 && more) { F_LOAD_W(stn, 0) }
+      if (i == NI - 1 && more) { F_LOAD_W(wsn, 0) }
       // -- LDS-DMA issue (VMEM issue slots of this wave only)
       if (i == NI - 1) { F_PREFETCH(kb + 4) }
-      if constexpr (NI == 4) {
+      if constexpr (W4) {
+        // behind this block's barrier (group 7): the activation tile two blocks ahead into the stage everyone has just left;
+        // next block's groups 0-2: the rest of it and the weights of the block after — the private region was read in group 7
+        // (lgkmcnt(0): the DMA engine does not order itself against this wave's outstanding LDS reads)
+        if (i == 7) { if (dma_head) { F_PIECE_A4(kb + 2, 0) F_PIECE_A4(kb + 2, 1) } }
+        else if (i == 0) { if (dma_tail) { F_PIECE_A4(kb + 1, 2) F_PIECE_A4(kb + 1, 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); F_PIECE_B4(kb + 1, 0) F_PIECE_B4(kb + 1, 1) } }
+        else if (i == 1) { if (dma_tail) { F_PIECE_B4(kb + 1, 2) F_PIECE_B4(kb + 1, 3) F_PIECE_B4(kb + 1, 4) } }
+        else if (i == 2) { if (dma_tail) { F_PIECE_B4(kb + 1, 5) F_PIECE_B4(kb + 1, 6) F_PIECE_B4(kb + 1, 7) } }
+      } else if constexpr (NI == 4) {
         // six pieces per wave and stage (2 activation + 4 weight chunks), all of stage kb+2 right behind this block's barrier:
         // three in the last group, three in the next block's first — ~3 groups ahead of the barrier that needs them
         if (i == 3) { if (dma_head) { F_PIECE(kb + 2, 0) F_PIECE(kb + 2, 4) F_PIECE(kb + 2, 1) } }
@@ -373,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
         F_FMAC4(accf[pi][j], t[prv][j], scl)
       }
       F_FENCE()
-      if (i == NI - 1 && more) { F_LOAD_W(stn, 1) }
+      if (i == NI - 1 && more) { F_LOAD_W(wsn, 1) }
       if (i == NI - 2) {
         // every LDS read of stage kb has returned (group 7's fragment was read at the top of this group),
         // this wave's pieces of stage kb+1 have landed; after the barrier: everyone's
@@ -757,25 +821,27 @@ __global__ __launch_bounds__(512, 2) void gemm_w8a8_fi_kernel(
   }
 }
 
-// one launch over the row tiles [tm0, tm0 + tiles_m) (tiles of 32 NI rows)
-template <int ODT, int EPI, bool HAS_BIAS, int DBG, int SCHED, bool QOUT, bool RES, int FAST, bool STATS, int VT, int NI>
+// one launch over the row tiles [tm0, tm0 + tiles_m) (tiles of 32 NI rows; the four-wave form: 128 rows)
+template <int ODT, int EPI, bool HAS_BIAS, int DBG, int SCHED, bool QOUT, bool RES, int FAST, bool STATS, int VT, int NI, int NW = 8>
 static int launch_gemm_fi_range(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                                 const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                                 hipStream_t st, float* qs, int64_t ldqs, const float* gate, int tm0, int tiles_m) {
-  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT, NI>;
-  constexpr int F_LDS = 131072;    // (both forms allocate 128 KB + scratch: one workgroup per CU either way)
+  auto kern = gemm_w8a8_fi_kernel<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT, NI, NW>;
+  // eight waves: 128 KB + scratch in both tile forms (one workgroup per CU either way); four waves: 64 KB + scratch, two per CU
+  constexpr int F_LDS = NW == 4 ? 65536 : 131072;
   const uint16_t* gelu_tab = nullptr;
-  if constexpr (QOUT && EPI == TD_EPI_GELU_TANH && ODT == TD_BF16) {
+  if constexpr (QOUT && EPI == TD_EPI_GELU_TANH && ODT == TD_BF16 && NW == 8) {   // (the table takes 128 KB of LDS: eight-wave forms only)
     if (td_tuning(TD_TUNE_GELU_TABLE) != 1) gelu_tab = td_gelu_table_bf16(st);   // 1 = the inline form (cross-check / A-B)
   }
   static std::atomic<uint64_t> attr_mask{0};
   td_ensure_dyn_lds(reinterpret_cast<const void*>(kern), F_LDS + F_DUMP, attr_mask);
   const int tiles_n = (int)td_cdiv(n, F_BN);
-  const int group_m = td_tuning(TD_TUNE_GEMM_GROUP_M) > 0 ? td_tuning(TD_TUNE_GEMM_GROUP_M) : 4;
+  int group_m = td_tuning(TD_TUNE_GEMM_GROUP_M) > 0 ? td_tuning(TD_TUNE_GEMM_GROUP_M) : 4;
+  if (NW == 4 && td_tuning(TD_TUNE_GEMM_GROUP_M) <= 0) group_m = 8;   // the same 1024 rows of activations per raster group
   const unsigned nwg = (unsigned)tiles_m * (unsigned)tiles_n;
   // profiling only: row stride of both int8 operands = k + pad (the caller's buffers must be that large)
   const int64_t ldab = k + td_tuning(TD_TUNE_GEMM_LDPAD);
-  kern<<<nwg, 512, F_LDS + F_DUMP, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldab, ldab, ldd,
+  kern<<<nwg, NW * 64, F_LDS + F_DUMP, st>>>(a, a_s, b, b_s, (const uint16_t*)bias, (uint16_t*)d, m, n, k, ldab, ldab, ldd,
                                 tiles_m, tiles_n, group_m, DBG ? td_dbg_buffer() : nullptr, qs, ldqs, gate, gelu_tab, tm0);
   TD_CHECK_LAUNCH();
   return TD_OK;
@@ -789,14 +855,23 @@ static int launch_gemm_fi_range(const int8_t* a, const float* a_s, const int8_t*
 //   (c) MIXED: as many whole rounds of 256-row tiles as fit, the remaining rows on 128-row tiles in a second launch
 //       (ffn.0 of a rank of 8: 560 tiles = 2.19 rounds -> 2 rounds + 140 half tiles = 2.6 instead of 3)
 // the cheapest wins; (c) must beat the better of (a) / (b) by 5 % to pay for its second launch.  Bit-identical whatever the
-// plan.  TD_TUNE_GEMM_VARIANT = 4 forces (a), 6 forces (b), 7 allows only (a) / (b).
+// plan.  TD_TUNE_GEMM_VARIANT = 4 forces (a), 6 forces (b), 7 allows only (a) / (b), 8 forces the four-wave form (128-row tiles,
+// two workgroups per CU).
+// Round 6: the dequant mode is a run-time choice for EVERY epilogue (td_gemm_fast_g() == 4 re-dispatches the exact
+// instantiation's call to its FAST = 4 twin; bf16 + bias — the model's linears); the plans apply to both modes.
 template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0, int NI = 8>
 static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
+  if constexpr (DBG == 0 && SCHED == 0 && FAST == 0 && ODT == TD_BF16 && HAS_BIAS) {
+    if (td_gemm_fast_g() == 4)
+      return launch_gemm_fi<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 4, STATS, VT, NI>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate);
+  }
   const int tm8 = (int)td_cdiv(m, 256), tm4 = (int)td_cdiv(m, 128), tn = (int)td_cdiv(n, F_BN);
-  if constexpr (DBG == 0 && SCHED == 0 && FAST == 0) {
+  if constexpr (DBG == 0 && SCHED == 0 && (FAST == 0 || FAST == 4)) {
     int v = td_tuning(TD_TUNE_GEMM_VARIANT);
+    if (v == 8)
+      return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, FAST, STATS, VT, 8, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, tm4);
     if (v == 0 && td_tuning(TD_TUNE_GEMM_COTENANT)) v = 4;   // beside another GEMM: a launch does not own the chip, whole tiles only
     const double c = (!QOUT && !RES && !STATS) ? 0.80 : 0.60;
     auto rounds = [](int64_t tiles) { return (double)td_cdiv(tiles, 256); };
@@ -814,11 +889,11 @@ static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, co
       }
     }
     if (v == 6 || (v != 4 && pb < pa && pb <= pc * 1.05))
-      return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 0, STATS, VT, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, tm4);
+      return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, FAST, STATS, VT, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, tm4);
     if (v != 4 && v != 6 && pc * 1.05 < pa && pc * 1.05 < pb) {
-      int rc = launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 0, STATS, VT, 8>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, m1);
+      int rc = launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, FAST, STATS, VT, 8>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, m1);
       if (rc != TD_OK) return rc;
-      return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 0, STATS, VT, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 2 * m1, tm4 - 2 * m1);
+      return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, FAST, STATS, VT, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 2 * m1, tm4 - 2 * m1);
     }
   }
   return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, DBG, SCHED, QOUT, RES, FAST, STATS, VT, NI>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, tm8);

@@ -879,8 +879,11 @@ def sp_pack_finish(pack, k, km, L_loc, lay):
             allp, rows = km
             require_gpu(allp)
             assert allp.dtype == torch.float32 and allp.dim() == 3 and tuple(allp.shape[1:]) == (H, D) and allp[0].is_contiguous()
-            assert allp.shape[0] <= 8, "the in-kernel smooth-K mean sums at most 8 per-rank partials"
-            n_parts, stride = allp.shape[0], allp.stride(0)
+            if allp.shape[0] <= 8:       # the kernel forms the mean itself from up to 8 per-rank partials (one node of MI355X)
+                n_parts, stride = allp.shape[0], allp.stride(0)
+            else:                        # wider groups (two nodes and more): one td_seq_mean_final launch in rank order, as before round 5
+                kmp = seq_mean_final(allp, allp.shape[0], D, allp.stride(0), int(rows), H, D, k.dtype)
+                allp, rows = None, 0
         else:
             require_gpu(km)
             kmp = km

@@ -91,7 +91,11 @@ class _Gather:
             # the emulated transfer runs where a real one does: on a stream of its own (RCCL's communicator stream), forked
             # off the issuing stream here and joined at ``wait`` — kernels enqueued in between overlap it, as they overlap
             # the wire.  (Still CU / HBM work of THIS GPU where the fabric's DMA would do the writes: pessimistic, not free.)
-            if self.out.is_cuda and self.async_op and EMU_WIRE_STREAM:
+            # Under a SEGMENTED capture (graph.SegmentRecorder) issue() is an eager point — re-run at every replay — while the
+            # join in wait() would be recorded once, inside a captured segment, against the event of the capture pass: the next
+            # segment could read the buffers before this replay's copy finished.  There the copy stays on the issuing stream.
+            from . import graph as _graph
+            if self.out.is_cuda and self.async_op and EMU_WIRE_STREAM and _graph._ACTIVE is None:
                 main = torch.cuda.current_stream()
                 st = _emu_stream()
                 e = torch.cuda.Event()
