@@ -414,7 +414,11 @@ def main():
                     "reference's sm80 branch; north-star default) or fp8 (its sm89+ branch, SLA/core.py:217-239: e4m3 P and V, "
                     "fp8 MFMA)")
     ap.add_argument("--gemm-fast", type=int, default=0, choices=[0, 2, 4, 8], help="W8A8 GEMM one-VALU dequant, re-centred "
-                    "every G K blocks (bounded difference to the exact arithmetic, csrc/gemm_w8a8_fi.hip); 0 = exact (default)")
+                    "every G K blocks (bounded difference to the exact arithmetic, csrc/gemm_w8a8_fi.hip); 0 = the library's "
+                    "default (round 6: G = 4)")
+    ap.add_argument("--gemm-exact", action="store_true", help="W8A8 GEMM with the reference's exact dequant (ops/gemm/utils.hpp:116-121: "
+                    "two VALU per element and K block) instead of the library's default one-VALU form — the A/B arm of "
+                    "profiles/r06_fast_dequant_ab.txt")
     ap.add_argument("--sigma-max", type=float, default=0.0, help="0: 80 for T2V, 200 for I2V (the scripts' defaults)")
     ap.add_argument("--layers", type=int, default=0, help="debug: override num_layers (INVALID as a bench number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -575,10 +579,15 @@ def main():
 
     if args.gemm_variant:
         K.set_tuning(K.TUNE_GEMM_VARIANT, args.gemm_variant)
+    if args.gemm_exact:
+        assert not args.gemm_fast, "--gemm-exact and --gemm-fast exclude each other"
+        K.set_tuning(K.TUNE_GEMM_FAST, 1)
     if args.gemm_fast:
-        K.set_tuning(K.TUNE_GEMM_VARIANT, args.gemm_variant or 5)   # the 32x32x32-MFMA kernel carries the fast schedule
+        # round 6: every epilogue of the default (16x16x64) kernel carries the one-VALU dequant; --gemm-variant 5 = round 2's form
+        # (the 32x32x32-MFMA kernel with its early-barrier schedule)
         K.set_tuning(K.TUNE_GEMM_FAST, args.gemm_fast)
-        K.set_tuning(4, 3)
+        if args.gemm_variant == 5:
+            K.set_tuning(4, 3)
     for m_ in filter(None, (net, net_low)):
         m_.sage_pv = args.sage_pv
     for kv in args.tune:
@@ -946,7 +955,7 @@ def main():
             "vs_baseline": (value * PUBLISHED_S[(args.model, args.res)]) if (
                 args.workload == "turbo" and (args.model, args.res) in PUBLISHED_S and not args.layers
                 and args.num_steps == 4) else None,
-            "dtype": (f"int8 (W8A8 linears{', one-VALU dequant G=%d' % args.gemm_fast if args.gemm_fast else ''}, QK^T) + "
+            "dtype": (f"int8 (W8A8 linears, {'exact dequant' if args.gemm_exact else 'one-VALU dequant G=%d' % (args.gemm_fast or 4)}, QK^T) + "
                       f"{args.sage_pv} PV + bf16 activations") if wl["quant_linear"] else f"bf16 (+int8 QK^T, {args.sage_pv} PV)",
             "data": "synthetic (seeded N(0,1) latents/text embedding, random-init weights of the named architecture)",
             "config": {"workload": wl["desc"].replace("Wan2.1-T2V-1.3B 480p", f"{args.model} {args.res}").replace(

@@ -69,8 +69,11 @@ const char* td_last_error(void);
 #define TD_TUNE_GEMM_SCHED 4   /* variant 5: bit 0 = barrier one chain earlier + refill spread over two chains, bit 1 = s_setprio for the
                                   younger half-workgroup (bit-identical results); variant 4: 1 = early LDS-DMA, 2 = L2 prefetch */
 #define TD_TUNE_ATTN_TAU 5     /* attention: lazy running-max threshold in log2 units (0 = default 8, -1 = eager online softmax) */
-#define TD_TUNE_GEMM_FAST 6     /* W8A8 GEMM dequant: 0 = build default, 1 = exact (bit-identical to the reference arithmetic),
-                                  G in {2,4,8} = one-VALU dequant re-centred every G K blocks (|diff| <= 0.75 (G+1) sum_k s_k) */
+#define TD_TUNE_GEMM_FAST 6     /* W8A8 GEMM dequant: 0 = build default (round 6: G = 4; TD_GEMM_EXACT=1 in the environment makes it exact),
+                                  1 = exact (bit-identical to the reference arithmetic, ops/gemm/utils.hpp:116-121),
+                                  G in {2,4,8} = one-VALU dequant re-centred every G K blocks (|diff| <= 0.75 (G+1) sum_k s_k in the fp32
+                                  accumulator: one bf16 rounding step on 1-8 % of the outputs).  bf16 + bias launches of the LDS-DMA kernels
+                                  (m >= 1024: the model's linears); small problems and f16 / bias-free launches are always exact */
 #define TD_TUNE_LIN_QB 7       /* linear branch, pass 2: Q blocks one workgroup walks (0 = default) */
 #define TD_TUNE_ATTN_OCC 8     /* INT8/FP16-PV attention builds kept for comparison: 2 = two workgroups per CU with explicit fragment prefetch, 3 = Q64 (waves as 2 Q halves x 2 key halves; equal to rounding, not bit-identical), 4 = build 2 with the softmax denominator accumulated on the matrix pipe (round-4 experiment; equal to rounding), 5 = the production build with the denominator from the fp16-ROUNDED probabilities, two per v_dot2_f32_f16 (round-5 experiment: 16 instead of 32 VALU per lane and tile; measured equal, profiles/r05_attn_dot2.txt) */
 #define TD_TUNE_VAE_CONV 9     /* td_vae_conv.  0 = default: the 2-D-tile kernel staged by LDS-DMA (csrc/vae_conv3.hip, frames-first tile order; 256-position tiles with two workgroups per CU, 512-position tiles for the 384-channel x 27-tap reductions) for the 3x3 spatial kernels with C_out % 96 == 0 or <= 32, the row-tile kernel (csrc/vae_conv.hip) for everything else; 8 / 9 = always 512 / 256 positions; 7 = 512 with the tiles of a frame first; 2 = the row-tile kernel everywhere (the default until round 4; cross-check); 1 = the first kernel (one gather per tap, flat position tiles), cross-check; 3 = row tiles of 512 columns, one workgroup per CU (experiment, slower), 4 = row tiles with 32-channel chunks in two LDS stages, 5 = row tiles, frames-first order, 6 = 4 with the chunk multiply unrolled (experiments: equal within 1 %) */
@@ -81,7 +84,10 @@ const char* td_last_error(void);
                                    split of a block's tail, wan.py): 256-row tiles only — the 128-row / mixed plans of gemm_w8a8_fi.hip price a
                                    launch as if it owned the 256 CUs, and half-height tiles cost 1.2x the matrix work per output (measured at
                                    N = 1 with the plans left on: -3.8 %, profiles/r05_gemm_plan_n1_ab.txt) */
-#define TD_TUNE_COUNT 13
+#define TD_TUNE_GEMM_W4 13      /* round 6: which W8A8 GEMM launches take the FOUR-wave form (TD_TUNE_GEMM_VARIANT 8) when the variant is automatic —
+                                   a bit mask over the epilogue kinds: 1 = fused output quantiser (ffn.0), 2 = V^T tiles (q|k|v), 4 = residual /
+                                   row statistics (o, cross-q, cross-o, ffn.2), 8 = plain; 0 = the build default (csrc/gemm_w8a8_fi.hip), 16 = none */
+#define TD_TUNE_COUNT 14
 int td_set_tuning(int key, int value);
 /* profiling: copy the n (<= 256) 64-bit s_memtime stamps of the last TD_TUNE_GEMM_ABLATE == 9 launch to host */
 int td_debug_read(unsigned long long* host_dst, int n);

@@ -105,6 +105,7 @@ def test_c2_dense_sage_attention_at_full_length(K):
     assert rel_l2(tail, g["attn_rows"][-120:]) < 2e-2
 
 
+@pytest.mark.shipping_gemm     # (round 6: the library's default W8A8 dequant — what the sampler ships with)
 def test_four_layers_four_steps_against_the_oracle(K, capsys):
     """"full 4-step latent vs the CPU reference at identical noise: report rel-L2 per step" — here against the
     oracle's turbo arithmetic (W8A8 + Fast norms + SageSLA), 4 layers deep, L = 4096, both teacher-forced and free-running."""
@@ -369,6 +370,7 @@ def test_forward_runs_no_library_operator_and_refuses_what_the_kernels_do_not_ta
         net._lin16(torch.zeros(4, 64, device=DEV), torch.zeros(8, 64, device=DEV), None)
 
 
+@pytest.mark.shipping_gemm
 def test_twelve_layers_deep_against_the_oracle(K, capsys):
     """Drift over depth against the ORACLE's statement of the turbo arithmetic (not against a dense-bf16 run): 12 blocks,
     W8A8 + Fast norms (the reference's Triton LayerNorm variance) + SageSLA top-k 0.25 at L = 4096.  Block-map near-ties and

@@ -34,18 +34,23 @@ def _model(cfg, topk):
         return WanModel(attention_type="sagesla", sla_topk=topk, quant_linear=True, **cfg)
 
 
-def _check(which, net, x, t, ctx, g, capsys):
+def _check(which, net, x, t, ctx, g, capsys, bound):
+    """Both W8A8 dequant forms (round 6): the library default (one-VALU) and the reference's exact arithmetic, same model."""
+    from turbodiffusion_amd import kernels as K_
     xd, td, cd = x.to(DEV).bfloat16(), t.to(DEV), ctx.to(DEV)
-    tok = net(xd, td, cd, _return_tokens=True)[0][g["rows"].to(DEV)]
-    v = net(xd, td, cd)
-    r_tok, r_v = rel_l2(tok, g["tok_rows"]), rel_l2(v, g["v"].float())
-    with capsys.disabled():
-        print(f"\n[{which}: {net.num_layers} layers at dim {net.dim}, L = 4096] rel-L2 vs the oracle: tokens after the last block "
-              f"{r_tok:.4f} (cosine {cosine(tok, g['tok_rows']):.5f}), velocity {r_v:.4f}")
-    assert torch.isfinite(v).all()
-    # measured 1.2e-2 ... 1.6e-2 (profiles/r04_pytest_gpu.txt, r05_pytest_gpu.txt); SURVEY §8d's one-block bar is 2e-2
-    assert r_tok < 2.5e-2 and cosine(tok, g["tok_rows"]) > 0.999, r_tok
-    assert r_v < 2.5e-2 and cosine(v, g["v"].float()) > 0.999, r_v
+    for mode, name in ((0, "one-VALU (shipping default)"), (1, "exact")):
+        K_.set_tuning(K_.TUNE_GEMM_FAST, mode)
+        tok = net(xd, td, cd, _return_tokens=True)[0][g["rows"].to(DEV)]
+        v = net(xd, td, cd)
+        r_tok, r_v = rel_l2(tok, g["tok_rows"]), rel_l2(v, g["v"].float())
+        with capsys.disabled():
+            print(f"\n[{which}: {net.num_layers} layers at dim {net.dim}, L = 4096; W8A8 dequant: {name}] rel-L2 vs the oracle: tokens after the last block "
+                  f"{r_tok:.4f} (cosine {cosine(tok, g['tok_rows']):.5f}), velocity {r_v:.4f}")
+        assert torch.isfinite(v).all()
+        # measured with the exact dequant: 1.31e-2 / 1.18e-2 at 1.3B width, 1.45e-2 / 1.56e-2 at 14B width (profiles/r05_pytest_gpu.txt);
+        # bound = 1.5 x that (round 6; 2.5e-2 before); SURVEY §8d's one-block bar is 2e-2
+        assert r_tok < bound and cosine(tok, g["tok_rows"]) > 0.9995, (name, r_tok)
+        assert r_v < bound and cosine(v, g["v"].float()) > 0.9995, (name, r_v)
 
 
 def test_thirty_layers_at_1p3b_width_against_the_oracle(capsys):
@@ -55,7 +60,7 @@ def test_thirty_layers_at_1p3b_width_against_the_oracle(capsys):
     net = _model(R4.CFG13, R4.FULL["topk"])
     net.load_from_float_state_dict({k_: v_.to(DEV) for k_, v_ in sd.items()})
     del sd
-    _check("full13", net.eval(), x, t, ctx, g, capsys)
+    _check("full13", net.eval(), x, t, ctx, g, capsys, 2.0e-2)
 
 
 def test_forty_layers_at_14b_width_against_the_oracle(capsys):
@@ -70,7 +75,7 @@ def test_forty_layers_at_14b_width_against_the_oracle(capsys):
     net.load_from_float_state_dict(sd)
     del sd
     torch.cuda.empty_cache()
-    _check("full14", net.eval(), x, t, ctx, g, capsys)
+    _check("full14", net.eval(), x, t, ctx, g, capsys, 2.3e-2)
 
 
 def test_two_blocks_at_the_real_c1_length_against_the_oracle(capsys):
@@ -80,12 +85,15 @@ def test_two_blocks_at_the_real_c1_length_against_the_oracle(capsys):
     net.load_from_float_state_dict({k_: v_.to(DEV) for k_, v_ in sd.items()})
     net.eval()
     assert net.split_tokens and net.fuse_row_stats and net.fuse_vt           # the production schedule
-    tok = net(x.to(DEV).bfloat16(), t.to(DEV), ctx.to(DEV), _return_tokens=True)[0]
-    assert tok.shape[0] == 32760
-    rows = g["rows"].to(DEV)
-    r = rel_l2(tok[rows], g["tok_rows"])
-    tail = rel_l2(tok[-120:], g["tok_rows"][-120:])
-    with capsys.disabled():
-        print(f"\n[two blocks at L = 32 760] rel-L2 vs the oracle: sampled rows {r:.4f}, the 120-row tail block {tail:.4f}, "
-              f"cosine {cosine(tok[rows], g['tok_rows']):.5f}")
-    assert r < 2e-2 and tail < 3e-2 and cosine(tok[rows], g["tok_rows"]) > 0.999
+    from turbodiffusion_amd import kernels as K_
+    for mode, name in ((0, "one-VALU (shipping default)"), (1, "exact")):
+        K_.set_tuning(K_.TUNE_GEMM_FAST, mode)
+        tok = net(x.to(DEV).bfloat16(), t.to(DEV), ctx.to(DEV), _return_tokens=True)[0]
+        assert tok.shape[0] == 32760
+        rows = g["rows"].to(DEV)
+        r = rel_l2(tok[rows], g["tok_rows"])
+        tail = rel_l2(tok[-120:], g["tok_rows"][-120:])
+        with capsys.disabled():
+            print(f"\n[two blocks at L = 32 760; W8A8 dequant: {name}] rel-L2 vs the oracle: sampled rows {r:.4f}, the 120-row tail block {tail:.4f}, "
+                  f"cosine {cosine(tok[rows], g['tok_rows']):.5f}")
+        assert r < 1.2e-2 and tail < 1.2e-2 and cosine(tok[rows], g["tok_rows"]) > 0.9995, (name, r, tail)      # (measured 7.7e-3 / 7.8e-3)

@@ -179,6 +179,16 @@ def test_projection_as_two_launches_is_bit_identical_at_the_real_widths(width, L
 
 
 # ---------------------------------------------------------------- parity at the REAL size, full depth (VERDICT r04 "next" 2)
+DEQUANT = pytest.mark.parametrize("dequant", ["one-VALU (shipping default)", "exact"])
+
+
+def _set_dequant(dequant):
+    """Round 6: both W8A8 dequant forms against the same fixture — the library default (one-VALU, csrc/capi.hip) and the exact
+    arithmetic of the reference (td_set_tuning(TD_TUNE_GEMM_FAST, 1)); tests/conftest.py resets the knob after the test."""
+    from turbodiffusion_amd import kernels as K_
+    K_.set_tuning(K_.TUNE_GEMM_FAST, 1 if dequant == "exact" else 0)
+
+
 def _gold(name):
     path = os.path.join(GOLD, f"r05_{name}.pt")
     if not os.path.exists(path):
@@ -197,15 +207,18 @@ def _c1_net():
     return net.eval()
 
 
-def test_headline_configuration_full_depth_at_the_real_length_against_the_oracle(capsys):
+@DEQUANT
+def test_headline_configuration_full_depth_at_the_real_length_against_the_oracle(capsys, dequant):
     """C1 as the bench runs it — Wan2.1-1.3B, 30 layers, L = 32 760 tokens, W8A8 + Fast norms + SageSLA top-k 0.1, the production
     schedule (hipGraph-able path: fused epilogues, two streams, token-half split) — ONE forward at step 2's t against the CPU
     oracle's forward of the same weights / inputs (tests/golden/r05_c1full.pt, 55 min of oracle time): tokens after the last
     block (every 32nd row + the 120-row tail block), the velocity, and the drift over depth (after blocks 1, 2, 4, 8, 16, 24).
     Bound: SURVEY §8d's 2e-2 / cosine 0.999 on the velocity would be the one-block figure; through 30 blocks of block-map
-    near-ties and INT8 rounding the measured figures are printed and bounded at 2.5e-2."""
+    near-ties and INT8 rounding the measured figures are printed; round 6 bounds them at 1.8e-2 (measured 1.29e-2 / 1.19e-2
+    with the exact dequant: a regression of 1.5x fails)."""
     from oracle import make_golden_r05 as R5
     g = _gold("c1full")
+    _set_dequant(dequant)
     net = _c1_net()
     assert net.split_tokens and net.fuse_row_stats and net.fuse_vt and net.two_streams
     x, ctx = R5.c1_inputs()
@@ -219,16 +232,17 @@ def test_headline_configuration_full_depth_at_the_real_length_against_the_oracle
     r_tok, r_tail, r_v = rel_l2(tok, g["tok_rows"].float()), rel_l2(taps[-1][0][-120:], g["tok_rows"][-120:].float()), rel_l2(v, g["v"].float())
     depth = {i: rel_l2(taps[i][0][::g["depth_every"]], d.float()) for i, d in sorted(g["depth"].items())}
     with capsys.disabled():
-        print(f"\n[C1 at full size: 30 layers x 32 760 tokens] rel-L2 vs the oracle: tokens after the last block {r_tok:.4f} (tail block "
+        print(f"\n[C1 at full size: 30 layers x 32 760 tokens; W8A8 dequant: {dequant}] rel-L2 vs the oracle: tokens after the last block {r_tok:.4f} (tail block "
               f"{r_tail:.4f}, cosine {cosine(tok, g['tok_rows'].float()):.5f}), velocity {r_v:.4f} (cosine {cosine(v, g['v'].float()):.5f}); "
               f"after blocks " + ", ".join(f"{i + 1}: {e:.4f}" for i, e in depth.items()))
     assert torch.isfinite(v).all()
-    assert r_tok < 2.5e-2 and cosine(tok, g["tok_rows"].float()) > 0.999, r_tok
-    assert r_v < 2.5e-2 and cosine(v, g["v"].float()) > 0.999, r_v
-    assert r_tail < 3.5e-2 and max(depth.values()) < 2.5e-2, (r_tail, depth)
+    assert r_tok < 1.8e-2 and cosine(tok, g["tok_rows"].float()) > 0.9995, r_tok
+    assert r_v < 1.8e-2 and cosine(v, g["v"].float()) > 0.9995, r_v
+    assert r_tail < 2.5e-2 and max(depth.values()) < 1.8e-2, (r_tail, depth)
 
 
-def test_four_sampler_steps_at_the_real_size_against_the_oracle(capsys):
+@DEQUANT
+def test_four_sampler_steps_at_the_real_size_against_the_oracle(capsys, dequant):
     """"full 4-step latent vs the eager CPU reference at identical noise: rel-L2 per step" — at the headline size: the
     same 30-layer model through the rCM loop (sampler.rcm_sample, hipGraph replay) against the oracle's loop at identical
     noise: the velocity at every step's input and the latent after every step (tests/golden/r05_c1steps.pt, ~3.6 h of
@@ -237,6 +251,7 @@ def test_four_sampler_steps_at_the_real_size_against_the_oracle(capsys):
     from turbodiffusion_amd.graph import GraphedModel
     from turbodiffusion_amd.sampler import rcm_sample_iter
     g = _gold("c1steps")
+    _set_dequant(dequant)
     net = GraphedModel(_c1_net())
     x0, ctx = R5.c1_inputs()
     noises = [n.to(DEV) for n in R5.c1_noises()]
@@ -253,20 +268,22 @@ def test_four_sampler_steps_at_the_real_size_against_the_oracle(capsys):
         gv, gx = (t if t.shape[-1] == R5.C1["latent"][-1] // 2 else R5._sub(t) for t in (g["v"][i], g["x"][i]))
         rv, rx = rel_l2(R5._sub(vs[i]), gv.float().to(DEV)), rel_l2(R5._sub(x_i.float()), gx.float().to(DEV))
         lines.append(f"step {i + 1}: velocity {rv:.4f}, latent {rx:.4f}")
-        assert rv < 3e-2 and rx < 3e-2, (i, rv, rx)
+        assert rv < 1.8e-2 and rx < 1.2e-2, (i, rv, rx)      # (measured with the exact dequant: velocity <= 1.23e-2, latent <= 0.68 %)
     with capsys.disabled():
-        print("\n[4 rCM steps at full size, identical noise] rel-L2 vs the oracle per step: " + "; ".join(lines)
+        print(f"\n[4 rCM steps at full size, identical noise; W8A8 dequant: {dequant}] rel-L2 vs the oracle per step: " + "; ".join(lines)
               + (" (fixture partial)" if g.get("partial") else ""))
     assert lines
 
 
-def test_two_blocks_at_c4_size_all_heads_against_the_oracle(capsys):
+@DEQUANT
+def test_two_blocks_at_c4_size_all_heads_against_the_oracle(capsys, dequant):
     """C4 / C5's size: dim 5120, 40 heads, ffn 13 824 at L = 75 600 tokens (720p), two blocks, all heads, top-k 0.1: tokens after the
     second block (every 128th row + the 80-row tail block) vs the oracle (tests/golden/r05_c4two.pt)."""
     from oracle import make_golden_r04 as R4
     from oracle import make_golden_r05 as R5
     from turbodiffusion_amd.wan import WanModel
     g = _gold("c4two")
+    _set_dequant(dequant)
     cfg = R5.C4["cfg"]
     with torch.device(DEV):
         net = WanModel(attention_type="sagesla", sla_topk=R5.C4["topk"], quant_linear=True, **cfg)
@@ -281,5 +298,5 @@ def test_two_blocks_at_c4_size_all_heads_against_the_oracle(capsys):
     rows = g["rows"].to(DEV)
     r, tail = rel_l2(tok[rows], g["tok_rows"].float()), rel_l2(tok[-80:], g["tok_rows"][-80:].float())
     with capsys.disabled():
-        print(f"\n[two blocks at C4's size: dim 5120 x 75 600 tokens, 40 heads] rel-L2 vs the oracle: sampled rows {r:.4f}, tail block {tail:.4f}")
-    assert r < 2e-2 and tail < 3e-2 and cosine(tok[rows], g["tok_rows"].float()) > 0.999
+        print(f"\n[two blocks at C4's size: dim 5120 x 75 600 tokens, 40 heads; W8A8 dequant: {dequant}] rel-L2 vs the oracle: sampled rows {r:.4f}, tail block {tail:.4f}")
+    assert r < 1.4e-2 and tail < 1.8e-2 and cosine(tok[rows], g["tok_rows"].float()) > 0.9995      # (measured 8.8e-3 / 8.8e-3)

@@ -43,6 +43,9 @@
 // per instantiation (NI = 8 | 4 sixteen-row sub-tiles per wave): tile rows F_BM = 32 NI = 256 | 128; one stage = an activation tile
 // of F_BM x 128 B + a weight tile of 256 x 128 B; two stages = 128 | 96 KB (F_EPI = where the epilogue's scratch behind them
 // starts: 128 KB in both forms, so that the GELU table fits)
+// measured end to end on one box (profiles/r06_fast_dequant_ab.txt, three interleaved repetitions, one-VALU dequant in every arm):
+// no four-wave launches 3.227 videos/s, the fused-quantiser GEMM (ffn.0) on it 3.257, + the q|k|v GEMM 3.256, every GEMM 3.221
+#define TD_GEMM_W4_DEFAULT 3
 #define F_MAGIC_I 0x4B400000
 #define F_MAGIC_F 12582912.0f
 
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_w8a8_fi_kernel(
       for (int j = 0; j < 4; ++j) {
         F_MFMA0(t[cur][j], wf[j][0], xf[cur][0])
         if constexpr (FAST == 0) { F_ADD4(t[prv][j]) }
-        else if (recentre) { F_ADDC4(accf[pi][j], c_neg) }
+        else if (i == 0 ? (u == 0 && kb > 0) : recentre) { F_ADDC4(accf[pi][j], c_neg) }   // (row group NI-1: one group later = the next block's first)
       }
       F_FENCE()
       if (i == NI - 1 && more) { F_LOAD_W(wsn, 0) }
@@ -462,6 +465,15 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_w8a8_fi_kernel(
   if constexpr (FAST == 0) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { F_ADD4(t[1][j]) }
+  }
+  if constexpr (FAST > 0) {
+    // every row group takes a re-centring add right BEFORE the fmac of the re-centring block's own sums — for the last row
+    // group that fmac sits in the next block's first group (or here): the same order of roundings for every output element
+    // whatever the tile form (NI = 4 | 8, eight | four waves), i.e. the one-VALU mode is bit-identical across the launch plans too
+    if (nk % UNR == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { F_ADDC4(accf[NI - 1][j], c_neg) }
+    }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) { F_FMAC4(accf[NI - 1][j], t[1][j], sc_old) }
@@ -870,7 +882,11 @@ static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, co
   const int tm8 = (int)td_cdiv(m, 256), tm4 = (int)td_cdiv(m, 128), tn = (int)td_cdiv(n, F_BN);
   if constexpr (DBG == 0 && SCHED == 0 && (FAST == 0 || FAST == 4)) {
     int v = td_tuning(TD_TUNE_GEMM_VARIANT);
-    if (v == 8)
+    // the four-wave form by epilogue kind (TD_TUNE_GEMM_W4; profiles/r06_gemm_forms_*.txt, r06_w4_ab.txt)
+    constexpr int kind = QOUT ? 1 : (VT != 0 ? 2 : ((RES || STATS) ? 4 : 8));
+    int w4 = td_tuning(TD_TUNE_GEMM_W4);
+    if (w4 == 0) w4 = TD_GEMM_W4_DEFAULT;
+    if (v == 8 || (v == 0 && (w4 & kind) && m >= 1024))
       return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, FAST, STATS, VT, 8, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, tm4);
     if (v == 0 && td_tuning(TD_TUNE_GEMM_COTENANT)) v = 4;   // beside another GEMM: a launch does not own the chip, whole tiles only
     const double c = (!QOUT && !RES && !STATS) ? 0.80 : 0.60;

@@ -74,6 +74,7 @@ TUNE_ATTN_OCC = 8    # 2 = INT8/FP16-PV attention built for two workgroups per C
 TUNE_VAE_CONV = 9    # 1 = the first td_vae_conv kernel (cross-check of the default)
 TUNE_GELU_TABLE = 11  # 1 = the fused FFN GEMM's GELU evaluated inline instead of looked up in the device-built table (bit-identical; A/B)
 TUNE_GEMM_COTENANT = 12  # 1 while W8A8 GEMMs are launched beside another GEMM on a second stream (256-row tiles only)
+TUNE_GEMM_W4 = 13    # bit mask of W8A8 launch kinds on the four-wave form (1 fused quantiser, 2 V^T tiles, 4 residual / row statistics, 8 plain; 16 none)
 TUNE_GEMM16 = 10     # td_gemm_bf16: 2 = the four-wave 128x128 experiment (bit-identical, measured equal); default eight waves of 128x64
 
 
