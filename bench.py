@@ -113,6 +113,18 @@ HBM_PEAK = 8.0e12                  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 I8_PEAK = 5.0e15                   # dense INT8 MFMA (= dense FP8 rate), MI355X_MICROARCH.md
 F16_PEAK = 2.5e15                  # dense FP16/BF16 MFMA
 RES = {"480p": (832, 480), "720p": (1280, 720)}
+# the HBM-bound family of a block (round 6, `roofline_hbm`): C-ABI entry point -> (what, algorithmic bytes per launch in units of
+# L x dim bytes [+ per-row bytes]) — DESIGN.md 3: every tensor the operator must read or write once, nothing for re-reads
+HBM_FAMILY = {
+    "td_layernorm_quant_stats": ("LayerNorm apply (+ AdaLN modulate) -> INT8 codes + block scales (a5-a7 -> a16); row statistics from the GEMM epilogue", 3.0, 8.0),
+    "td_qk_norm_rope": ("RMSNorm(dim) + RoPE + head-major relayout of q or k (a3 / a8)", 4.0, 512.0),
+    "td_qk_norm_rope_pair": ("the same for q and k in one launch", 8.0, 512.0),
+    "td_sage_quant_pool": ("Sage per-block INT8 quantiser (+ smooth-K) + block mean pooling of q or k (a11 / a13)", 3.0, 0.0),
+    "td_sla_linear_kv": ("linear branch, pass over K and V^T: sum phi(k)^T v, sum phi(k) (+ the smooth-K mean) (a14)", 4.0, 0.0),
+    "td_sla_linear_out_t": ("linear branch, pass over Q: phi(q) (kv) / (phi(q) . ksum) -> proj_l -> o_l (a14)", 4.0, 0.0),
+    "td_sla_linear_out": ("linear branch, pass over Q, added to the attention output in place", 6.0, 0.0),
+    "td_row_stats_finalize": ("row statistics from the GEMM epilogue's per-64-column pieces", 0.125, 8.0),
+}
 WORKLOADS = {
     "turbo": dict(attention_type="sagesla", quant_linear=True,
                   desc="TurboWan2.1-T2V-1.3B-480P 4-step: SageSLA top-k 0.1 + W8A8 + fused norms"),
@@ -647,6 +659,7 @@ def main():
     K.set_timer(None)
     phase(f"timed region done: {args.steps} videos in {elapsed:.2f} s")
     eager_elapsed = None
+    hbm_timer = None
     if use_graph:
         # a replayed graph has no per-launch Python hook: the per-kernel HIP events are taken on one more
         # video of the SAME workload enqueued eagerly right after the timed region (same kernels, same stream)
@@ -669,6 +682,22 @@ def main():
             m_.split_tokens = v_
             m_.split_qkv = q_
         phase(f"eager video with per-kernel events done ({eager_elapsed:.2f} s)")
+        # round 6: the HBM-bound family (quantiser / norms / modulate / RoPE / pooling / linear branch) against ITS
+        # roofline — one more eager video with every schedule switch that runs two kernels side by side off (two streams too),
+        # HIP events around the C-ABI entry points of the family (kernels.call): each launch's own duration
+        if world == 1 and wl["quant_linear"] and emu is None:
+            saved_sched = [(m_, m_.split_tokens, m_.split_qkv, m_.two_streams) for m_ in filter(None, (net, net_low))]
+            for m_, *_r in saved_sched:
+                m_.split_tokens = m_.split_qkv = m_.two_streams = False
+            hbm_timer = K.KernelTimer((), entries=HBM_FAMILY)
+            K.set_timer(hbm_timer)
+            sync()
+            one_video(net)
+            sync()
+            K.set_timer(None)
+            for m_, v_, q_, t_ in saved_sched:
+                m_.split_tokens, m_.split_qkv, m_.two_streams = v_, q_, t_
+            phase("eager single-stream video with events around the HBM-bound entry points done")
     # ---- serving-style extra (N = 1): two independent videos in flight (two graph replays on two streams); the GPU
     #      fills one video's bubbles (GEMM prologues / store phases, barrier waits) with the other's kernels
     two_in_flight = None
@@ -773,7 +802,9 @@ def main():
             p2p = {"error": repr(e)}
 
     multi = None
-    if world > 1:
+    if world > 1 or args.rccl_one_rank:     # (round 6: the one-rank RCCL rig emits the same record — the probe path proven before any 8-GPU run)
+        if args.rccl_one_rank:
+            backend = "nccl"
         cdev = dev if backend == "nccl" else "cpu"
         mine = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         every = [torch.zeros_like(mine) for _ in range(world)]
@@ -787,7 +818,7 @@ def main():
         # stream-side wait for an asynchronous gather (seqpar.WAIT_PROBE) — the time the compute stream sat waiting for the
         # wire, per collective, on every rank
         waits = None
-        if sp > 1:
+        if sp > 1 or args.rccl_one_rank:
             from turbodiffusion_amd import seqpar as _sq
             _sq.WAIT_PROBE = []
             sync()
@@ -947,6 +978,27 @@ def main():
         if roof is None:    # no W8A8 GEMM in this workload: `roofline` = whichever of the 16-bit GEMM / the attention kernel holds more of the step
             cands = [r_ for r_ in (roof16, roof_attn) if r_ is not None]
             roof = max(cands, key=lambda r_: r_["share_of_step"]) if cands else None
+        roof_hbm = None
+        if hbm_timer is not None and hbm_timer.records:
+            # per entry point: the launches over the video's own token count (the text side's 512-row launches are another regime)
+            dim_ = cfg["dim"]
+            kern, tot_b, tot_t = [], 0.0, 0.0
+            for name, recs in hbm_timer.records.items():
+                what, per_ld, per_row = HBM_FAMILY[name]
+                ms_ = [a_.elapsed_time(b_) for a_, b_, _ in recs]
+                big = [t_ for t_ in ms_ if t_ > 0.5 * max(ms_)] if name != "td_row_stats_finalize" else ms_
+                byts = per_ld * L_tok * dim_ + per_row * L_tok
+                t_avg = sum(big) / len(big) * 1e-3
+                kern.append({"entry": name, "what": what, "launches": len(big), "avg_launch_us": t_avg * 1e6, "algorithmic_bytes": byts,
+                             "achieved_GBps": byts / t_avg / 1e9, "frac": byts / t_avg / HBM_PEAK})
+                tot_b += byts * len(big)
+                tot_t += t_avg * len(big)
+            kern.sort(key=lambda r_: -r_["avg_launch_us"] * r_["launches"])
+            roof_hbm = {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s", "achieved": tot_b / tot_t / 1e9, "frac": tot_b / tot_t / HBM_PEAK,
+                        "share_of_step": tot_t / per_video, "launches_per_video": sum(k_["launches"] for k_ in kern),
+                        "how": "HIP events around each C-ABI entry point on its launch stream, one eager single-stream video (no second "
+                               "stream, no token split) after the timed region; algorithmic bytes = every operand read or written once",
+                        "kernels": kern}
         res = {
             "metric": f"end-to-end videos/sec (4-step rCM denoising loop, {args.model} {args.res})",
             "value": value, "unit": "videos/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -970,6 +1022,7 @@ def main():
                            f"dp{dp} x sp{sp}: {dp} independent videos, each sharded by sequence over {sp} GPUs "
                            f"(RCCL all-gather of the quantised K/V per layer)" if sp > 1 else f"dp{dp}: {dp} independent videos")},
             "roofline": roof, "roofline_attention": roof_attn, **({"roofline_gemm16": roof16} if roof16 is not None else {}),
+            **({"roofline_hbm": roof_hbm} if roof_hbm is not None else {}),
             "launch_mode": (("hipGraph replay, one graph per DiT forward" if sp == 1 else
                              "hipGraph replay in segments, the all-gathers issued eagerly between them") +
                             "; kernel events from one eager video (full-size launches: token-half split off, q|k|v projection as one launch) after the timed region"
@@ -1029,7 +1082,15 @@ def main():
                 "branches_in_parallel": bool(spo.branches_in_parallel(cfg["num_heads"], spo.per, lay.G)),
                 "pack_bytes_per_layer": pack, "head_groups": lay.G,
                 "modelled_wire_ms_per_dit_step": {"link_GBps": link / 1e9, "fully_exposed": nl * wire_layer * 1e3,
-                                                  "first_head_group_exposed": nl * wire_layer * lay.pieces[0][1] / lay.total * 1e3},
+                                                  "first_head_group_exposed": nl * wire_layer * lay.pieces[0][1] / lay.total * 1e3,
+                                                  # round 6: bytes are not what decides a small shard — every collective also costs a launch +
+                                                  # rendezvous latency that no byte model sees.  Exposed per layer: the early exchange(s) (the K
+                                                  # quantiser waits for the sums) + the first piece; the later pieces fly under attention.
+                                                  "collectives_per_layer": spo.collectives_per_layer(lay.G, at not in ("original", "sage")),
+                                                  "exposed_collectives_per_layer": spo.exposed_collectives_per_layer(at not in ("original", "sage")),
+                                                  "with_latency_us_per_collective": {
+                                                      str(lat_us): nl * (wire_layer * lay.pieces[0][1] / lay.total + spo.exposed_collectives_per_layer(at not in ("original", "sage")) * lat_us * 1e-6) * 1e3
+                                                      for lat_us in (10, 20, 40)}},
                 "what": "one rank's kernels of an N-way sequence split on one GPU: its token shard, gathered buffers of the real "
                         "size filled by device copies of its own pack (the HBM writes of the incoming xGMI traffic, NOT overlapped), "
                         "no communication; the step of a real N-GPU run = this compute term + the exposed part of the wire term"}

@@ -94,8 +94,11 @@ class _Gather:
             # Under a SEGMENTED capture (graph.SegmentRecorder) issue() is an eager point — re-run at every replay — while the
             # join in wait() would be recorded once, inside a captured segment, against the event of the capture pass: the next
             # segment could read the buffers before this replay's copy finished.  There the copy stays on the issuing stream.
+            # The choice is made at the FIRST issue and kept: the replay re-runs this method outside any capture.
             from . import graph as _graph
-            if self.out.is_cuda and self.async_op and EMU_WIRE_STREAM and _graph._ACTIVE is None:
+            if not hasattr(self, "_on_issuing_stream"):
+                self._on_issuing_stream = _graph._ACTIVE is not None
+            if self.out.is_cuda and self.async_op and EMU_WIRE_STREAM and not self._on_issuing_stream:
                 main = torch.cuda.current_stream()
                 st = _emu_stream()
                 e = torch.cuda.Event()
@@ -253,6 +256,20 @@ class SeqParallel:
             self.head_groups = int(os.environ["TD_SP_HEAD_GROUPS"])
         if os.environ.get("TD_SP_PARALLEL_GROUPS"):
             self.parallel_groups = os.environ["TD_SP_PARALLEL_GROUPS"] != "0"
+        # round 6: ONE early exchange per layer (K column sums | linear partials in one buffer) instead of two — one collective
+        # less per layer (a launch + a rendezvous: what decides a small shard is the count, not the bytes); the sums then
+        # leave a few microseconds later, behind the pack's first half (V^T tiles + linear partials), with this rank's Q
+        # quantiser between the issue and the wait as before.  TD_SP_MERGE_EARLY=0: round 5's two exchanges (A/B).
+        self.merge_early = os.environ.get("TD_SP_MERGE_EARLY", "1") != "0"
+
+    def collectives_per_layer(self, G, linear):
+        """all-gathers one self-attention layer issues: the early exchange(s) + one per head-group piece."""
+        return (1 if (self.merge_early or not linear) else 2) + G
+
+    def exposed_collectives_per_layer(self, linear):
+        """of which the compute stream has to wait for with nothing of its own left to run: the early exchange in front of the K
+        quantiser and the first piece in front of the block map (later pieces fly under the previous group's attention)."""
+        return 2
 
     def groups_for(self, H, per):
         """Head groups of the K-side exchange for a rank with ``per`` tokens.  More groups hide more of the exchange behind
@@ -396,18 +413,27 @@ class SeqParallel:
         # rank is prepared while they are in flight.  The mean itself is formed inside the K quantiser from the gathered sums.
         early = torch.empty((lay.early_sum + lay.early_lin,), dtype=torch.float32, device=dev)
         allp = km_work = alll = lin_work = None
+        merged = self.merge_early and linear and (sage or not dense)
         if sage or not dense:
             part = ops.seq_sum(k, out=early[:lay.early_sum].view(H, D))
-            allp, km_work = self.all_gather(part, async_op=True)                # [W, H, D]
+            if not merged:
+                allp, km_work = self.all_gather(part, async_op=True)                # [W, H, D]
         lin_ks = early[lay.early_sum:lay.early_sum + H * D].view(H, D) if linear else None
         lin_kv = early[lay.early_sum + H * D:].view(H, D, D) if linear else None
         pack = ops.sp_pack_begin(k, v_src, v_strides, L_loc, lay, lin_kv, lin_ks)      # V^T tiles; linear partials -> early
+        if merged:
+            # ONE exchange: [sums | ks | kv] of every rank; both consumers read rank-major views of the same gathered buffer
+            alle, km_work = self.all_gather(early, async_op=True)                   # [W, early_sum + early_lin]
+            lin_work = km_work
+            allp = alle[:, :lay.early_sum].view(W, H, D)
+            alll = alle[:, lay.early_sum:]
         # ---- the linear branch's reduction over the ranks and its second pass (-> o_l [all heads], which the attention
         # epilogue adds): on a
         # side stream beside the Q / K quantisers and the pack's exchange below (a graph branch under capture), joined before attention
-        o_l = e_ol = None
+        o_l = e_ol = e_early = None
         if linear:
-            alll, lin_work = self.all_gather(early[lay.early_sum:], async_op=True)      # [W, H*D + H*D*D]
+            if not merged:
+                alll, lin_work = self.all_gather(early[lay.early_sum:], async_op=True)      # [W, H*D + H*D*D]
             main = torch.cuda.current_stream() if on_streams else None
             st_l = self._stream(100) if on_streams else None
             if st_l is not None:
@@ -416,6 +442,11 @@ class SeqParallel:
                 st_l.wait_event(e_f)
             with (torch.cuda.stream(st_l) if st_l is not None else _NullCtx()):
                 lin_work.wait()
+                if merged and st_l is not None:
+                    # the ONE early gather has two consumers on two streams; its handle is awaited once, here — the main stream
+                    # joins through this event (recorded right behind the wait: nothing else of this stream is in front of it)
+                    e_early = torch.cuda.Event()
+                    e_early.record(st_l)
                 ks_parts = alll[:, :H * D].view(W, H, D)                       # [W, H, D] rank-major views of the early gather
                 kv_parts = alll[:, H * D:].view(W, H, D, D)
                 kv_t, ksum = ops.sla_linear_kv_final(kv_parts, ks_parts, W, D * D, kv_parts.stride(0), D, ks_parts.stride(0), H, D, dt)
@@ -429,7 +460,10 @@ class SeqParallel:
         elif not dense:
             pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
         if allp is not None:
-            km_work.wait()
+            if merged and linear and e_early is not None:
+                torch.cuda.current_stream().wait_event(e_early)
+            else:
+                km_work.wait()      # (merged on ONE stream: already awaited above, in order — a no-op)
 
         # ---- (2) the part of the K-side state that needs the mean, written straight into the send buffer: ONE launch ----
         ops.sp_pack_finish(pack, k, None if allp is None else (allp, L), L_loc, lay)
