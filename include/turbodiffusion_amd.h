@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define TD_ABI_VERSION 4
+#define TD_ABI_VERSION 5   /* round 6: + td_attn_16_qnorm_pieces, TD_TUNE_GEMM_W4; TD_SLA_NCH 32 -> 64 (workspace extents); default W8A8 dequant = one-VALU */
 
 /* status codes */
 #define TD_OK 0
@@ -397,6 +397,12 @@ int td_attn_16_qnorm(const void* q_src, int64_t ld_q, const float* q_rstd, const
                      const void* vt, const int32_t* lut, int nsel, void* o, int dtype, int64_t o_stride_h,
                      int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int64_t Lk_alloc, int H,
                      const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream);
+/* round 6 (ABI v5): the same with the row statistic formed on load from the per-64-column pieces of td_gemm_w8a8_stats
+ * (stats_ws float2 [L, pieces], pieces = H * 128 / 64): == td_row_stats_finalize(mode 1) + td_attn_16_qnorm bit for bit. */
+int td_attn_16_qnorm_pieces(const void* q_src, int64_t ld_q, const float* stats_ws, int pieces, float eps, const float* q_w,
+                            const void* k, const void* vt, const int32_t* lut, int nsel, void* o, int dtype, int64_t o_stride_h,
+                            int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk, int64_t Lk_alloc, int H,
+                            const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream);
 
 /* ---- sequence parallelism: the same attention / block-map kernels reading the K side STRAIGHT from the
  * output of the per-layer all-gather, which is rank-major: K block j (64 keys) is block j % kb_per_rank of rank
@@ -437,7 +443,7 @@ int td_sage_quant_pool_packed_kmsum(const void* x, const void* km, const float* 
 int td_sla_topk_sp(const void* pq, const void* pk, int dtype, int32_t* lut, int H, int Qb, int Kb, int kb_per_rank,
                    int64_t pk_rank_stride, int D, int topk, td_stream_t stream);
 
-#define TD_SLA_NCH 32 /* partial-sum chunks per head of td_sla_linear_kv* (workspace leading extent) */
+#define TD_SLA_NCH 64 /* partial-sum chunks per head of td_sla_linear_kv* (workspace leading extent) */
 
 /* ---- a14: linear-attention branch (SLA/core.py:243-253, feature_map = softmax) ----
  * pass 1: ck = cast(softmax_D(k)); kvsum[h] = cast(ck^T @ v) ; ksum[h] = cast(sum_L ck)

@@ -214,6 +214,35 @@ def test_attn_16_qnorm_bit_exact(K, H, L, Lk, dtype, quant_out):
             torch.testing.assert_close(out, out_ref, rtol=0, atol=1e-3)
 
 
+@pytest.mark.parametrize("H,L,Lk,k", [(12, 1500, 512, 256), (40, 1100, 512, 128), (12, 4096, 77, 1536)])
+@pytest.mark.parametrize("quant_out", [False, True])
+def test_attn_16_qnorm_from_the_gemm_epilogue_pieces_is_bit_identical(K, H, L, Lk, k, quant_out):
+    """Round 6: td_attn_16_qnorm_pieces — the RMSNorm statistic of Q formed where the attention kernel loads Q, from the
+    per-64-column (mean, M2) pieces the q projection's STATS epilogue wrote — against td_row_stats_finalize(mode 1) +
+    td_attn_16_qnorm: the same additions in the same order, the same bits (outputs, and the fused INT8 codes + scales)."""
+    g = torch.Generator().manual_seed(H * L + Lk)
+    dim = H * 128
+    a = (torch.randn(L, k, generator=g) * 1.3).to(torch.bfloat16).to(DEV)
+    w_ = (torch.randn(dim, k, generator=g) / k ** 0.5).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(dim, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    aq, as_ = K.quant_i8_block128(a)
+    wq, ws_ = K.quant_i8_block128(w_)
+    src, pieces = K.gemm_w8a8_stats(aq, as_, wq, ws_, b)
+    wn = (torch.rand(dim, generator=g) + 0.5).to(DEV)
+    kk = torch.randn(H, Lk, 128, generator=g).to(torch.bfloat16).to(DEV)
+    v = torch.randn(Lk, H, 128, generator=g).to(torch.bfloat16).to(DEV)
+    vt = K.v_transpose(v, 128, H * 128, Lk, H, 128, torch.bfloat16)
+    rstd = K.row_stats_finalize(pieces, dim, 1e-6, rms=True)
+    o0 = torch.empty(L, dim, dtype=torch.bfloat16, device=DEV)
+    o1 = torch.empty(L, dim, dtype=torch.bfloat16, device=DEV)
+    r0 = K.attn_16_qnorm(src, rstd, wn, kk, vt, None, o0, 128, dim, quant_out=quant_out)
+    r1 = K.attn_16_qnorm(src, (pieces, 1e-6), wn, kk, vt, None, o1, 128, dim, quant_out=quant_out)
+    if quant_out:
+        assert torch.equal(r0[0], r1[0]) and torch.equal(r0[1], r1[1])
+    else:
+        assert torch.isfinite(o0.float()).all() and torch.equal(o0, o1)
+
+
 @pytest.mark.parametrize("H,L", [(2, 300), (12, 1111), (3, 4100)])
 def test_linear_kv_pass_also_yields_the_smooth_k_mean(K, H, L):
     """td_sla_linear_kv with a km output: kvsum / ksum unchanged (bit for bit) and km == td_seq_mean(k) up to the

@@ -356,7 +356,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/turbodiffusion_amd.h but not exported"
         assert name in L.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.td_abi_version() == L.ABI_VERSION == 4
+    assert lib.td_abi_version() == L.ABI_VERSION == 5
 
 
 def test_ops_fail_loudly_without_gpu():

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("TD_LIB_PATH") or os.path.join(_HERE, "libturbodiffusi
 
 TD_F16, TD_BF16, TD_F32 = 0, 1, 2
 TD_EPI_NONE, TD_EPI_GELU_TANH = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 
@@ -80,6 +80,8 @@ SIGNATURES = {
     "td_rms_stats": [_vp, _i64, _i32, _vp, _f32, _i64, _i64, _vp],
     "td_attn_16_qnorm": [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32,
                          _vp, _vp, _vp, _vp],
+    "td_attn_16_qnorm_pieces": [_vp, _i64, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32,
+                                _vp, _vp, _vp, _vp],
     "td_attn_16_ex": [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i64, _i64, _f32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp],
     "td_sla_linear_out_t": [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp],
     "td_sla_linear_kv_partial": [_vp, _i32, _vp, _i32, _vp, _vp, _i64, _i32, _i32, _vp],

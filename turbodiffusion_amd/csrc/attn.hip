@@ -49,6 +49,11 @@ struct AttnParams {
   int64_t q_stride_h, q_stride_l;   // bytes; 0 = the packed [H, L, 128] layout
   const float* q_rstd;              // [L] 1/rms of the row over the FULL model dim (td_rms_stats), or null
   const float* q_w;                 // [H*128] RMSNorm weight
+  // round 6: instead of q_rstd, the row statistic formed HERE from the per-64-column pieces (mean, M2) the producing GEMM's STATS
+  // epilogue wrote — td_row_stats_finalize's arithmetic (mode 1) for the row this lane owns, without its launch
+  const float* q_pieces;            // float2 [L][q_npieces], or null
+  int q_npieces;
+  float q_inv_n, q_eps;
   const float* v_scale;             // FP8-PV instantiation: per-(h, d) channel scale of the e4m3 V tiles [H, 128]
   // sequence-parallel GATHERED layout (kbp > 0): the K side is the output of an all-gather, rank-major — K block kb lives
   // on rank r = kb / kbp as that rank's block kb % kbp: K rows at k + r*k_rs + (h*kbp*64 + ...)*row bytes, scales at
@@ -155,10 +160,29 @@ __global__ __launch_bounds__(256, (QK_I8 && !OCC2) ? 3 : 2) void attn_kernel(Att
 #pragma unroll
     for (int kc = 0; kc < NQ; ++kc) qf[kc] = *reinterpret_cast<const uint4*>(qp + kc * 32 + hi * 16);
     if constexpr (!QK_I8) {
-      if (p.q_rstd != nullptr) {
+      if (p.q_rstd != nullptr || p.q_pieces != nullptr) {
         // q = cast(rmsnorm(x) * w) exactly as td_qk_norm_rope computes it (no RoPE: cross-attention), applied to the 64
         // elements this lane holds — the head-major normalised copy of Q is never written
-        const float rs = p.q_rstd[qrow];
+        float rs;
+        if (p.q_pieces != nullptr) {
+          // row_stats_finalize_kernel (norm_quant.hip), mode 1, in ONE lane: its eight lanes' in-order partial sums over the
+          // pieces j, j + 8, ... (each piece contributes M2 + 64 mean^2), then its 3-step butterfly's association
+          // ((s0+s1)+(s2+s3)) + ((s4+s5)+(s6+s7)) — the same additions in the same order: the same bits
+          const float2* pc = reinterpret_cast<const float2*>(p.q_pieces) + (int64_t)qrow * p.q_npieces;
+          float sj[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            sj[j] = 0.f;
+            for (int pi = j; pi < p.q_npieces; pi += 8) {
+              const float2 v = pc[pi];
+              sj[j] += fmaf(64.0f * v.x, v.x, v.y);
+            }
+          }
+          const float qsum = ((sj[0] + sj[1]) + (sj[2] + sj[3])) + ((sj[4] + sj[5]) + (sj[6] + sj[7]));
+          rs = 1.0f / sqrtf(qsum * p.q_inv_n + p.q_eps);
+        } else {
+          rs = p.q_rstd[qrow];
+        }
 #pragma unroll
         for (int kc = 0; kc < NQ; ++kc) {
           const float* wp_ = p.q_w + h * 128 + kc * 16 + hi * 8;
@@ -960,6 +984,7 @@ static int attn_i8_impl(const int8_t* q_i8, const float* q_s, const int8_t* k_i8
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_heads = ga.q_heads > 0 ? ga.q_heads : H; p.q_ld = (int64_t)p.q_heads * 128;
   p.q_stride_h = 0; p.q_stride_l = 0; p.q_rstd = nullptr; p.q_w = nullptr; p.v_scale = v_scale;
+  p.q_pieces = nullptr; p.q_npieces = 0; p.q_inv_n = 0.f; p.q_eps = 0.f;
   p.kbp = ga.kbp; p.k_rs = ga.k_rs; p.v_rs = ga.v_rs; p.ks_rs = ga.ks_rs;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
@@ -1010,7 +1035,7 @@ static int attn_16_impl(const char* who, const void* q, int64_t q_stride_h, int6
                         const float* q_w, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
                         int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L, int64_t Lk,
                         int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale, td_stream_t stream,
-                        const AttnGather& ga = kFlat) {
+                        const AttnGather& ga = kFlat, const float* q_pieces = nullptr, int q_npieces = 0, float q_eps = 0.f) {
   int rc = attn_common_checks(who, q, k, vt, q_out ? (void*)q_out : o, nsel, L, Lk, H, lut);
   TD_REQUIRE((q_out == nullptr) == (q_scale == nullptr), TD_ERR_INVALID, "%s: q_out/q_scale mismatch", who);
   if (!q_out) { rc = attn_stride_check(who, o_stride_h, o_stride_l); if (rc) return rc; }
@@ -1021,6 +1046,7 @@ static int attn_16_impl(const char* who, const void* q, int64_t q_stride_h, int6
   p.o = (uint16_t*)o; p.o_stride_h = o_stride_h; p.o_stride_l = o_stride_l;
   p.add_t = (const uint16_t*)add_t; p.q_out = q_out; p.q_scale = q_scale; p.q_heads = ga.q_heads > 0 ? ga.q_heads : H; p.q_ld = (int64_t)p.q_heads * 128;
   p.q_stride_h = q_stride_h; p.q_stride_l = q_stride_l; p.q_rstd = q_rstd; p.q_w = q_w; p.v_scale = nullptr;
+  p.q_pieces = q_pieces; p.q_npieces = q_npieces; p.q_inv_n = q_npieces > 0 ? 1.0f / (float)((int64_t)q_npieces * 64) : 0.f; p.q_eps = q_eps;
   p.kbp = ga.kbp; p.k_rs = ga.k_rs; p.v_rs = ga.v_rs; p.ks_rs = ga.ks_rs;
   p.scale_log2 = sm_scale * 1.4426950408889634f;
   p.L = L; p.Lk = Lk; p.H = H; p.Qb = (int)td_cdiv(L, 128); p.Kb = (int)td_cdiv(Lk, 64); p.nsel = nsel;
@@ -1060,6 +1086,23 @@ extern "C" int td_attn_16_qnorm(const void* q_src, int64_t ld_q, const float* q_
   TD_REQUIRE(ld_q >= (int64_t)H * 128 && ld_q % 8 == 0, TD_ERR_INVALID, "td_attn_16_qnorm: ld_q=%lld", (long long)ld_q);
   return attn_16_impl("td_attn_16_qnorm", q_src, 256, ld_q * 2, q_rstd, q_w, k, vt, lut, nsel, o, dtype, o_stride_h,
                       o_stride_l, sm_scale, L, Lk, Lk_alloc, H, add_t, q_out, q_scale, stream);
+}
+
+
+// td_attn_16_qnorm with the row statistic taken from the STATS pieces of the GEMM that produced q_src (td_gemm_w8a8_stats:
+// float2 [L, n / 64] = (mean, M2) per 64-column piece, n = H * 128 here): == td_row_stats_finalize(mode 1) + td_attn_16_qnorm
+// bit for bit, one launch less per cross-attention (round 6).
+extern "C" int td_attn_16_qnorm_pieces(const void* q_src, int64_t ld_q, const float* stats_ws, int pieces, float eps,
+                                       const float* q_w, const void* k, const void* vt, const int32_t* lut, int nsel, void* o,
+                                       int dtype, int64_t o_stride_h, int64_t o_stride_l, float sm_scale, int64_t L,
+                                       int64_t Lk, int64_t Lk_alloc, int H, const void* add_t, int8_t* q_out, float* q_scale,
+                                       td_stream_t stream) {
+  TD_REQUIRE(stats_ws && q_w, TD_ERR_INVALID, "td_attn_16_qnorm_pieces: null statistics / weight");
+  TD_REQUIRE(pieces > 0 && pieces <= 128 && (int64_t)pieces * 64 == (int64_t)H * 128, TD_ERR_INVALID,
+             "td_attn_16_qnorm_pieces: pieces=%d for H=%d heads (need 64 * pieces == 128 * H: the statistic is over the full width)", pieces, H);
+  TD_REQUIRE(ld_q >= (int64_t)H * 128 && ld_q % 8 == 0, TD_ERR_INVALID, "td_attn_16_qnorm_pieces: ld_q=%lld", (long long)ld_q);
+  return attn_16_impl("td_attn_16_qnorm_pieces", q_src, 256, ld_q * 2, nullptr, q_w, k, vt, lut, nsel, o, dtype, o_stride_h,
+                      o_stride_l, sm_scale, L, Lk, Lk_alloc, H, add_t, q_out, q_scale, stream, kFlat, stats_ws, pieces, eps);
 }
 
 

@@ -64,17 +64,26 @@ template <int DT, int FM> __device__ __forceinline__ float sla_feature(float x) 
 // is written as 8-byte pieces (4 consecutive tokens of one channel are 4 consecutive MFMA positions).
 // ---------------------------------------------------------------------------------------
 template <int KDT, int VDT, bool WANT_KM, int FM = 0>
-__global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* __restrict__ k,
+__global__ __launch_bounds__(256, 3) void linear_kv_partial_kernel(const uint16_t* __restrict__ k,
                                                                 const uint16_t* __restrict__ vt,
                                                                 float* __restrict__ ws_kv,
                                                                 float* __restrict__ ws_ks,
                                                                 float* __restrict__ ws_km, int64_t L,
                                                                 int Kb, int Kb_alloc, int hg, int64_t gs) {
   // vt may live in the sequence-parallel pack (td_head_off, td_common.h): Kb_alloc tiles allocated per head, (hg, gs)
-  __shared__ __attribute__((aligned(16))) char ckT[128 * 128];  // [d1][64 positions] 16-bit
-  __shared__ __attribute__((aligned(16))) char vT[128 * 128];   // [d2][64 positions] 16-bit
-  __shared__ float ksred[16][128];
+  // Round 6: the pass ran at 0.35 of the HBM rate — 384 workgroups (32 chunks x 12 heads) of 228 VGPRs, two per CU, each a
+  // serial chain of [load 32 KB -> softmax -> LDS -> 16 MFMAs] with one tile of look-ahead staged through 16 VGPRs.  Now the V^T
+  // tile (16 KB, contiguous) arrives by LDS-DMA into a two-slot ring (no staging registers, no ds_write), the rounded
+  // softmax is kept packed, 48 KB of LDS and <= 168 VGPRs let THREE workgroups share a CU, and TD_SLA_NCH = 64 chunks per head
+  // give 768 of them at C1: one full round.
+  __shared__ __attribute__((aligned(16))) char ckT[128 * 128];      // [d1][64 positions] 16-bit
+  __shared__ __attribute__((aligned(16))) char vT1[128 * 128];      // [d2][64 positions] 16-bit, lane-linear DMA image: ONE buffer —
+  // the next tile's pieces are issued right behind the barrier that ends the MFMA phase and fly under the next softmax phase
+  __shared__ float kmred[WANT_KM ? 16 : 1][128];                    // the smooth-K column sums accumulate HERE (8 registers per lane
+  // more than the 168 three workgroups per CU allow: the compiler spilled 45 dwords and the pass took 130 us instead of 60)
+  float (*ksred)[128] = reinterpret_cast<float (*)[128]>(&vT1[0]);  // (after the loop: 16 x 128 floats)
   typedef typename MmaT<VDT>::frag frag;
+  typedef __attribute__((address_space(3))) void* lptr_k;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, hi = lane >> 5;
   const int c8 = tid & 15, tg = tid >> 4;
@@ -95,91 +104,103 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float ks_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  float km_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // plain column sums of k (rows past L are loaded as 0): the smooth-K mean
-
-  // The V^T tile (contiguous 16 KB) and this thread's 4 K rows of block kb+1 are requested as soon as block kb's copies
-  // have been consumed (V^T: after its LDS write; K: after the softmax) INTO THE SAME REGISTERS, so the HBM round trip
-  // runs under the softmax / MFMA phase without a second set of staging registers (a separate prefetch set spilled).
-  uint4 vv[4], kr[4];
+  // plain column sums of k (rows past L count as 0) -> the smooth-K mean: accumulated in LDS, slot [tg][8 c8 + j] is this lane's
+  // alone.  Measured on one box (tools/glue_bench.py, the whole entry point incl. its two finalisers): round 5's kernel (32 chunks,
+  // 228 VGPRs, two workgroups per CU, V^T staged through registers) 77.0 us with the mean, 65.7 without; this one 71.9 / 58.9;
+  // with the sums in 8 registers the compiler spills 45 dwords at 168 VGPRs (130 us), at two workgroups per CU 85 us, pairs of
+  // rows added first 77 us, LDS float atomics (ds_add_f32) 303 us.
+  if constexpr (WANT_KM) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    vv[i] = make_uint4(0, 0, 0, 0);
-    if (kb_lo < kb_hi)
-      vv[i] = *reinterpret_cast<const uint4*>(vt + td_head_off(h, hg, gs, (int64_t)Kb_alloc * (128 * 64)) + (int64_t)kb_lo * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
+    for (int j = 0; j < 8; ++j) kmred[tg][c8 * 8 + j] = 0.f;
   }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int64_t l = (int64_t)kb_lo * 64 + 4 * tg + t;
-    kr[t] = make_uint4(0, 0, 0, 0);
-    if (kb_lo < kb_hi && l < L) kr[t] = *reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8);
+  // V^T tile kb -> ring slot kb & 1: 16 pieces of 1 KB (8 rows x 128 B), wave w moves pieces w + 4t.  The LDS image of a piece
+  // is lane-linear, so the read side's bank swizzle (sw128) goes onto the global address; it does not depend on t (32 rows per
+  // step), so ONE address register serves the four pieces through the instruction's scalar offset.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(vt + td_head_off(h, hg, gs, (int64_t)Kb_alloc * (128 * 64))), 0, 0x7fffffff, 0x00020000);
+  const uint32_t v_off0 = (uint32_t)((8 * wave_u + (lane >> 3)) * 128 + (((lane & 7) ^ ((4 * wave_u + (lane >> 4)) & 7)) * 16));
+#define LK_VDMA(kb_)                                                                                       \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                            \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lptr_k)(&vT1[0] + (wave_u + 4 * t) * 1024), 16, v_off0, \
+                                             (uint32_t)(kb_) * 16384u + (uint32_t)t * 4096u, 0, 0);
+  // this thread's 4 K rows of a block: ALWAYS four load instructions per wave (rows past L re-read row L - 1 and are zeroed),
+  // so that the counts behind the s_waitcnt below are the same for every wave
+  uint4 kr[4];
+#define LK_KLOAD(kb_)                                                                                      \
+  _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                          \
+    int64_t l_ = (int64_t)(kb_) * 64 + 4 * tg + t;                                                         \
+    if (l_ > L - 1) l_ = L - 1;                                                                            \
+    kr[t] = *reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l_) * 128 + c8 * 8);                     \
+  }
+  if (kb_lo < kb_hi) {
+    LK_VDMA(kb_lo)
+    LK_KLOAD(kb_lo)
   }
   for (int kb = kb_lo; kb < kb_hi; ++kb) {
     const bool more = kb + 1 < kb_hi;
+    // softmax over D (16 lanes share a row), rounded to KDT, then to VDT: two rows at a time, kept PACKED (ckp[j][pair])
+    uint32_t ckp[8][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int v = tid + 256 * i;
-      *reinterpret_cast<uint4*>(vT + sw128(v >> 3, v & 7)) = vv[i];
-    }
-    if (more) {
+    for (int pr = 0; pr < 2; ++pr) {
+      float ck2[2][8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        vv[i] = *reinterpret_cast<const uint4*>(vt + td_head_off(h, hg, gs, (int64_t)Kb_alloc * (128 * 64)) + (int64_t)(kb + 1) * (128 * 64) + (int64_t)(tid + 256 * i) * 8);
-    }
-    // softmax over D (16 lanes share a row), rounded to KDT; ck[t][j]
-    float ck[4][8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const bool ok = (int64_t)kb * 64 + 4 * tg + t < L;
-      float f[8];
-      unpack8<KDT>(kr[t], f);
-      if constexpr (WANT_KM) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) km_acc[j] += f[j];
-      }
-      if constexpr (FM != 0) {   // elementwise feature map (already a 16-bit value), zero for rows past the end
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          ck[t][j] = ok ? sla_feature<KDT, FM>(f[j]) : 0.f;
-          ks_acc[j] += ck[t][j];
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * pr + u;
+        const bool ok = (int64_t)kb * 64 + 4 * tg + t < L;
+        float f[8];
+        if constexpr (WANT_KM) {   // (a row past L is a re-read of row L - 1: it must count as zeros in the column sums)
+          if (!ok) kr[t] = make_uint4(0, 0, 0, 0);
         }
-        continue;
+        unpack8<KDT>(kr[t], f);
+        if constexpr (WANT_KM) {   // (same order of additions per slot as a register accumulator: bit-identical sums)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) kmred[tg][c8 * 8 + j] += f[j];
+        }
+        if constexpr (FM != 0) {   // elementwise feature map (already a 16-bit value), zero for rows past the end
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            ck2[u][j] = ok ? sla_feature<KDT, FM>(f[j]) : 0.f;
+            ks_acc[j] += ck2[u][j];
+          }
+          continue;
+        }
+        float mx = f[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) mx = fmaxf(mx, f[j]);
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float mb = mx * TD_LOG2E;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { f[j] = __builtin_amdgcn_exp2f(fmaf(f[j], TD_LOG2E, -mb)); sum += f[j]; }
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float inv = ok ? __builtin_amdgcn_rcpf(sum) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const uint32_t w = pack2<KDT>(f[j] * inv, f[j + 1] * inv);  // softmax(...).to(dtype)
+          unpack2<KDT>(w, ck2[u][j], ck2[u][j + 1]);
+          ks_acc[j] += ck2[u][j];
+          ks_acc[j + 1] += ck2[u][j + 1];
+        }
       }
-      float mx = f[0];
 #pragma unroll
-      for (int j = 1; j < 8; ++j) mx = fmaxf(mx, f[j]);
-#pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-      const float mb = mx * TD_LOG2E;
-      float sum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { f[j] = __builtin_amdgcn_exp2f(fmaf(f[j], TD_LOG2E, -mb)); sum += f[j]; }
-#pragma unroll
-      for (int o = 8; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
-      const float inv = ok ? __builtin_amdgcn_rcpf(sum) : 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; j += 2) {
-        const uint32_t w = pack2<KDT>(f[j] * inv, f[j + 1] * inv);  // softmax(...).to(dtype)
-        unpack2<KDT>(w, ck[t][j], ck[t][j + 1]);
-        ks_acc[j] += ck[t][j];
-        ks_acc[j + 1] += ck[t][j + 1];
-      }
+      for (int j = 0; j < 8; ++j) ckp[j][pr] = pack2<VDT>(ck2[0][j], ck2[1][j]);
     }
-    if (more) {  // this thread's K rows of the next block (the current ones are consumed)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int64_t l = (int64_t)(kb + 1) * 64 + 4 * tg + t;
-        kr[t] = make_uint4(0, 0, 0, 0);
-        if (l < L) kr[t] = *reinterpret_cast<const uint4*>(k + ((int64_t)h * L + l) * 128 + c8 * 8);
-      }
-    }
+    if (more) { LK_KLOAD(kb + 1) }  // this thread's K rows of the next block (the current ones are consumed)
     // transposed write: for channel d1 = 8c8+j the 4 tokens are one 8-byte piece
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const uint32_t d1 = (uint32_t)(c8 * 8 + j);
-      *reinterpret_cast<uint2*>(ckT + sw128(d1, ck_slot) + ck_sub) =
-          make_uint2(pack2<VDT>(ck[0][j], ck[1][j]), pack2<VDT>(ck[2][j], ck[3][j]));
+      *reinterpret_cast<uint2*>(ckT + sw128(d1, ck_slot) + ck_sub) = make_uint2(ckp[j][0], ckp[j][1]);
     }
+    // this wave's pieces of tile kb are older than the K rows just consumed (loads return in order); younger and allowed to
+    // stay in flight: the next block's 4 K-row loads
+    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const char* vT = &vT1[0];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       frag a[2], b[2];
@@ -195,7 +216,10 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
         for (int j = 0; j < 2; ++j) acc[i][j] = MmaT<VDT>::mma(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
+    if (more) { LK_VDMA(kb + 1) }     // every wave has read tile kb's fragments: the buffer takes the next tile
   }
+#undef LK_VDMA
+#undef LK_KLOAD
   // partial kv: D[d1][d2], lane = d2 column, registers = d1 rows
   float* out = ws_kv + ((int64_t)h * LK_NCH + ch) * (128 * 128);
 #pragma unroll
@@ -219,13 +243,10 @@ __global__ __launch_bounds__(256) void linear_kv_partial_kernel(const uint16_t* 
   }
   if constexpr (WANT_KM) {  // first stage of td_seq_mean on the way (second stage: td_seq_mean_final over LK_NCH partials)
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) ksred[tg][c8 * 8 + j] = km_acc[j];
-    __syncthreads();
     if (tid < 128) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += ksred[r][tid];
+      for (int r = 0; r < 16; ++r) s += kmred[r][tid];
       ws_km[((int64_t)h * LK_NCH + ch) * 128 + tid] = s;
     }
   }

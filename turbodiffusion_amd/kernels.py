@@ -666,17 +666,29 @@ def rms_stats(src, n, eps):
 
 
 def attn_16_qnorm(q_src, rstd, w, k, vt, lut, out, o_stride_h, o_stride_l, sm_scale=None, lk=None, quant_out=False):
-    """attn_16 whose Q is a [L, H*128] linear output normalised on load (== attn_16(qk_norm_rope(q_src, w, no RoPE), ...))."""
-    require_gpu(q_src, rstd, w, k, vt, lut)
+    """attn_16 whose Q is a [L, H*128] linear output normalised on load (== attn_16(qk_norm_rope(q_src, w, no RoPE), ...)).
+    rstd: f32 [L] (rms_stats / row_stats_finalize), or a pair (ws, eps): the STATS partials f32 [L, H*128/64, 2] of the GEMM that
+    produced q_src — the statistic is then formed inside the kernel (td_attn_16_qnorm_pieces: no finaliser launch; same bits)."""
+    require_gpu(q_src, w, k, vt, lut)
     H, lk_alloc, D = k.shape
     L_ = q_src.shape[0]
     Lk = lk_alloc if lk is None else lk
     assert D == 128 and vt.dtype == q_src.dtype and q_src.stride(1) == 1
-    _f32c(w, "norm weight"), _f32c(rstd, "rstd")
+    _f32c(w, "norm weight")
     if sm_scale is None:
         sm_scale = 1.0 / math.sqrt(D)
     nsel = 0 if lut is None else lut.shape[-1]
     oq, os_ = _attn_quant_outputs(L_, H, q_src.device) if quant_out else (None, None)
+    if isinstance(rstd, tuple):
+        ws, eps = rstd
+        require_gpu(ws)
+        assert ws.dtype == torch.float32 and ws.is_contiguous() and tuple(ws.shape) == (L_, H * D // 64, 2)
+        call("td_attn_16_qnorm_pieces", ptr(q_src), q_src.stride(0), ptr(ws), ws.shape[1], float(eps), ptr(w), ptr(k), ptr(vt), ptr(lut),
+             nsel, None if quant_out else ptr(out), dt_code(q_src.dtype), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc,
+             H, None, ptr(oq), ptr(os_), stream_ptr())
+        return (oq, os_) if quant_out else out
+    require_gpu(rstd)
+    _f32c(rstd, "rstd")
     call("td_attn_16_qnorm", ptr(q_src), q_src.stride(0), ptr(rstd), ptr(w), ptr(k), ptr(vt), ptr(lut), nsel,
          None if quant_out else ptr(out), dt_code(q_src.dtype), o_stride_h, o_stride_l, float(sm_scale), L_, Lk, lk_alloc,
          H, None, ptr(oq), ptr(os_), stream_ptr())
@@ -684,7 +696,7 @@ def attn_16_qnorm(q_src, rstd, w, k, vt, lut, out, o_stride_h, o_stride_l, sm_sc
 
 
 # ----------------------------------------------------------------------------- a14
-SLA_NCH = 32  # TD_SLA_NCH in include/turbodiffusion_amd.h
+SLA_NCH = 64  # TD_SLA_NCH in include/turbodiffusion_amd.h
 
 
 FEATURE_MAPS = {"softmax": 0, "elu": 1, "relu": 2}

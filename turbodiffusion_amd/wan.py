@@ -185,6 +185,7 @@ class WanModel(nn.Module):
         self._ckv_all = None
         self.fuse_row_stats = True  # LayerNorm / cross-q RMSNorm row statistics from the producing GEMM's epilogue
         self.fuse_vt = True         # self-attention V leaves the q|k|v GEMM as the attention kernel's V^T tiles (K.gemm_w8a8_vt)
+        self.fuse_stats_finalize = True   # the row-statistics finalisers inside their consumers where that is possible (round 6)
         self.two_streams = True     # SageSLA self-attention: Q-side chain on a second stream beside the K-side chain (sla.py)
         self.split_qkv = True       # ... and the q|k|v projection as K|V then Q, the K-side chain under the Q GEMM (round 5)
         self.split_tokens = True    # everything after self-attention is token-local: two token halves on two streams (_block)
@@ -599,7 +600,9 @@ class WanModel(nn.Module):
         if isinstance(xn, tuple) and self.fuse_cross_q_norm and self._stats_ok(L_):
             # q projection whose epilogue also yields the RMSNorm statistic of its own output rows (no td_rms_stats pass)
             qc, ws = K.gemm_w8a8_stats(xn[0], xn[1], ca.q.int8_weight, ca.q.scale, ca.q.bias, out_dtype=context.dtype)
-            rstd = K.row_stats_finalize(ws, dim, self.eps, rms=True)
+            # round 6: the pieces go to the attention kernel as they are (td_attn_16_qnorm_pieces forms the row statistic on
+            # load, in td_row_stats_finalize's own order of additions): one launch less per cross-attention, the same bits
+            rstd = (ws, self.eps) if self.fuse_stats_finalize else K.row_stats_finalize(ws, dim, self.eps, rms=True)
         else:
             qc = self._lin_q(ca.q, xn[0], xn[1], context.dtype) if isinstance(xn, tuple) else self._lin(ca.q, xn)
         k, vt = kvt if kvt is not None else self._text_kvt(i, blk, context, text_kv)
