@@ -339,10 +339,19 @@ class SeqParallel:
         if me_src:
             buf = t if t.is_contiguous() else t.contiguous()
         else:
+            # ALIASING (documented contract): a receiving rank gets the SAME tensor object for a slot on every
+            # forward with that input signature — the previous forward's x / t / text of that slot is overwritten.  WanModel.forward
+            # consumes its inputs inside the call, so nothing outlives it; a caller that keeps a received tensor must clone it.
+            # At most 4 signatures per slot are kept (least recently used goes; a video server alternates a handful of shapes):
+            # an evicted text buffer only costs one payload broadcast + one text-cache miss when that signature returns.
             key = (slot, tuple(t.shape), t.dtype, str(t.device))
-            buf = self._bcast_bufs.get(key)
-            if buf is None:    # (one per distinct input signature; never evicted: the first rank's "unchanged" flag refers to it)
-                buf = self._bcast_bufs[key] = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+            buf = self._bcast_bufs.pop(key, None)
+            if buf is None:
+                buf = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+                mine = [k_ for k_ in self._bcast_bufs if k_[0] == slot]
+                if len(mine) >= 4:
+                    del self._bcast_bufs[mine[0]]          # dicts keep insertion order: the first is the least recently used
+            self._bcast_bufs[key] = buf                    # (re-inserted at the end: most recently used)
 
         def payload():
             if via_host:
@@ -431,6 +440,21 @@ class SeqParallel:
         # epilogue adds): on a
         # side stream beside the Q / K quantisers and the pack's exchange below (a graph branch under capture), joined before attention
         o_l = e_ol = e_early = None
+        pq = q_q = q_s = None
+        q_side_done = False
+
+        def q_side():
+            nonlocal pq, q_q, q_s, q_side_done
+            if sage:
+                pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
+            elif not dense:
+                pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
+            q_side_done = True
+        if linear and not on_streams:
+            # ONE stream (a segmented capture, the CPU rig): this rank's Q quantiser goes BETWEEN the issue of the early exchange
+            # and its wait, where the side-stream form puts it by construction (issue and wait back to back were two
+            # eager points around an empty graph segment, the exchange fully exposed)
+            q_side()
         if linear:
             if not merged:
                 alll, lin_work = self.all_gather(early[lay.early_sum:], async_op=True)      # [W, H*D + H*D*D]
@@ -454,11 +478,8 @@ class SeqParallel:
                 if st_l is not None:
                     e_ol = torch.cuda.Event()
                     e_ol.record(st_l)
-        pq = q_q = q_s = None
-        if sage:
-            pq, q_q, q_s = ops.sage_quant_pool(q, None, 128, want_pool=not dense)
-        elif not dense:
-            pq, _, _ = ops.sage_quant_pool(q, None, 128, want_quant=False)
+        if not q_side_done:
+            q_side()
         if allp is not None:
             if merged and linear and e_early is not None:
                 torch.cuda.current_stream().wait_event(e_early)
@@ -476,13 +497,18 @@ class SeqParallel:
         handles = [_Gather(self.group, torch.empty((W, lay.pieces[g][1]), dtype=torch.uint8, device=dev), lay.piece(pack, g), True)
                    for g in range(lay.G)]
 
+        seg = _graph._ACTIVE is not None
+
         def issue_all():   # ONE eager point (graph.py): all pieces' gathers
             for h in handles:
                 h.issue()
+            if seg:        # segmented capture: the first piece's wait rides in the same eager point (no empty segment between them)
+                handles[0]._wait()
         eager_point(issue_all)
         outs = [h.out for h in handles]
 
-        handles[0].wait()
+        if not seg:
+            handles[0].wait()
         # The attention / block-map kernels read the K side STRAIGHT from the all-gathers' rank-major outputs (the *_sp
         # entry points: block j = block j % kbp of rank j // kbp): no re-layout of the gathered K / V^T / scales / pooled K.
         topk = min(kb_tot, int(topk_ratio * kb_tot)) if not dense else 0
