@@ -886,7 +886,10 @@ static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, co
     constexpr int kind = QOUT ? 1 : (VT != 0 ? 2 : ((RES || STATS) ? 4 : 8));
     int w4 = td_tuning(TD_TUNE_GEMM_W4);
     if (w4 == 0) w4 = TD_GEMM_W4_DEFAULT;
-    if (v == 8 || (v == 0 && (w4 & kind) && m >= 1024))
+    // (a PLAIN launch as wide as a fused q|k|v projection — the sequence-parallel path's, which packs V itself — is the same
+    //  main loop as the V^T-epilogue one: 45.8 vs 55 us at m = 4096, profiles/r06_gemm_forms_m4096.txt, r06_timeline_emulated_rank_0_of_8.txt)
+    const bool wide_plain = kind == 8 && (w4 & 2) && n >= 3072;
+    if (v == 8 || (v == 0 && ((w4 & kind) || wide_plain) && m >= 1024))
       return launch_gemm_fi_range<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, FAST, STATS, VT, 8, 4>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate, 0, tm4);
     if (v == 0 && td_tuning(TD_TUNE_GEMM_COTENANT)) v = 4;   // beside another GEMM: a launch does not own the chip, whole tiles only
     const double c = (!QOUT && !RES && !STATS) ? 0.80 : 0.60;
