@@ -313,6 +313,15 @@ def test_turbo_diffusion_ops_compat_drives_the_reference_call_sequence(K):
     xq_ref, xs_ref = O.quant_block128(x.cpu())
     assert torch.equal(x_q.cpu(), xq_ref) and torch.equal(x_s.cpu(), xs_ref)
     assert ulp_diff_bf16(y, O.gemm_w8a8(xq_ref, xs_ref, w_q, w_s)).max().item() <= 1
+    # TurboT2AV's newer entry points (LTX-2 ltx_distillation/acceleration.py:753-769): the raster hints are accepted and ignored,
+    # the bias variant is Int8Linear's cast / + bias / cast
+    from turbo_diffusion_ops import gemm_cuda_swizzle, gemm_cuda_swizzle_bias
+    y2 = torch.zeros_like(y)
+    assert gemm_cuda_swizzle(x_q, x_s, w_q.to(DEV), w_s.to(DEV), y2, 1, 3) is None and torch.equal(y2, y)
+    bias = (torch.randn(264, generator=torch.Generator().manual_seed(9)) * 0.1).bfloat16().to(DEV)
+    y3 = torch.zeros_like(y)
+    gemm_cuda_swizzle_bias(x_q, x_s, w_q.to(DEV), w_s.to(DEV), y3, bias, 0, 0)
+    assert torch.equal(y3, (y.float() + bias.float()).bfloat16())
     # caller-provided outputs are written in place and returned
     oq, os_ = torch.empty_like(x_q), torch.empty_like(x_s)
     r = quant_cuda(x, oq, os_)

@@ -23,7 +23,7 @@ import torch
 from .. import kernels as K
 from .._lib import call, dt_code, ptr, require_gpu, stream_ptr
 
-__all__ = ["quant_cuda", "gemm_cuda", "rms_norm_cuda", "layer_norm_cuda"]
+__all__ = ["quant_cuda", "gemm_cuda", "gemm_cuda_swizzle", "gemm_cuda_swizzle_bias", "rms_norm_cuda", "layer_norm_cuda"]
 
 
 def quant_cuda(Input: torch.Tensor, Output: Optional[torch.Tensor] = None,
@@ -53,6 +53,33 @@ def gemm_cuda(A: torch.Tensor, A_S: torch.Tensor, B: torch.Tensor, B_S: torch.Te
     n = B.shape[0]
     assert B.shape[1] == k and C.shape == (m, n) and C.stride(1) == 1
     call("td_gemm_w8a8", ptr(A), ptr(A_S), ptr(B), ptr(B_S), None, ptr(C), dt_code(C.dtype), 0, m, n, k, C.stride(0),
+         stream_ptr())
+
+
+def gemm_cuda_swizzle(A: torch.Tensor, A_S: torch.Tensor, B: torch.Tensor, B_S: torch.Tensor, C: torch.Tensor,
+                      swizzle_dir: int = 0, swizzle_log: int = 0) -> None:
+    """The call TurboT2AV's ``_TurboDiffusionInt8Linear`` makes (LTX-2 ``ltx_distillation/acceleration.py:753-769``; the
+    binding is newer than ``ops/bindings.cpp`` in the reference tree — API drift).  ``swizzle_dir`` /
+    ``swizzle_log`` are the CUTLASS threadblock-raster hint of that kernel: results do not depend on them, and this
+    library's raster is chosen per launch (XCD-aware m-grouped walk, csrc/gemm_w8a8_fi.hip) — accepted and ignored."""
+    gemm_cuda(A, A_S, B, B_S, C)
+
+
+def gemm_cuda_swizzle_bias(A: torch.Tensor, A_S: torch.Tensor, B: torch.Tensor, B_S: torch.Tensor, C: torch.Tensor,
+                           bias: torch.Tensor, swizzle_dir: int = 0, swizzle_log: int = 0) -> None:
+    """``gemm_cuda_swizzle`` with the bias in the epilogue: C = cast(cast(acc) + bias), the rounding sequence of
+    ``Int8Linear.forward`` (ops/core.py:408-412: the GEMM result is rounded to the activation dtype, the bias add rounds again)
+    — the source of the fused kernel is not in the reference tree, so this is the unfused module's arithmetic."""
+    require_gpu(A, A_S, B, B_S, C, bias)
+    if C.dtype not in (torch.float16, torch.bfloat16):
+        raise RuntimeError("Unsupported output data type for int8 gemm.")
+    assert A.dtype == torch.int8 and B.dtype == torch.int8 and A_S.dtype == torch.float32 and B_S.dtype == torch.float32
+    assert A.is_contiguous() and B.is_contiguous() and A_S.is_contiguous() and B_S.is_contiguous()
+    m, k = A.shape
+    n = B.shape[0]
+    assert B.shape[1] == k and C.shape == (m, n) and C.stride(1) == 1
+    assert bias.dtype == C.dtype and bias.shape == (n,) and bias.is_contiguous()
+    call("td_gemm_w8a8", ptr(A), ptr(A_S), ptr(B), ptr(B_S), ptr(bias), ptr(C), dt_code(C.dtype), 0, m, n, k, C.stride(0),
          stream_ptr())
 
 
