@@ -114,6 +114,8 @@ def main():
                     else:
                         out = fn()
                     out = [t.clone() for t in (out if isinstance(out, tuple) else (out,))]
+                    if name == "qkv":     # (the V columns of d are not written by the V^T epilogue: compare what is)
+                        out[0] = out[0][:, :2 * dim].clone()
                     same = None
                     if fast in ref:
                         same = all(torch.equal(p.view(torch.uint8), q.view(torch.uint8)) for p, q in zip(ref[fast], out))
