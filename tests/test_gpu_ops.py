@@ -452,7 +452,7 @@ def test_gemm_vt_epilogue_is_gemm_plus_v_transpose(K, m, dim, k, dt, vt_dt):
 
 # ---------------------------------------------------------------- round 5: the 128-row form of the LDS-DMA kernel (NI = 4)
 @pytest.mark.parametrize("m,n,k", [(4096, 1536, 1536), (4000, 1544, 384), (2100, 512, 256), (4096, 1536, 8960), (1100, 4608, 1536),
-                                   (4096, 8960, 1536)])
+                                   (4096, 8960, 1536), (300, 272, 256), (129, 768, 128), (77, 64, 640)])
 def test_gemm_128_row_tile_form_is_bit_identical(K, m, n, k):
     """TD_TUNE_GEMM_VARIANT = 6 forces the 128 x 256 tile (csrc/gemm_w8a8_fi.hip, NI = 4: the eight waves on 64 x 64 each) — the
     form the per-rank GEMMs of a sequence shard take automatically: every epilogue (plain + GELU, gated / plain residual,
