@@ -427,7 +427,7 @@ def main():
                     "fp8 MFMA)")
     ap.add_argument("--gemm-fast", type=int, default=0, choices=[0, 2, 4, 8], help="W8A8 GEMM one-VALU dequant, re-centred "
                     "every G K blocks (bounded difference to the exact arithmetic, csrc/gemm_w8a8_fi.hip); 0 = the library's "
-                    "default (round 6: G = 4)")
+                    "default (round 6: G = 8)")
     ap.add_argument("--gemm-exact", action="store_true", help="W8A8 GEMM with the reference's exact dequant (ops/gemm/utils.hpp:116-121: "
                     "two VALU per element and K block) instead of the library's default one-VALU form — the A/B arm of "
                     "profiles/r06_fast_dequant_ab.txt")
@@ -1007,7 +1007,7 @@ def main():
             "vs_baseline": (value * PUBLISHED_S[(args.model, args.res)]) if (
                 args.workload == "turbo" and (args.model, args.res) in PUBLISHED_S and not args.layers
                 and args.num_steps == 4) else None,
-            "dtype": (f"int8 (W8A8 linears, {'exact dequant' if args.gemm_exact else 'one-VALU dequant G=%d' % (args.gemm_fast or 4)}, QK^T) + "
+            "dtype": (f"int8 (W8A8 linears, {'exact dequant' if args.gemm_exact else 'one-VALU dequant G=%d' % (args.gemm_fast or 8)}, QK^T) + "
                       f"{args.sage_pv} PV + bf16 activations") if wl["quant_linear"] else f"bf16 (+int8 QK^T, {args.sage_pv} PV)",
             "data": "synthetic (seeded N(0,1) latents/text embedding, random-init weights of the named architecture)",
             "config": {"workload": wl["desc"].replace("Wan2.1-T2V-1.3B 480p", f"{args.model} {args.res}").replace(

@@ -69,7 +69,7 @@ const char* td_last_error(void);
 #define TD_TUNE_GEMM_SCHED 4   /* variant 5: bit 0 = barrier one chain earlier + refill spread over two chains, bit 1 = s_setprio for the
                                   younger half-workgroup (bit-identical results); variant 4: 1 = early LDS-DMA, 2 = L2 prefetch */
 #define TD_TUNE_ATTN_TAU 5     /* attention: lazy running-max threshold in log2 units (0 = default 8, -1 = eager online softmax) */
-#define TD_TUNE_GEMM_FAST 6     /* W8A8 GEMM dequant: 0 = build default (round 6: G = 4; TD_GEMM_EXACT=1 in the environment makes it exact),
+#define TD_TUNE_GEMM_FAST 6     /* W8A8 GEMM dequant: 0 = build default (round 6: G = 8, the period instantiated for every epilogue and tile form; TD_GEMM_EXACT=1 in the environment makes it exact),
                                   1 = exact (bit-identical to the reference arithmetic, ops/gemm/utils.hpp:116-121),
                                   G in {2,4,8} = one-VALU dequant re-centred every G K blocks (|diff| <= 0.75 (G+1) sum_k s_k in the fp32
                                   accumulator: one bf16 rounding step on 1-8 % of the outputs).  bf16 + bias launches of the LDS-DMA kernels

@@ -471,7 +471,7 @@ def test_gemm_128_row_tile_form_is_bit_identical(K, m, n, k):
     for variant in (4, 6, 8, 0, 104, 108):      # 0: the automatic plan — for (4096, 8960, 1536) the MIXED one (two rounds of 256-row tiles + 128-row tiles)
         # 8 (round 6): the FOUR-wave form (128 x 256 tile, two workgroups per CU); 104 / 108: forms 4 / 8 with the one-VALU dequant
         K.set_tuning(K.TUNE_GEMM_VARIANT, variant % 100)
-        K.set_tuning(K.TUNE_GEMM_FAST, 4 if variant >= 100 else 1)
+        K.set_tuning(K.TUNE_GEMM_FAST, 8 if variant >= 100 else 1)     # (8: the period whose instantiations cover every epilogue and form)
         try:
             r = {"plain": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b), "gelu": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16, bias=b, gelu_tanh=True),
                  "nobias": K.gemm_w8a8(aq, as_, wq, ws, torch.bfloat16),

@@ -24,8 +24,8 @@ extern "C" int td_set_tuning(int key, int value) {
   return TD_OK;
 }
 
-// W8A8 GEMM dequant mode (TD_TUNE_GEMM_FAST).  Round 6: the BUILD DEFAULT is the one-VALU form re-centred every 4 K blocks
-// (csrc/gemm_w8a8_fi.hip: |difference to the exact form| <= 3.75 sum_k s_k in the fp32 accumulator, i.e. one bf16 rounding step
+// W8A8 GEMM dequant mode (TD_TUNE_GEMM_FAST).  Round 6: the BUILD DEFAULT is the one-VALU form re-centred every 8 K blocks
+// (csrc/gemm_w8a8_fi.hip: |difference to the exact form| <= 6.75 sum_k s_k in the fp32 accumulator, i.e. one bf16 rounding step
 // on 1-8 % of the outputs; inside SURVEY.md 8(d)'s "<= 1 bf16 ulp" and the reference's own --use_fast_math build; measured
 // -7 % joules per launch, +3.2 % videos/s on the same box, profiles/r06_fast_dequant_ab.txt).  The reference's exact
 // arithmetic (ops/gemm/utils.hpp:116-121: int32 -> fp32, then one fma per K block) stays selectable: td_set_tuning(
@@ -34,7 +34,7 @@ int td_gemm_fast_g(void) {
   const int v = g_tuning[TD_TUNE_GEMM_FAST];
   if (v == 0) {
     static const int env_exact = [] { const char* e = getenv("TD_GEMM_EXACT"); return (e && e[0] && e[0] != '0') ? 1 : 0; }();
-    return env_exact ? 0 : 4;
+    return env_exact ? 0 : 8;
   }
   return (v == 2 || v == 4 || v == 8) ? v : 0;
 }

@@ -46,6 +46,12 @@
 // measured end to end on one box (profiles/r06_fast_dequant_ab.txt, three interleaved repetitions, one-VALU dequant in every arm):
 // no four-wave launches 3.227 videos/s, the fused-quantiser GEMM (ffn.0) on it 3.257, + the q|k|v GEMM 3.256, every GEMM 3.221
 #define TD_GEMM_W4_DEFAULT 3
+// the re-centring period whose instantiations cover EVERY epilogue and tile form (the run-time twin of the exact kernel and the
+// library default, csrc/capi.hip); the other periods (2, 4 | 8) exist for the plain / fused-quantiser / residual epilogues of the
+// 256 x 256 tile only (tests, A/B)
+#ifndef TD_GEMM_FAST_TWIN
+#define TD_GEMM_FAST_TWIN 8
+#endif
 #define F_MAGIC_I 0x4B400000
 #define F_MAGIC_F 12582912.0f
 
@@ -369,7 +375,9 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_w8a8_fi_kernel(
   for (int u = 0; u < UNR; ++u) {
     const int kb = kb0 + u;
     if (UNR > 1 && kb >= nk) break;
-    const bool recentre = FAST > 0 && u == UNR - 1;
+    // (no re-centring in the LAST K block: the drain takes everything that still rides on the accumulators out anyway — for
+    //  K = 1536 that is one add per element less out of 17, round 6)
+    const bool recentre = FAST > 0 && u == UNR - 1 && kb + 1 < nk;
     if constexpr (FAST > 0) {
       if (recentre) {
         const float c_hi = (float)c_sum;
@@ -466,15 +474,10 @@ __global__ __launch_bounds__(NW * 64, 2) void gemm_w8a8_fi_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) { F_ADD4(t[1][j]) }
   }
-  if constexpr (FAST > 0) {
-    // every row group takes a re-centring add right BEFORE the fmac of the re-centring block's own sums — for the last row
-    // group that fmac sits in the next block's first group (or here): the same order of roundings for every output element
-    // whatever the tile form (NI = 4 | 8, eight | four waves), i.e. the one-VALU mode is bit-identical across the launch plans too
-    if (nk % UNR == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { F_ADDC4(accf[NI - 1][j], c_neg) }
-    }
-  }
+  // (FAST: every row group takes a re-centring add right BEFORE the fmac of the re-centring block's own sums — for the last row
+  //  group that fmac sits in the NEXT block's first group, and a re-centring block always has a next block: the same order of
+  //  roundings for every output element whatever the tile form (NI = 4 | 8, eight | four waves), i.e. the one-VALU mode is
+  //  bit-identical across the launch plans too)
 #pragma unroll
   for (int j = 0; j < 4; ++j) { F_FMAC4(accf[NI - 1][j], t[1][j], sc_old) }
   if constexpr (FAST > 0) {
@@ -869,18 +872,18 @@ static int launch_gemm_fi_range(const int8_t* a, const float* a_s, const int8_t*
 // the cheapest wins; (c) must beat the better of (a) / (b) by 5 % to pay for its second launch.  Bit-identical whatever the
 // plan.  TD_TUNE_GEMM_VARIANT = 4 forces (a), 6 forces (b), 7 allows only (a) / (b), 8 forces the four-wave form (128-row tiles,
 // two workgroups per CU).
-// Round 6: the dequant mode is a run-time choice for EVERY epilogue (td_gemm_fast_g() == 4 re-dispatches the exact
+// Round 6: the dequant mode is a run-time choice for EVERY epilogue (td_gemm_fast_g() == TD_GEMM_FAST_TWIN re-dispatches the exact
 // instantiation's call to its FAST = 4 twin; bf16 + bias — the model's linears); the plans apply to both modes.
 template <int ODT, int EPI, bool HAS_BIAS, int DBG = 0, int SCHED = 0, bool QOUT = false, bool RES = false, int FAST = 0, bool STATS = false, int VT = 0, int NI = 8>
 static int launch_gemm_fi(const int8_t* a, const float* a_s, const int8_t* b, const float* b_s,
                           const void* bias, void* d, int64_t m, int64_t n, int64_t k, int64_t ldd,
                           hipStream_t st, float* qs = nullptr, int64_t ldqs = 0, const float* gate = nullptr) {
   if constexpr (DBG == 0 && SCHED == 0 && FAST == 0 && ODT == TD_BF16 && HAS_BIAS) {
-    if (td_gemm_fast_g() == 4)
-      return launch_gemm_fi<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, 4, STATS, VT, NI>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate);
+    if (td_gemm_fast_g() == TD_GEMM_FAST_TWIN)
+      return launch_gemm_fi<ODT, EPI, HAS_BIAS, 0, 0, QOUT, RES, TD_GEMM_FAST_TWIN, STATS, VT, NI>(a, a_s, b, b_s, bias, d, m, n, k, ldd, st, qs, ldqs, gate);
   }
   const int tm8 = (int)td_cdiv(m, 256), tm4 = (int)td_cdiv(m, 128), tn = (int)td_cdiv(n, F_BN);
-  if constexpr (DBG == 0 && SCHED == 0 && (FAST == 0 || FAST == 4)) {
+  if constexpr (DBG == 0 && SCHED == 0 && (FAST == 0 || FAST == TD_GEMM_FAST_TWIN)) {
     int v = td_tuning(TD_TUNE_GEMM_VARIANT);
     // the four-wave form by epilogue kind (TD_TUNE_GEMM_W4; profiles/r06_gemm_forms_*.txt, r06_w4_ab.txt)
     constexpr int kind = QOUT ? 1 : (VT != 0 ? 2 : ((RES || STATS) ? 4 : 8));
