@@ -5,7 +5,7 @@ is paid back by the kernels after it, profiles/NOTES_r03.md).
     python tools/gemm_forms.py [--rows 32760] [--forms 4,8] [--fast 1,4] [--seconds 1.0] [--only ffn2,crossq]
 
 form = TD_TUNE_GEMM_VARIANT (4: eight waves, 256 x 256 tile; 6: eight waves, 128 x 256; 8: FOUR waves, 128 x 256, two
-workgroups per CU; 0: the launch planner), fast = TD_TUNE_GEMM_FAST (1 exact, 4 one-VALU dequant).  One JSON line per
+workgroups per CU; 0: the launch planner), fast = TD_TUNE_GEMM_FAST (1 exact, 8 one-VALU dequant: the period instantiated for every epilogue).  One JSON line per
 (GEMM, form, fast); a summary table at the end.  Also checks that every form gives the bits of form 4 (per dequant mode).
 """
 import argparse
@@ -59,7 +59,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=32760)
     ap.add_argument("--forms", default="4,8")
-    ap.add_argument("--fast", default="1,4")
+    ap.add_argument("--fast", default="1,8")
     ap.add_argument("--seconds", type=float, default=1.0)
     ap.add_argument("--only", default="")
     ap.add_argument("--dim", type=int, default=1536)

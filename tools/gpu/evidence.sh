@@ -76,8 +76,8 @@ if has emu; then      # the emulated-rank table (per-rank compute measured, wire
   grep '^{' gpurun_out/rccl_one_rank_$T.log | python -c "import sys,json; r=json.loads(sys.stdin.readline()); print('RCCL one rank: %.2f ms per DiT step; rccl record: %s; exposed_wait: %s' % (r['dit_step_ms'], json.dumps(r.get('rccl')), json.dumps(r.get('exposed_wait'))))" | cut -c1-900 | tee gpurun_out/rccl_one_rank_$T.txt
 fi
 if has gemm; then     # the block's six GEMMs on every tile form / dequant mode: us + J per launch, C1's rows and an eighth of them
-  timeout 900 python tools/gemm_forms.py --forms 4,8 --fast 1,4 > gpurun_out/gemm_forms_$T.txt 2>&1; tail -26 gpurun_out/gemm_forms_$T.txt
-  timeout 600 python tools/gemm_forms.py --rows 4096 --forms 0,4,6,8 --fast 4 --seconds 0.5 > gpurun_out/gemm_forms_m4096_$T.txt 2>&1; tail -24 gpurun_out/gemm_forms_m4096_$T.txt
+  timeout 900 python tools/gemm_forms.py --forms 4,8 --fast 1,8 > gpurun_out/gemm_forms_$T.txt 2>&1; tail -26 gpurun_out/gemm_forms_$T.txt
+  timeout 600 python tools/gemm_forms.py --rows 4096 --forms 0,4,6,8 --fast 8 --seconds 0.5 > gpurun_out/gemm_forms_m4096_$T.txt 2>&1; tail -24 gpurun_out/gemm_forms_m4096_$T.txt
 fi
 if has ab; then       # same-box A/B: exact dequant | one-VALU | + four-wave form for ffn.0 | + q|k|v (the default) | every GEMM
   TAG=fast_dequant_ab_$T REPS=3 bash tools/gpu/ab.sh "--gemm-exact --tune 13=16" "--tune 13=16" "--tune 13=1" "" "--tune 13=15"
